@@ -1,0 +1,174 @@
+"""Deterministic synthetic inputs for the GigaPose hot path.
+
+numpy RandomState streams only (bit-stable across machines), so the golden fixtures in
+tests/golden/ store OUTPUTS plus an input checksum instead of megabytes of inputs.
+Used by tests/, bench.py, __graft_entry__.smoke() and oracle/make_goldens.py.
+"""
+import hashlib
+
+import numpy as np
+
+P = 256
+G = 16
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # reference configs/data/transform.yaml:6
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)    # reference configs/data/transform.yaml:7
+TEMPLATE_K = np.array([[572.4114, 0.0, 320.0], [0.0, 573.57043, 240.0], [0.0, 0.0, 1.0]],
+                      dtype=np.float32)             # reference template_dataset.py:194-196
+
+
+def checksum(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode() + str(a.shape).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()[:16]
+
+
+def _unit(x, axis):
+    n = np.sqrt((x.astype(np.float64) ** 2).sum(axis=axis, keepdims=True))
+    return (x / np.maximum(n, 1e-12)).astype(np.float32)
+
+
+def _smooth_field(rs, C, coarse=4, fine=0.6):
+    """(C,16,16) field: bilinear-upsampled coarse noise + per-patch noise (neighbouring patches
+    are correlated, so several template patches compete above the 0.5 threshold)."""
+    c = rs.standard_normal((C, coarse, coarse)).astype(np.float32)
+    xs = np.linspace(0, coarse - 1, G)
+    i0 = np.floor(xs).astype(int).clip(0, coarse - 2)
+    w = (xs - i0).astype(np.float32)
+    rows = c[:, i0, :] * (1 - w)[None, :, None] + c[:, i0 + 1, :] * w[None, :, None]
+    up = rows[:, :, i0] * (1 - w)[None, None, :] + rows[:, :, i0 + 1] * w[None, None, :]
+    return up + fine * rs.standard_normal((C, G, G)).astype(np.float32)
+
+
+def disc_mask(rs, size=224, include_origin=None):
+    """Random disc / rectangle {0,1} mask with partially covered patches.  `include_origin`
+    forces pixel (0,0) (= patch 0's sample point, matching.py nearest rule) in or out."""
+    yy, xx = np.mgrid[0:size, 0:size]
+    if rs.rand() < 0.5:
+        cx, cy = rs.uniform(70, 154, 2)
+        r = rs.uniform(60, 105)
+        m = ((xx - cx) ** 2 + (yy - cy) ** 2) <= r * r
+    else:
+        x0, y0 = rs.randint(0, 60, 2)
+        x1, y1 = rs.randint(150, 224, 2)
+        m = (xx >= x0) & (xx < x1) & (yy >= y0) & (yy < y1)
+    m = m.astype(np.float32)
+    if include_origin is True:
+        m[:20, :20] = 1.0
+    elif include_origin is False:
+        m[:14, :14] = 0.0
+    return m
+
+
+def matcher_case(seed, B, O, N, C, noise=0.35, shift=True, full_masks=False):
+    """Feature-level inputs for LocalSimilarity.test with planted, graded matches.
+
+    Template n of object o = unit(w_n * field_o rolled by (dy_n,dx_n) + (1-w_n) * noise_n) so
+    templates score differently (no top-k ties); query b = unit(field_{o_b} + noise).
+    Returns dict(src_feats (O,N,C,16,16), tar_feat (B,C,16,16), src_masks (O,N,224,224),
+    tar_mask (B,224,224), labels (B,) 0-based int32).
+    """
+    rs = np.random.RandomState(seed)
+    fields = np.stack([_smooth_field(rs, C) for _ in range(O)])
+    src = np.empty((O, N, C, G, G), np.float32)
+    for o in range(O):
+        ws = np.linspace(1.0, 0.55, N)
+        rs.shuffle(ws)
+        for n in range(N):
+            f = fields[o]
+            if shift:
+                dy, dx = rs.randint(-2, 3, 2)
+                f = np.roll(f, (int(dy), int(dx)), axis=(1, 2))
+            t = ws[n] * _unit(f, 0) + (1 - ws[n]) * 1.4 * _unit(rs.standard_normal((C, G, G)), 0)
+            src[o, n] = _unit(t, 0)
+    labels = rs.randint(0, O, B).astype(np.int32)
+    tar = np.empty((B, C, G, G), np.float32)
+    for b in range(B):
+        t = _unit(fields[labels[b]], 0) + noise * _unit(rs.standard_normal((C, G, G)), 0)
+        tar[b] = _unit(t, 0)
+    if full_masks:
+        src_masks = np.ones((O, N, 224, 224), np.float32)
+        tar_mask = np.ones((B, 224, 224), np.float32)
+    else:
+        src_masks = np.stack([np.stack([disc_mask(rs, include_origin=[None, True, False][(o + n) % 3])
+                                        for n in range(N)]) for o in range(O)])
+        tar_mask = np.stack([disc_mask(rs, include_origin=[True, False, None][b % 3]) for b in range(B)])
+    return dict(src_feats=src, tar_feat=tar, src_masks=src_masks, tar_mask=tar_mask, labels=labels)
+
+
+def random_features(seed, B, O, N, C):
+    """Unstructured bench-scale features (values only matter for timing, not for matching)."""
+    rs = np.random.RandomState(seed)
+    bank = _unit(rs.standard_normal((O, N, C, P)).astype(np.float32), 2)
+    q = _unit(rs.standard_normal((B, C, P)).astype(np.float32), 1)
+    return bank, q
+
+
+def template_images(seed, N, size=224):
+    """Templates: low-frequency noise (16x16 N(0,1) bilinear-upsampled) x disc mask radius 100."""
+    rs = np.random.RandomState(seed)
+    coarse = rs.standard_normal((N, 3, G, G)).astype(np.float32)
+    xs = np.linspace(0, G - 1, size)
+    i0 = np.floor(xs).astype(int).clip(0, G - 2)
+    w = (xs - i0).astype(np.float32)
+    rows = coarse[:, :, i0, :] * (1 - w)[None, None, :, None] + coarse[:, :, i0 + 1, :] * w[None, None, :, None]
+    up = rows[:, :, :, i0] * (1 - w) + rows[:, :, :, i0 + 1] * w
+    yy, xx = np.mgrid[0:size, 0:size]
+    mask = (((xx - size / 2) ** 2 + (yy - size / 2) ** 2) <= 100.0 ** 2).astype(np.float32)
+    masks = np.broadcast_to(mask, (N, size, size)).copy()
+    return (up * masks[:, None]).astype(np.float32), masks
+
+
+def query_crops(seed, templates, masks, choose, noise=0.1):
+    """Crops = chosen template + noise, times its mask."""
+    rs = np.random.RandomState(seed)
+    imgs = templates[choose] + noise * rs.standard_normal(templates[choose].shape).astype(np.float32)
+    return (imgs * masks[choose][:, None]).astype(np.float32), masks[choose].copy()
+
+
+def crop_geometry(seed, B):
+    """tar_K (f in [500,1200]) and tar_M = isotropic scale in [0.3,3] + translation
+    (satisfies the asserts of reference lib3d/torch.py:54-55)."""
+    rs = np.random.RandomState(seed)
+    K = np.zeros((B, 3, 3), np.float32)
+    f = rs.uniform(500, 1200, B)
+    K[:, 0, 0] = f
+    K[:, 1, 1] = f * rs.uniform(0.98, 1.02, B)
+    K[:, 0, 2] = rs.uniform(280, 360, B)
+    K[:, 1, 2] = rs.uniform(200, 280, B)
+    K[:, 2, 2] = 1
+    M = np.zeros((B, 3, 3), np.float32)
+    s = rs.uniform(0.3, 3.0, B)
+    M[:, 0, 0] = s
+    M[:, 1, 1] = s
+    M[:, 0, 2] = rs.uniform(-300, 50, B)
+    M[:, 1, 2] = rs.uniform(-300, 50, B)
+    M[:, 2, 2] = 1
+    return K, M
+
+
+def template_geometry(seed, O, N):
+    """Template crop transforms M (O,N,3,3), intrinsics K (O,3,3) and poses (O,N,4,4):
+    orthonormal R looking at the origin from an icosphere-like direction, |t| = 400
+    (reference uses obj_poses_level1.npy * 0.4, render_bop_templates.py:69-70)."""
+    rs = np.random.RandomState(seed)
+    K = np.broadcast_to(TEMPLATE_K, (O, 3, 3)).copy()
+    M = np.zeros((O, N, 3, 3), np.float32)
+    s = rs.uniform(0.8, 2.5, (O, N))
+    M[..., 0, 0] = s
+    M[..., 1, 1] = s
+    M[..., 0, 2] = rs.uniform(-400, -50, (O, N))
+    M[..., 1, 2] = rs.uniform(-300, -20, (O, N))
+    M[..., 2, 2] = 1
+    poses = np.zeros((O, N, 4, 4), np.float32)
+    for o in range(O):
+        for n in range(N):
+            q, _ = np.linalg.qr(rs.standard_normal((3, 3)))
+            if np.linalg.det(q) < 0:
+                q[:, 0] = -q[:, 0]
+            poses[o, n, :3, :3] = q
+            poses[o, n, :3, 3] = [rs.uniform(-20, 20), rs.uniform(-20, 20), rs.uniform(350, 450)]
+            poses[o, n, 3, 3] = 1
+    return K, M, poses

@@ -1,0 +1,156 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of gigapose_amd.
+//
+// Everything here is written for wave64 + the f32-input matrix core
+// (v_mfma_f32_32x32x2_f32): exact f32, bit-for-bit a k-ordered fmaf chain when k-pairs are
+// issued in ascending order -- which is what makes index outputs reproducible against the
+// CPU oracle (oracle/gp_oracle.c).  Build with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GP_OK 0
+#define GP_EINVAL -1
+#define GP_ELAUNCH -2
+
+#define GP_P 256  // patches per crop (16x16)
+#define GP_G 16
+
+// set by every entry point on failure; read through gp_last_error()
+void gp_set_error(const char* fmt, ...);
+
+#define GP_REQUIRE(cond, ...)             \
+    do {                                  \
+        if (!(cond)) {                    \
+            gp_set_error(__VA_ARGS__);    \
+            return GP_EINVAL;             \
+        }                                 \
+    } while (0)
+
+#define GP_CHECK_LAUNCH(name)                                                   \
+    do {                                                                        \
+        hipError_t e_ = hipGetLastError();                                      \
+        if (e_ != hipSuccess) {                                                 \
+            gp_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return GP_ELAUNCH;                                                  \
+        }                                                                       \
+    } while (0)
+
+// MFMA 32x32x2 f32 C/D fragment map (guide section 3): lane l, register r in [0,16):
+//   col = l & 31,  row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// XCD-aware, bijective-by-construction tile order: hardware places block id on XCD id % 8,
+// so give each XCD one contiguous chunk of the tile list (neighbours share operand panels in
+// that XCD's private L2).  Returns -1 for padding blocks (grid = 8 * ceil(total / 8)).
+__device__ __forceinline__ int xcd_chunked_tile(int block_id, int total)
+{
+    const int per = (total + 7) >> 3;
+    const int q = (block_id & 7) * per + (block_id >> 3);
+    return (q < total && (block_id >> 3) < per) ? q : -1;
+}
+static inline int xcd_chunked_grid(int total) { return 8 * ((total + 7) / 8); }
+
+// ---------------------------------------------------------------------------------------------
+// k-major f32 MFMA main loop.
+//   D[i][j] = sum_k A[k][i] * B[k][j],  A: [K][lda] (i contiguous), B: [K][ldb] (j contiguous)
+// Block tile BM x BN = (WM*MI*32) x (WN*NI*32); WM*WN waves; wave (wm, wn) owns MI x NI MFMA
+// tiles.  K is consumed in slabs of KS rows staged through LDS (double buffered, one barrier per
+// slab); global loads of slab s+1 are in flight while slab s feeds the matrix core.
+// Per lane the k index of an MFMA operand is 2*kk + (lane >> 5): ascending k-pairs => the
+// accumulator is exactly  acc = fmaf(A[k][i], B[k][j], acc)  for k = 0..K-1.
+// Requirements: K % KS == 0, lda/ldb % 4 == 0, A/B 16-byte aligned, tile fully in bounds.
+// LDS needed: 2 * KS * (BM + BN) floats.
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, int MI, int NI, int KS>
+struct KMajor {
+    static constexpr int BM = WM * MI * 32;
+    static constexpr int BN = WN * NI * 32;
+    static constexpr int NT = WM * WN * 64;
+    static constexpr int A4 = KS * BM / 4 / NT;  // float4 loads per thread per slab (A)
+    static constexpr int B4 = KS * BN / 4 / NT;
+    static constexpr int LDS_FLOATS = 2 * KS * (BM + BN);
+    static_assert((KS * BM / 4) % NT == 0 && (KS * BN / 4) % NT == 0, "slab not divisible");
+    static_assert(KS % 2 == 0, "KS must be even");
+
+
+    __device__ static __forceinline__ void gload(const float* __restrict__ A, int lda,
+                                                  const float* __restrict__ B, int ldb, int k0, int tid,
+                                                  f32x4 (&ra)[A4], f32x4 (&rb)[B4])
+    {
+#pragma unroll
+        for (int u = 0; u < A4; ++u) {
+            const int f = tid + u * NT;
+            const int r = f / (BM / 4), c4 = f % (BM / 4);
+            ra[u] = *reinterpret_cast<const f32x4*>(A + (size_t)(k0 + r) * lda + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < B4; ++u) {
+            const int f = tid + u * NT;
+            const int r = f / (BN / 4), c4 = f % (BN / 4);
+            rb[u] = *reinterpret_cast<const f32x4*>(B + (size_t)(k0 + r) * ldb + c4 * 4);
+        }
+    }
+    __device__ static __forceinline__ void swrite(float* __restrict__ sA, float* __restrict__ sB, int buf,
+                                                   int tid, const f32x4 (&ra)[A4], const f32x4 (&rb)[B4])
+    {
+#pragma unroll
+        for (int u = 0; u < A4; ++u)
+            *reinterpret_cast<f32x4*>(sA + buf * KS * BM + (tid + u * NT) * 4) = ra[u];
+#pragma unroll
+        for (int u = 0; u < B4; ++u)
+            *reinterpret_cast<f32x4*>(sB + buf * KS * BN + (tid + u * NT) * 4) = rb[u];
+    }
+
+    __device__ static __forceinline__ void run(const float* __restrict__ A, int lda,
+                                                const float* __restrict__ B, int ldb, int K,
+                                                float* __restrict__ smem, f32x16 (&acc)[MI][NI])
+    {
+        const int tid = threadIdx.x;
+        const int lane = tid & 63;
+        const int wave = tid >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        float* sA = smem;                // [2][KS][BM]
+        float* sB = smem + 2 * KS * BM;  // [2][KS][BN]
+
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+        f32x4 ra[A4], rb[B4];
+        const int nslab = K / KS;
+        gload(A, lda, B, ldb, 0, tid, ra, rb);
+        swrite(sA, sB, 0, tid, ra, rb);
+        __syncthreads();
+        const int arow = wm * MI * 32 + (lane & 31);
+        const int bcol = wn * NI * 32 + (lane & 31);
+        const int khalf = lane >> 5;
+        for (int s = 0; s < nslab; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nslab) gload(A, lda, B, ldb, (s + 1) * KS, tid, ra, rb);
+            const float* cA = sA + buf * KS * BM;
+            const float* cB = sB + buf * KS * BN;
+#pragma unroll
+            for (int kk = 0; kk < KS / 2; ++kk) {
+                const int k = 2 * kk + khalf;
+                float a[MI], b[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) a[mi] = cA[k * BM + arow + mi * 32];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) b[ni] = cB[k * BN + bcol + ni * 32];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (s + 1 < nslab) swrite(sA, sB, buf ^ 1, tid, ra, rb);
+            __syncthreads();
+        }
+    }
+};

@@ -1,0 +1,333 @@
+// Fused template matcher for gfx950: LocalSimilarity.test of the reference
+// (src/models/matching.py:188-316) without ever materialising the (B,N,256,256) similarity
+// tensor in HBM.
+//
+//   gp_l2norm_cp      F.normalize over C                      (matching.py:224,229; ae_net.py:69)
+//   gp_match_tiles    one workgroup per (detection, template): 256x256xC f32 MFMA contraction,
+//                     then masks / threshold / row+col argmax / cycle check / score in
+//                     registers + LDS                          (matching.py:233-278, :80-113)
+//   gp_topk           top-k templates per detection           (matching.py:279)
+//   gp_gather_records per-candidate patch records             (matching.py:282-295)
+//   gp_format_points  -1-padded (x,y) correspondences         (matching.py:29-61, :63-68)
+//
+// Arithmetic order is the one fixed in oracle/gp_oracle.c (sequential fmaf over channels), so
+// every output -- float scores included -- is bit-identical to the oracle.
+#include "gp_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ F.normalize over C
+// x, out: (rows, C, 256).  One workgroup per row, thread p owns patch p (coalesced over p).
+__global__ __launch_bounds__(256) void l2norm_cp_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ out, int C)
+{
+    const size_t base = (size_t)blockIdx.x * C * GP_P + threadIdx.x;
+    float ss = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float v = x[base + (size_t)c * GP_P];
+        ss = __builtin_fmaf(v, v, ss);
+    }
+    const float d = fmaxf(__builtin_sqrtf(ss), 1e-12f);
+    for (int c = 0; c < C; ++c) out[base + (size_t)c * GP_P] = x[base + (size_t)c * GP_P] / d;
+}
+
+// ------------------------------------------------------------------ fused match tile
+// 8 waves as 4 (query rows t) x 2 (template cols s); wave tile 64 x 128 = 2 x 4 MFMA tiles.
+using MM = KMajor<4, 2, 2, 4, 16>;
+static_assert(MM::BM == 256 && MM::BN == 256 && MM::NT == 512, "matcher tile must be 256x256");
+
+struct MatchSmem {
+    float stage[MM::LDS_FLOATS];  // 64 KiB operand staging
+    float qmask[GP_P];
+    float smask[GP_P];
+    float rowv[2][GP_P];  // per column-wave partial row maxima
+    int rowi[2][GP_P];
+    float colv[4][GP_P];  // per row-wave partial column maxima
+    int coli[4][GP_P];
+    float sc_t2s[GP_P];
+    int id_t2s[GP_P];
+    float sc_s2t[GP_P];
+    int id_s2t[GP_P];
+    float contrib[GP_P];
+    float maskv[GP_P];
+};
+
+__global__ __launch_bounds__(512, 2) void match_tiles_kernel(
+    const float* __restrict__ query,  // (B, C, 256)   matcher-normalised
+    const float* __restrict__ bank,   // (O, N, C, 256) matcher-normalised
+    const float* __restrict__ qmask,  // (B, 256)
+    const float* __restrict__ bmask,  // (O, N, 256)
+    const int* __restrict__ labels,   // (B) 0-based object index
+    int B, int N, int C, float thr, float patch_thr,
+    uint8_t* __restrict__ idx_t2s,    // (B, N, 256)
+    float* __restrict__ score_t2s,    // (B, N, 256)
+    float* __restrict__ mask_all,     // (B, N, 256)
+    float* __restrict__ sim_avg)      // (B, N)
+{
+    __shared__ MatchSmem sm;
+    const int q = xcd_chunked_tile(blockIdx.x, B * N);
+    if (q < 0) return;
+    const int n = q / B, b = q % B;  // b fastest: neighbours on one XCD share the template tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const size_t on = (size_t)labels[b] * N + n;
+    const float* A = query + (size_t)b * C * GP_P;
+    const float* Bm = bank + on * (size_t)C * GP_P;
+
+    if (tid < GP_P) sm.qmask[tid] = qmask[(size_t)b * GP_P + tid];
+    else sm.smask[tid - GP_P] = bmask[on * GP_P + (tid - GP_P)];
+
+    f32x16 acc[2][4];
+    MM::run(A, GP_P, Bm, GP_P, C, sm.stage, acc);  // ends with __syncthreads(): masks visible
+
+    // ---- sim *= src_mask; sim *= tar_mask; sim[sim < thr] = 0   (matching.py:234-236)
+    const int s_lane = 128 * wc + (lane & 31);
+    const int t_lane = 64 * wr + 4 * (lane >> 5);
+    float sm_s[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) sm_s[ni] = sm.smask[s_lane + 32 * ni];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float tm = sm.qmask[t_lane + 32 * mi + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                float v = acc[mi][ni][r] * sm_s[ni];
+                v = v * tm;
+                acc[mi][ni][r] = (v < thr) ? 0.f : v;
+            }
+        }
+
+    // ---- row maxima (over s, first max wins)   torch.max(sim, dim=3)  (matching.py:240)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float bv = acc[mi][0][r];
+            int bi = s_lane;
+#pragma unroll
+            for (int ni = 1; ni < 4; ++ni) {
+                const float x = acc[mi][ni][r];
+                if (x > bv) { bv = x; bi = s_lane + 32 * ni; }
+            }
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if ((lane & 31) == 0) {
+                const int t = t_lane + 32 * mi + (r & 3) + 8 * (r >> 2);
+                sm.rowv[wc][t] = bv;
+                sm.rowi[wc][t] = bi;
+            }
+        }
+
+    // ---- column maxima (over t, first max wins)   torch.max(sim, dim=2)  (matching.py:241)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        float bv = acc[0][ni][0];
+        int bi = t_lane;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {  // (mi, r) ascending == t ascending for this lane
+                const float x = acc[mi][ni][r];
+                if (x > bv) { bv = x; bi = t_lane + 32 * mi + (r & 3) + 8 * (r >> 2); }
+            }
+        const float ov = __shfl_xor(bv, 32);
+        const int oi = __shfl_xor(bi, 32);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        if (lane < 32) {
+            sm.colv[wr][s_lane + 32 * ni] = bv;
+            sm.coli[wr][s_lane + 32 * ni] = bi;
+        }
+    }
+    __syncthreads();
+
+    // ---- merge the per-wave partials (lower index range first, strict > keeps first max)
+    if (tid < GP_P) {
+        float bv = sm.rowv[0][tid];
+        int bi = sm.rowi[0][tid];
+        if (sm.rowv[1][tid] > bv) { bv = sm.rowv[1][tid]; bi = sm.rowi[1][tid]; }
+        sm.sc_t2s[tid] = bv;
+        sm.id_t2s[tid] = bi;
+    } else {
+        const int s = tid - GP_P;
+        float bv = sm.colv[0][s];
+        int bi = sm.coli[0][s];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (sm.colv[w][s] > bv) { bv = sm.colv[w][s]; bi = sm.coli[w][s]; }
+        sm.sc_s2t[s] = bv;
+        sm.id_s2t[s] = bi;
+    }
+    __syncthreads();
+
+    // ---- masks + per-patch outputs   (matching.py:247-271, find_consistency_patches :80-113)
+    if (tid < GP_P) {
+        const int t = tid;
+        const int js = sm.id_t2s[t];
+        const float sc = sm.sc_t2s[t];
+        const bool mask_sim = sc >= thr;
+        const int t2 = sm.id_s2t[js];
+        const float dx = (float)(t2 % GP_G) - (float)(t % GP_G);
+        const float dy = (float)(t2 / GP_G) - (float)(t / GP_G);
+        const float dist = __builtin_sqrtf(dx * dx + dy * dy);
+        const bool mask_dist = dist <= patch_thr;
+        const bool mask_sim2 = sm.sc_s2t[js] >= thr;
+        // reference quirk: (idx_src2tar != 0) is applied at POSITION t, not at the matched s
+        float nz = sm.qmask[t] * sm.smask[js];
+        nz = nz * (float)(sm.id_s2t[t] != 0);
+        nz = nz * (float)(js != 0);
+        const float m = (float)(mask_sim && mask_dist && mask_sim2) * nz;
+        const size_t o = ((size_t)b * N + n) * GP_P + t;
+        idx_t2s[o] = (uint8_t)js;
+        score_t2s[o] = sc;
+        mask_all[o] = m;
+        sm.contrib[t] = sc * m;
+        sm.maskv[t] = m;
+    }
+    __syncthreads();
+    if (tid == 0) {  // fixed sequential order (oracle: same loop); 256 adds, negligible
+        float a = 0.f, cnt = 0.f;
+        for (int t = 0; t < GP_P; ++t) {
+            a = a + sm.contrib[t];
+            cnt = cnt + sm.maskv[t];
+        }
+        sim_avg[(size_t)b * N + n] = (cnt > 0.f) ? a / 256.0f : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ top-k per detection
+// One wave per detection.  Order: higher score, then lower template index (torch.topk leaves
+// ties unspecified; the oracle uses the same rule).
+__global__ __launch_bounds__(64) void topk_kernel(const float* __restrict__ sim_avg, int N, int k,
+                                                   int* __restrict__ ids, float* __restrict__ scores)
+{
+    extern __shared__ unsigned char taken[];  // N flags
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int n = lane; n < N; n += 64) taken[n] = 0;
+    __syncthreads();
+    const float* v = sim_avg + (size_t)b * N;
+    for (int j = 0; j < k; ++j) {
+        float bv = 0.f;
+        int bi = 0x7fffffff;
+        for (int n = lane; n < N; n += 64) {
+            if (taken[n]) continue;
+            const float x = v[n];
+            if (bi == 0x7fffffff || x > bv) { bv = x; bi = n; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) {
+            ids[(size_t)b * k + j] = bi;
+            scores[(size_t)b * k + j] = bv;
+            taken[bi] = 1;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ gather candidate records
+__global__ __launch_bounds__(256) void gather_records_kernel(
+    const int* __restrict__ ids, const uint8_t* __restrict__ idx_t2s,
+    const float* __restrict__ score_t2s, const float* __restrict__ mask_all, int N, int k,
+    uint8_t* __restrict__ rec_idx, float* __restrict__ rec_score, float* __restrict__ rec_mask)
+{
+    const int bk = blockIdx.x, b = bk / k, t = threadIdx.x;
+    const size_t src = ((size_t)b * N + ids[bk]) * GP_P + t;
+    const size_t dst = (size_t)bk * GP_P + t;
+    rec_idx[dst] = idx_t2s[src];
+    rec_score[dst] = score_t2s[src];
+    rec_mask[dst] = mask_all[src];
+}
+
+// ------------------------------------------------------------------ format_prediction
+__global__ __launch_bounds__(256) void format_points_kernel(const uint8_t* __restrict__ rec_idx,
+                                                             const float* __restrict__ rec_mask,
+                                                             long long* __restrict__ tar_pts,
+                                                             long long* __restrict__ src_pts)
+{
+    const size_t i = (size_t)blockIdx.x * GP_P + threadIdx.x;
+    const int t = threadIdx.x;
+    const bool valid = rec_mask[i] != 0.f;  // torch.nonzero(mask)  (matching.py:42)
+    const int js = rec_idx[i];
+    tar_pts[2 * i + 0] = valid ? (t % GP_G) : -1;
+    tar_pts[2 * i + 1] = valid ? (t / GP_G) : -1;
+    src_pts[2 * i + 0] = valid ? (js % GP_G) : -1;
+    src_pts[2 * i + 1] = valid ? (js / GP_G) : -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gp_l2norm_cp(const float* x, float* out, int rows, int C, void* stream)
+{
+    GP_REQUIRE(x && out && rows >= 0 && C > 0, "gp_l2norm_cp: bad arguments (rows=%d C=%d)", rows, C);
+    if (rows == 0) return GP_OK;
+    hipLaunchKernelGGL(l2norm_cp_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, out, C);
+    GP_CHECK_LAUNCH("gp_l2norm_cp");
+    return GP_OK;
+}
+
+int gp_match_tiles(const float* query, const float* bank, const float* qmask, const float* bmask,
+                   const int* labels, int B, int O, int N, int C, float sim_threshold,
+                   float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
+                   float* sim_avg, void* stream)
+{
+    GP_REQUIRE(query && bank && qmask && bmask && labels && idx_t2s && score_t2s && mask_all && sim_avg,
+               "gp_match_tiles: null pointer");
+    GP_REQUIRE(B >= 0 && O > 0 && N > 0, "gp_match_tiles: bad sizes B=%d O=%d N=%d", B, O, N);
+    GP_REQUIRE(C > 0 && C % 16 == 0, "gp_match_tiles: C=%d must be a positive multiple of 16", C);
+    if (B == 0) return GP_OK;
+    hipLaunchKernelGGL(match_tiles_kernel, dim3(xcd_chunked_grid(B * N)), dim3(512), 0,
+                       (hipStream_t)stream, query, bank, qmask, bmask, labels, B, N, C, sim_threshold,
+                       patch_threshold, idx_t2s, score_t2s, mask_all, sim_avg);
+    GP_CHECK_LAUNCH("gp_match_tiles");
+    return GP_OK;
+}
+
+int gp_topk(const float* sim_avg, int B, int N, int k, int* ids, float* scores, void* stream)
+{
+    GP_REQUIRE(sim_avg && ids && scores, "gp_topk: null pointer");
+    // torch.topk raises when k > N (matching.py:279); so do we.
+    GP_REQUIRE(k >= 1 && k <= N, "gp_topk: selected index k out of range (k=%d, N=%d)", k, N);
+    if (B == 0) return GP_OK;
+    hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(64), (size_t)N, (hipStream_t)stream, sim_avg, N, k, ids, scores);
+    GP_CHECK_LAUNCH("gp_topk");
+    return GP_OK;
+}
+
+int gp_gather_records(const int* ids, const uint8_t* idx_t2s, const float* score_t2s,
+                      const float* mask_all, int B, int N, int k, uint8_t* rec_idx, float* rec_score,
+                      float* rec_mask, void* stream)
+{
+    GP_REQUIRE(ids && idx_t2s && score_t2s && mask_all && rec_idx && rec_score && rec_mask,
+               "gp_gather_records: null pointer");
+    GP_REQUIRE(k >= 1 && N >= 1, "gp_gather_records: bad sizes");
+    if (B == 0) return GP_OK;
+    hipLaunchKernelGGL(gather_records_kernel, dim3(B * k), dim3(256), 0, (hipStream_t)stream, ids,
+                       idx_t2s, score_t2s, mask_all, N, k, rec_idx, rec_score, rec_mask);
+    GP_CHECK_LAUNCH("gp_gather_records");
+    return GP_OK;
+}
+
+int gp_format_points(const uint8_t* rec_idx, const float* rec_mask, int rows, long long* tar_pts,
+                     long long* src_pts, void* stream)
+{
+    GP_REQUIRE(rec_idx && rec_mask && tar_pts && src_pts, "gp_format_points: null pointer");
+    if (rows <= 0) return GP_OK;
+    hipLaunchKernelGGL(format_points_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, rec_idx,
+                       rec_mask, tar_pts, src_pts);
+    GP_CHECK_LAUNCH("gp_format_points");
+    return GP_OK;
+}
+
+}  // extern "C"

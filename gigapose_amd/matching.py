@@ -1,0 +1,150 @@
+"""Template matching on MI355X behind the reference's `LocalSimilarity` interface.
+
+Drop-in for `src.models.matching.LocalSimilarity` (reference matching.py:9-316; Hydra target
+in configs/model/large.yaml:35-39): same constructor kwargs, `.k`, and
+`test(src_feats, tar_feat, src_masks, tar_mask, max_batch_size=None)` returning a
+PandasTensorCollection with id_src / score_src / score_pts / tar_pts / src_pts.
+
+All arithmetic runs in libgigapose_hip.so (gp_l2norm_cp, gp_match_tiles, gp_topk,
+gp_gather_records, gp_format_points); torch only owns the buffers.  The fast path,
+`test_bank`, matches detections against a RESIDENT bank indexed by label inside the kernel,
+so the reference's 170 MB/detection gather `ae_features[label-1]` (gigaPose.py:520) and its
+per-batch re-normalisation of the bank (matching.py:229) disappear.
+"""
+import pandas as pd
+import torch
+
+from . import _lib
+from .tensor_collection import PandasTensorCollection
+
+P = 256
+
+
+def patch_grid_mask(mask224):
+    """F.interpolate(mask, size=(16,16)) nearest (matching.py:222,227) == sample pixel (14i,14j)."""
+    assert mask224.shape[-1] % 16 == 0 and mask224.shape[-2] % 16 == 0
+    sy, sx = mask224.shape[-2] // 16, mask224.shape[-1] // 16
+    m = mask224[..., ::sy, ::sx].to(torch.float32)
+    return m.reshape(*m.shape[:-2], P).contiguous()
+
+
+class MatchBank:
+    """Matcher-ready template bank: twice-normalised features (AENet's F.normalize, then the
+    matcher's own, matching.py:229) as (O,N,C,256) f32 and patch masks (O,N,256)."""
+
+    def __init__(self, ae_features, masks224):
+        O, N, C = ae_features.shape[:3]
+        feats = ae_features.reshape(O * N, C, P).contiguous().float()
+        self.features = torch.empty_like(feats)
+        _lib.call("gp_l2norm_cp", _lib.ptr(feats), _lib.ptr(self.features), _lib.i(O * N), _lib.i(C),
+                  _lib.stream_ptr())
+        self.features = self.features.view(O, N, C, P)
+        self.masks = patch_grid_mask(masks224)
+        self.O, self.N, self.C = O, N, C
+
+
+class LocalSimilarity(torch.nn.Module):
+    def __init__(self, k, sim_threshold, patch_threshold, search_direction="tar2src",
+                 image_size=224, patch_size=14, max_batch_size=32):
+        super().__init__()
+        if search_direction != "tar2src":
+            raise NotImplementedError("only search_direction='tar2src' (the reference default) is built")
+        self.max_batch_size = max_batch_size
+        self.k = k
+        self.sim_threshold = sim_threshold
+        self.patch_threshold = patch_threshold
+        self.search_direction = search_direction
+        self.num_patches = image_size // patch_size
+        if patch_threshold <= 0:
+            raise NotImplementedError("patch_threshold must be > 0 (reference default 3; <= 0 disables the "
+                                      "cycle check in the reference, which is not built)")
+        if self.num_patches != 16:
+            raise NotImplementedError("kernels are specialised for a 16x16 patch grid (224/14)")
+
+    # ---- kernel-level stages (also used by the template-sharded multi-GPU path) -----------
+    def normalize(self, feats):
+        """(rows, C, 16, 16) or (rows, C, 256) -> matcher-normalised (rows, C, 256)."""
+        rows, C = feats.shape[:2]
+        x = feats.reshape(rows, C, P).contiguous().float()
+        out = torch.empty_like(x)
+        _lib.call("gp_l2norm_cp", _lib.ptr(x), _lib.ptr(out), _lib.i(rows), _lib.i(C), _lib.stream_ptr())
+        return out
+
+    def match_tiles(self, query, qmask, bank, labels0):
+        """All (detection, template) tiles.  query (B,C,256) normalised, qmask (B,256),
+        bank: MatchBank, labels0 (B,) int32 0-based.  Returns idx_t2s u8, score_t2s, mask_all
+        (B,N,256) and sim_avg (B,N)."""
+        B, C, _ = query.shape
+        N = bank.N
+        dev = query.device
+        idx = torch.empty(B, N, P, dtype=torch.uint8, device=dev)
+        sc = torch.empty(B, N, P, dtype=torch.float32, device=dev)
+        ma = torch.empty(B, N, P, dtype=torch.float32, device=dev)
+        avg = torch.empty(B, N, dtype=torch.float32, device=dev)
+        _lib.call("gp_match_tiles", _lib.ptr(query), _lib.ptr(bank.features), _lib.ptr(qmask),
+                  _lib.ptr(bank.masks), _lib.ptr(labels0), _lib.i(B), _lib.i(bank.O), _lib.i(N), _lib.i(C),
+                  _lib.f(self.sim_threshold), _lib.f(self.patch_threshold), _lib.ptr(idx), _lib.ptr(sc),
+                  _lib.ptr(ma), _lib.ptr(avg), _lib.stream_ptr())
+        return idx, sc, ma, avg
+
+    def topk(self, sim_avg, k=None):
+        k = self.k if k is None else k
+        B, N = sim_avg.shape
+        if k > N:
+            raise RuntimeError("selected index k out of range")  # torch.topk's error (matching.py:279)
+        ids = torch.empty(B, k, dtype=torch.int32, device=sim_avg.device)
+        scores = torch.empty(B, k, dtype=torch.float32, device=sim_avg.device)
+        _lib.call("gp_topk", _lib.ptr(sim_avg), _lib.i(B), _lib.i(N), _lib.i(k), _lib.ptr(ids),
+                  _lib.ptr(scores), _lib.stream_ptr())
+        return ids, scores
+
+    def gather_records(self, ids, idx, sc, ma):
+        B, k = ids.shape
+        N = idx.shape[1]
+        dev = ids.device
+        rec_idx = torch.empty(B, k, P, dtype=torch.uint8, device=dev)
+        rec_score = torch.empty(B, k, P, dtype=torch.float32, device=dev)
+        rec_mask = torch.empty(B, k, P, dtype=torch.float32, device=dev)
+        _lib.call("gp_gather_records", _lib.ptr(ids), _lib.ptr(idx), _lib.ptr(sc), _lib.ptr(ma), _lib.i(B),
+                  _lib.i(N), _lib.i(k), _lib.ptr(rec_idx), _lib.ptr(rec_score), _lib.ptr(rec_mask),
+                  _lib.stream_ptr())
+        return rec_idx, rec_score, rec_mask
+
+    def format_points(self, rec_idx, rec_mask):
+        B, k = rec_idx.shape[:2]
+        tar_pts = torch.empty(B, k, P, 2, dtype=torch.int64, device=rec_idx.device)
+        src_pts = torch.empty(B, k, P, 2, dtype=torch.int64, device=rec_idx.device)
+        _lib.call("gp_format_points", _lib.ptr(rec_idx), _lib.ptr(rec_mask), _lib.i(B * k), _lib.ptr(tar_pts),
+                  _lib.ptr(src_pts), _lib.stream_ptr())
+        return tar_pts, src_pts
+
+    # ---- resident-bank entry point (what GigaPose.eval_retrieval uses) --------------------
+    def test_bank(self, bank, tar_feat, tar_mask, labels0):
+        """tar_feat (B,C,16,16) AENet features, tar_mask (B,224,224), labels0 (B,) 0-based."""
+        query = self.normalize(tar_feat)
+        qmask = patch_grid_mask(tar_mask)
+        idx, sc, ma, avg = self.match_tiles(query, qmask, bank, labels0.to(torch.int32).contiguous())
+        ids, score_src = self.topk(avg)
+        rec_idx, rec_score, rec_mask = self.gather_records(ids, idx, sc, ma)
+        tar_pts, src_pts = self.format_points(rec_idx, rec_mask)
+        return PandasTensorCollection(infos=pd.DataFrame(), id_src=ids.long(), score_src=score_src,
+                                      score_pts=rec_score, tar_pts=tar_pts, src_pts=src_pts)
+
+    # ---- reference-signature entry point ---------------------------------------------------
+    def test(self, src_feats, tar_feat, src_masks, tar_mask, max_batch_size=None):
+        """Reference signature (matching.py:188): src_feats (B,N,C,H,W) is a per-detection
+        gathered bank.  Each detection becomes its own 'object' of a temporary bank; chunking by
+        max_batch_size only bounds that temporary (results do not depend on it)."""
+        if max_batch_size is None:
+            max_batch_size = self.max_batch_size
+        B = tar_feat.shape[0]
+        outs = []
+        for s in range(0, B, max_batch_size):
+            e = min(B, s + max_batch_size)
+            bank = MatchBank(src_feats[s:e], src_masks[s:e])
+            labels0 = torch.arange(e - s, dtype=torch.int32, device=tar_feat.device)
+            outs.append(self.test_bank(bank, tar_feat[s:e], tar_mask[s:e], labels0))
+        out = outs[0]
+        for o in outs[1:]:
+            out.cat_df(o)
+        return PandasTensorCollection(infos=pd.DataFrame(), **out.tensors)

@@ -1,0 +1,62 @@
+/*
+ * gigapose_hip.h -- C-ABI of libgigapose_hip.so: the MI355X (gfx950) implementation of the
+ * GigaPose coarse-pose hot path (reference: nv-nguyen/gigapose, src/models/).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated otherwise; the caller owns all buffers,
+ *     kernels never allocate; inputs are never modified;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous;
+ *   - return value: 0 = ok, -1 = invalid argument, -2 = launch failure; gp_last_error() returns a
+ *     thread-local message for the last failure (the reference raises Python exceptions /
+ *     asserts at the same places, cited per function);
+ *   - tensors are dense, row-major in the order written, f32 unless stated otherwise;
+ *   - P = 256 patches (16x16 grid of 14-px patches on a 224x224 crop).
+ */
+#ifndef GIGAPOSE_HIP_H
+#define GIGAPOSE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int gp_abi_version(void);
+const char* gp_last_error(void);
+
+/* ---- template matching: LocalSimilarity.test (src/models/matching.py:188-316) ------------- */
+
+/* F.normalize(x, dim=C) for x (rows, C, 256).  Replaces matching.py:224,229 and ae_net.py:69. */
+int gp_l2norm_cp(const float* x, float* out, int rows, int C, void* stream);
+
+/* Fused similarity + masks + threshold + bidirectional argmax + cycle check + template score
+ * for every (detection b, template n) pair.  Replaces matching.py:233-278 and
+ * find_consistency_patches (:80-113); the (B,N,256,256) `sim` tensor is never written.
+ *   query (B,C,256), bank (O,N,C,256): features already normalised by gp_l2norm_cp
+ *   qmask (B,256), bmask (O,N,256): patch-grid masks (nearest sample of the 224x224 masks,
+ *                                    matching.py:222,227)
+ *   labels (B) int32: 0-based object index per detection (reference: label-1, gigaPose.py:520)
+ * outputs: idx_t2s u8 (B,N,256), score_t2s (B,N,256), mask_all (B,N,256), sim_avg (B,N).
+ * Requires C % 16 == 0. */
+int gp_match_tiles(const float* query, const float* bank, const float* qmask, const float* bmask,
+                   const int* labels, int B, int O, int N, int C, float sim_threshold,
+                   float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
+                   float* sim_avg, void* stream);
+
+/* torch.topk(sim_avg, k, dim=1) (matching.py:279); ties: lower template index first.
+ * Fails (-1) when k > N, like torch.topk raises. ids int32 (B,k), scores (B,k). */
+int gp_topk(const float* sim_avg, int B, int N, int k, int* ids, float* scores, void* stream);
+
+/* Gather the per-patch records of the selected templates (matching.py:282-285):
+ * rec_idx u8 (B,k,256), rec_score (B,k,256) [= score_pts], rec_mask (B,k,256). */
+int gp_gather_records(const int* ids, const uint8_t* idx_t2s, const float* score_t2s,
+                      const float* mask_all, int B, int N, int k, uint8_t* rec_idx, float* rec_score,
+                      float* rec_mask, void* stream);
+
+/* format_prediction + convert_index2location (matching.py:29-61, 63-68):
+ * tar_pts, src_pts int64 (rows,256,2) as (x,y), -1 where rec_mask == 0.  rows = B*k. */
+int gp_format_points(const uint8_t* rec_idx, const float* rec_mask, int rows, long long* tar_pts,
+                     long long* src_pts, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIGAPOSE_HIP_H */

@@ -1,0 +1,141 @@
+"""GPU parity of the fused HIP matcher (through the C-ABI) against the CPU oracle and the
+reference goldens.  Index outputs: bit-exact.  Float outputs: ALSO bit-exact against the
+oracle (same fmaf order by construction); 1e-6 against the reference goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gigapose_amd import synthetic as syn
+from oracle import cpu as oracle
+from test_oracle_matcher import CASES, load_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def run_hip(case, k):
+    from gigapose_amd.matching import LocalSimilarity, MatchBank
+
+    metric = LocalSimilarity(k=k, sim_threshold=0.5, patch_threshold=3)
+    bank = MatchBank(torch.from_numpy(case["src_feats"]).to(DEV), torch.from_numpy(case["src_masks"]).to(DEV))
+    out = metric.test_bank(bank, torch.from_numpy(case["tar_feat"]).to(DEV),
+                           torch.from_numpy(case["tar_mask"]).to(DEV),
+                           torch.from_numpy(case["labels"]).to(DEV))
+    torch.cuda.synchronize()
+    return metric, bank, {k_: v.cpu().numpy() for k_, v in out.tensors.items()}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_matcher_vs_oracle_bit_exact(golden_dir, name):
+    g, case, k = load_case(golden_dir, name)
+    _, _, hip = run_hip(case, k)
+    ref = oracle.local_similarity_test(case["src_feats"], case["tar_feat"], case["src_masks"],
+                                       case["tar_mask"], case["labels"], k)
+    for key in ["id_src", "tar_pts", "src_pts"]:
+        np.testing.assert_array_equal(hip[key], ref[key], err_msg=key)
+    for key in ["score_src", "score_pts"]:  # bit-exact floats: compare raw bits
+        np.testing.assert_array_equal(hip[key].view(np.uint32), ref[key].view(np.uint32), err_msg=key)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_matcher_vs_reference_golden(golden_dir, name):
+    g, case, k = load_case(golden_dir, name)
+    _, _, hip = run_hip(case, k)
+    np.testing.assert_array_equal(hip["id_src"], g["id_src"])
+    np.testing.assert_array_equal(hip["tar_pts"], g["tar_pts"].astype(np.int64))
+    np.testing.assert_array_equal(hip["src_pts"], g["src_pts"].astype(np.int64))
+    np.testing.assert_allclose(hip["score_src"], g["score_src"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(hip["score_pts"], g["score_pts"], rtol=0, atol=2e-6)
+
+
+def test_l2norm_bit_exact():
+    rs = np.random.RandomState(5)
+    x = (rs.standard_normal((7, 384, 256)) * rs.uniform(0.1, 30, (7, 1, 256))).astype(np.float32)
+    x[0, :, 3] = 0.0  # zero vector -> eps clamp path
+    from gigapose_amd.matching import LocalSimilarity
+
+    y = LocalSimilarity(5, 0.5, 3).normalize(torch.from_numpy(x).to(DEV)).cpu().numpy()
+    np.testing.assert_array_equal(y.view(np.uint32), oracle.l2norm_cp(x).view(np.uint32))
+    np.testing.assert_allclose(y, torch.nn.functional.normalize(torch.from_numpy(x), dim=1).numpy(),
+                               rtol=2e-6, atol=1e-12)
+
+
+def test_reference_signature_equals_bank_path():
+    """`test(src_feats[B,N,...])` (matching.py:188 signature) == resident-bank path."""
+    case = syn.matcher_case(seed=21, B=5, O=2, N=6, C=32)
+    metric, _, a = run_hip(case, 5)
+    lab = torch.from_numpy(case["labels"]).long()
+    out = metric.test(torch.from_numpy(case["src_feats"])[lab].to(DEV), torch.from_numpy(case["tar_feat"]).to(DEV),
+                      torch.from_numpy(case["src_masks"])[lab].to(DEV), torch.from_numpy(case["tar_mask"]).to(DEV),
+                      max_batch_size=2)  # ragged chunks 2,2,1
+    for key, v in out.tensors.items():
+        np.testing.assert_array_equal(v.cpu().numpy(), a[key], err_msg=key)
+    assert out.id_src.dtype == torch.int64 and out.tar_pts.dtype == torch.int64
+    assert out.score_src.dtype == torch.float32 and tuple(out.src_pts.shape) == (5, 5, 256, 2)
+
+
+def test_errors_and_edges():
+    from gigapose_amd import _lib
+    from gigapose_amd.matching import LocalSimilarity, MatchBank
+
+    case = syn.matcher_case(seed=22, B=2, O=1, N=3, C=32)
+    metric = LocalSimilarity(k=5, sim_threshold=0.5, patch_threshold=3)
+    bank = MatchBank(torch.from_numpy(case["src_feats"]).to(DEV), torch.from_numpy(case["src_masks"]).to(DEV))
+    with pytest.raises(RuntimeError):  # N=3 < k=5: torch.topk raises in the reference too
+        metric.test_bank(bank, torch.from_numpy(case["tar_feat"]).to(DEV), torch.from_numpy(case["tar_mask"]).to(DEV),
+                         torch.zeros(2, dtype=torch.int32, device=DEV))
+    with pytest.raises(_lib.GigaPoseHipError):  # C not a multiple of 16
+        q = torch.zeros(1, 24, 256, device=DEV)
+        metric.match_tiles(q, torch.ones(1, 256, device=DEV),
+                           type("B", (), dict(features=torch.zeros(1, 1, 24, 256, device=DEV),
+                                              masks=torch.ones(1, 1, 256, device=DEV), O=1, N=1, C=24))(),
+                           torch.zeros(1, dtype=torch.int32, device=DEV))
+    # empty batch
+    m4 = LocalSimilarity(k=3, sim_threshold=0.5, patch_threshold=3)
+    out = m4.test_bank(bank, torch.zeros(0, 32, 16, 16, device=DEV), torch.zeros(0, 224, 224, device=DEV),
+                       torch.zeros(0, dtype=torch.int32, device=DEV))
+    assert tuple(out.id_src.shape) == (0, 3) and tuple(out.src_pts.shape) == (0, 3, 256, 2)
+    # all-zero masks: nothing matches, ids are the first k templates, points all -1
+    out = m4.test_bank(bank, torch.from_numpy(case["tar_feat"]).to(DEV), torch.zeros(2, 224, 224, device=DEV),
+                       torch.zeros(2, dtype=torch.int32, device=DEV))
+    assert out.id_src.cpu().tolist() == [[0, 1, 2]] * 2 and (out.tar_pts == -1).all() and not out.score_src.any()
+
+
+def test_full_size_config2_properties():
+    """BASELINE config 2 shape (B=64, N=162, C=1024): oracle check on a sample of tiles plus
+    size-independent properties (template-permutation equivariance, planted top-1)."""
+    from gigapose_amd.matching import LocalSimilarity, MatchBank
+
+    B, N, C = 64, 162, 1024
+    rs = np.random.RandomState(31)
+    case = syn.matcher_case(seed=31, B=B, O=1, N=N, C=C, full_masks=True)
+    # plant: query b is a noisy copy of template (7*b) % N -> that template must win
+    for b in range(B):
+        t = case["src_feats"][0, (7 * b) % N] + 0.05 * syn._unit(rs.standard_normal((C, 16, 16)), 0)
+        case["tar_feat"][b] = syn._unit(t, 0)
+    metric, bank, hip = run_hip(case, 5)
+    assert (hip["id_src"][:, 0] == (7 * np.arange(B)) % N).all()
+    # oracle on a sample of (b, n) tiles
+    q = metric.normalize(torch.from_numpy(case["tar_feat"]).to(DEV))
+    from gigapose_amd.matching import patch_grid_mask
+    idx, sc, ma, avg = metric.match_tiles(q, patch_grid_mask(torch.from_numpy(case["tar_mask"]).to(DEV)), bank,
+                                          torch.zeros(B, dtype=torch.int32, device=DEV))
+    bs, ns = [0, 17, 63], [0, 7, 119, 161]
+    qn = oracle.l2norm_cp(case["tar_feat"].reshape(B, C, 256))[bs]
+    bn = oracle.l2norm_cp(case["src_feats"].reshape(1, N, C, 256))[:, ns]
+    oi, osc, oma, oavg = oracle.match(qn, bn, np.ones((len(bs), 256), np.float32),
+                                      np.ones((1, len(ns), 256), np.float32), np.zeros(len(bs), np.int32))
+    sel = np.ix_(bs, ns)
+    np.testing.assert_array_equal(idx.cpu().numpy()[sel], oi)
+    np.testing.assert_array_equal(sc.cpu().numpy()[sel].view(np.uint32), osc.view(np.uint32))
+    np.testing.assert_array_equal(ma.cpu().numpy()[sel], oma)
+    np.testing.assert_array_equal(avg.cpu().numpy()[sel].view(np.uint32), oavg.view(np.uint32))
+    # permuting the templates permutes sim_avg and leaves the winners' records unchanged
+    perm = rs.permutation(N)
+    case2 = dict(case, src_feats=case["src_feats"][:, perm], src_masks=case["src_masks"][:, perm])
+    _, _, hip2 = run_hip(case2, 5)
+    np.testing.assert_array_equal(perm[hip2["id_src"][:, 0]], hip["id_src"][:, 0])
+    np.testing.assert_array_equal(hip2["src_pts"][:, 0], hip["src_pts"][:, 0])
+    np.testing.assert_array_equal(hip2["score_src"][:, 0].view(np.uint32), hip["score_src"][:, 0].view(np.uint32))

@@ -1,0 +1,129 @@
+// k-major f32 MFMA GEMM with fused epilogues (gfx950).
+//
+//   D[i][j] = epi( sum_k A[k][i] * B[k][j] )        A: [K][lda], B: [K][ldb], D: [I][ldd]
+//
+// Every dense layer of the hot path is this contraction with activations kept TRANSPOSED
+// ("channel-major": X^T [features][tokens]), so operand loads and result stores are coalesced
+// without any transpose pass:
+//   ViT linear layers (DINOv2 block: qkv / proj / fc1 / fc2; HF modeling_dinov2.py:199-297,
+//   reference call site ae_net.py:44-47):   A = W^T [in][out] (pre-transposed once at load),
+//   B = X^T [in][tokens]  ->  D = Y^T [out][tokens]
+//   IST regressor MLPs (reference ist_net.py:140-155): same, tokens = correspondences.
+// Accumulation order is the sequential fmaf chain over k of KMajor (gp_common.h).
+#include "gp_common.h"
+
+namespace {
+
+enum {
+    EPI_NONE = 0,
+    EPI_BIAS_I = 1,            // + bias[i]
+    EPI_BIAS_I_GELU = 2,       // gelu_erf(acc + bias[i])                      (DINOv2 fc1)
+    EPI_BIAS_I_SCALE_RES = 3,  // res[i][j] + scale[i] * (acc + bias[i])       (LayerScale + residual)
+    EPI_BIAS_J = 4,            // + bias[j]                                    (token-major V)
+    EPI_BIAS_I_RELU = 5,       // relu(acc + bias[i])                          (IST MLP)
+};
+
+using GM = KMajor<2, 2, 2, 2, 16>;  // 128 x 128 block tile, 4 waves, 64 accumulators/lane
+
+__device__ __forceinline__ float gelu_erf(float x)
+{
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kmajor_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* D,
+    int ldd, int tiles_i, int tiles_j, int K, const float* __restrict__ bias,
+    const float* __restrict__ scale, const float* res /* may alias D (in-place residual) */, int ldr)
+{
+    __shared__ float smem[GM::LDS_FLOATS];
+    const int q = xcd_chunked_tile(blockIdx.x, tiles_i * tiles_j);
+    if (q < 0) return;
+    // i fastest: the blocks of one XCD chunk share the B (activation) panel in that XCD's L2
+    const int ti = q % tiles_i, tj = q / tiles_i;
+    const int i0 = ti * GM::BM, j0 = tj * GM::BN;
+    f32x16 acc[2][2];
+    GM::run(A + i0, lda, B + j0, ldb, K, smem, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int j = j0 + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + wm * 64 + mi * 32 + frag_row(r, lane);
+                float v = acc[mi][ni][r];
+                if (EPI == EPI_BIAS_I || EPI == EPI_BIAS_I_GELU || EPI == EPI_BIAS_I_SCALE_RES ||
+                    EPI == EPI_BIAS_I_RELU)
+                    v = v + bias[i];
+                if (EPI == EPI_BIAS_J) v = v + bias[j];
+                if (EPI == EPI_BIAS_I_GELU) v = gelu_erf(v);
+                if (EPI == EPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
+                if (EPI == EPI_BIAS_I_SCALE_RES) v = res[(size_t)i * ldr + j] + scale[i] * v;
+                D[(size_t)i * ldd + j] = v;
+            }
+        }
+}
+
+template <int EPI>
+int launch(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J, int K,
+           const float* bias, const float* scale, const float* res, int ldr, hipStream_t st)
+{
+    const int ti = I / GM::BM, tj = J / GM::BN;
+    hipLaunchKernelGGL(gemm_kmajor_kernel<EPI>, dim3(xcd_chunked_grid(ti * tj)), dim3(GM::NT), 0, st, A,
+                       lda, B, ldb, D, ldd, ti, tj, K, bias, scale, res, ldr);
+    return 0;
+}
+
+}  // namespace
+
+// internal C++ entry used by gp_vit.hip / gp_ist.hip
+int gp_gemm_launch(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J,
+                   int K, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
+                   hipStream_t st)
+{
+    GP_REQUIRE(I > 0 && J > 0 && K > 0, "gp_gemm_kmajor: empty problem (I=%d J=%d K=%d)", I, J, K);
+    GP_REQUIRE(I % 128 == 0 && J % 128 == 0 && K % 16 == 0,
+               "gp_gemm_kmajor: I=%d, J=%d must be multiples of 128 and K=%d of 16 (pad the operands)", I, J, K);
+    GP_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= I && ldb >= J && ldd >= J,
+               "gp_gemm_kmajor: bad leading dimensions lda=%d ldb=%d ldd=%d", lda, ldb, ldd);
+    GP_REQUIRE(A && B && D, "gp_gemm_kmajor: null pointer");
+    GP_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "gp_gemm_kmajor: operands must be 16-byte aligned");
+    switch (epilogue) {
+        case EPI_NONE: launch<EPI_NONE>(A, lda, B, ldb, D, ldd, I, J, K, bias, scale, res, ldr, st); break;
+        case EPI_BIAS_I:
+            GP_REQUIRE(bias, "gp_gemm_kmajor: bias required");
+            launch<EPI_BIAS_I>(A, lda, B, ldb, D, ldd, I, J, K, bias, scale, res, ldr, st);
+            break;
+        case EPI_BIAS_I_GELU:
+            GP_REQUIRE(bias, "gp_gemm_kmajor: bias required");
+            launch<EPI_BIAS_I_GELU>(A, lda, B, ldb, D, ldd, I, J, K, bias, scale, res, ldr, st);
+            break;
+        case EPI_BIAS_I_SCALE_RES:
+            GP_REQUIRE(bias && scale && res && ldr >= J, "gp_gemm_kmajor: bias/scale/residual required");
+            launch<EPI_BIAS_I_SCALE_RES>(A, lda, B, ldb, D, ldd, I, J, K, bias, scale, res, ldr, st);
+            break;
+        case EPI_BIAS_J:
+            GP_REQUIRE(bias, "gp_gemm_kmajor: bias required");
+            launch<EPI_BIAS_J>(A, lda, B, ldb, D, ldd, I, J, K, bias, scale, res, ldr, st);
+            break;
+        case EPI_BIAS_I_RELU:
+            GP_REQUIRE(bias, "gp_gemm_kmajor: bias required");
+            launch<EPI_BIAS_I_RELU>(A, lda, B, ldb, D, ldd, I, J, K, bias, scale, res, ldr, st);
+            break;
+        default: GP_REQUIRE(false, "gp_gemm_kmajor: unknown epilogue %d", epilogue);
+    }
+    GP_CHECK_LAUNCH("gp_gemm_kmajor");
+    return GP_OK;
+}
+
+extern "C" int gp_gemm_kmajor(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I,
+                              int J, int K, int epilogue, const float* bias, const float* scale,
+                              const float* residual, int ldr, void* stream)
+{
+    return gp_gemm_launch(A, lda, B, ldb, D, ldd, I, J, K, epilogue, bias, scale, residual, ldr,
+                          (hipStream_t)stream);
+}

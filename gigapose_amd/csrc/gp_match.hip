@@ -270,8 +270,9 @@ extern "C" {
 
 int gp_l2norm_cp(const float* x, float* out, int rows, int C, void* stream)
 {
-    GP_REQUIRE(x && out && rows >= 0 && C > 0, "gp_l2norm_cp: bad arguments (rows=%d C=%d)", rows, C);
-    if (rows == 0) return GP_OK;
+    GP_REQUIRE(rows >= 0 && C > 0, "gp_l2norm_cp: bad arguments (rows=%d C=%d)", rows, C);
+    if (rows == 0) return GP_OK;  // empty batch: nothing to do (pointers may be NULL)
+    GP_REQUIRE(x && out, "gp_l2norm_cp: null pointer");
     hipLaunchKernelGGL(l2norm_cp_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, out, C);
     GP_CHECK_LAUNCH("gp_l2norm_cp");
     return GP_OK;
@@ -282,11 +283,11 @@ int gp_match_tiles(const float* query, const float* bank, const float* qmask, co
                    float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
                    float* sim_avg, void* stream)
 {
-    GP_REQUIRE(query && bank && qmask && bmask && labels && idx_t2s && score_t2s && mask_all && sim_avg,
-               "gp_match_tiles: null pointer");
     GP_REQUIRE(B >= 0 && O > 0 && N > 0, "gp_match_tiles: bad sizes B=%d O=%d N=%d", B, O, N);
     GP_REQUIRE(C > 0 && C % 16 == 0, "gp_match_tiles: C=%d must be a positive multiple of 16", C);
     if (B == 0) return GP_OK;
+    GP_REQUIRE(query && bank && qmask && bmask && labels && idx_t2s && score_t2s && mask_all && sim_avg,
+               "gp_match_tiles: null pointer");
     hipLaunchKernelGGL(match_tiles_kernel, dim3(xcd_chunked_grid(B * N)), dim3(512), 0,
                        (hipStream_t)stream, query, bank, qmask, bmask, labels, B, N, C, sim_threshold,
                        patch_threshold, idx_t2s, score_t2s, mask_all, sim_avg);
@@ -296,10 +297,10 @@ int gp_match_tiles(const float* query, const float* bank, const float* qmask, co
 
 int gp_topk(const float* sim_avg, int B, int N, int k, int* ids, float* scores, void* stream)
 {
-    GP_REQUIRE(sim_avg && ids && scores, "gp_topk: null pointer");
     // torch.topk raises when k > N (matching.py:279); so do we.
     GP_REQUIRE(k >= 1 && k <= N, "gp_topk: selected index k out of range (k=%d, N=%d)", k, N);
     if (B == 0) return GP_OK;
+    GP_REQUIRE(sim_avg && ids && scores, "gp_topk: null pointer");
     hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(64), (size_t)N, (hipStream_t)stream, sim_avg, N, k, ids, scores);
     GP_CHECK_LAUNCH("gp_topk");
     return GP_OK;
@@ -309,10 +310,10 @@ int gp_gather_records(const int* ids, const uint8_t* idx_t2s, const float* score
                       const float* mask_all, int B, int N, int k, uint8_t* rec_idx, float* rec_score,
                       float* rec_mask, void* stream)
 {
-    GP_REQUIRE(ids && idx_t2s && score_t2s && mask_all && rec_idx && rec_score && rec_mask,
-               "gp_gather_records: null pointer");
     GP_REQUIRE(k >= 1 && N >= 1, "gp_gather_records: bad sizes");
     if (B == 0) return GP_OK;
+    GP_REQUIRE(ids && idx_t2s && score_t2s && mask_all && rec_idx && rec_score && rec_mask,
+               "gp_gather_records: null pointer");
     hipLaunchKernelGGL(gather_records_kernel, dim3(B * k), dim3(256), 0, (hipStream_t)stream, ids,
                        idx_t2s, score_t2s, mask_all, N, k, rec_idx, rec_score, rec_mask);
     GP_CHECK_LAUNCH("gp_gather_records");
@@ -322,8 +323,8 @@ int gp_gather_records(const int* ids, const uint8_t* idx_t2s, const float* score
 int gp_format_points(const uint8_t* rec_idx, const float* rec_mask, int rows, long long* tar_pts,
                      long long* src_pts, void* stream)
 {
-    GP_REQUIRE(rec_idx && rec_mask && tar_pts && src_pts, "gp_format_points: null pointer");
     if (rows <= 0) return GP_OK;
+    GP_REQUIRE(rec_idx && rec_mask && tar_pts && src_pts, "gp_format_points: null pointer");
     hipLaunchKernelGGL(format_points_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, rec_idx,
                        rec_mask, tar_pts, src_pts);
     GP_CHECK_LAUNCH("gp_format_points");

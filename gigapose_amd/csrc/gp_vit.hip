@@ -1,0 +1,282 @@
+// DINOv2 ViT forward for gfx950, f32, activations kept channel-major (X^T: [C][tokens]).
+//
+// Replaces the un-vendored backbone the reference calls at ae_net.py:44-47
+// (`dinov2_model.forward_features(x)["x_prenorm"]`, wired in configs/model/ae_net/dinov2_l.yaml);
+// block structure per HF transformers modeling_dinov2.py:97-112 (embeddings), :199-229
+// (attention), :272-299 (LayerScale, MLP), :342-380 (pre-norm block), eps 1e-6.
+// The final LayerNorm is NOT applied (GigaPose consumes x_prenorm); the epilogue drops CLS and
+// L2-normalises over C (ae_net.py:64-69) straight into the (B, C, 16, 16) layout the matcher reads.
+//
+// Token column of image b, token t:  m = b * T + t   (T = 257, no per-image padding);
+// all activation matrices have Mpad = round_up(B*T, 128) columns.
+#include "gp_common.h"
+
+int gp_gemm_launch(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J,
+                   int K, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
+                   hipStream_t st);
+
+namespace {
+
+constexpr int PATCH = 14, IMG = 224, KPE = 588, KPE_PAD = 592, T_TOK = 257;
+
+// ---- patch-embed operand: col[k][b*256+p] = img[b][ci][14py+dy][14px+dx], k = ci*196+dy*14+dx
+// (flatten order of Conv2d weight (C,3,14,14); HF modeling_dinov2.py:139).  Rows 588..591 = 0.
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, float* __restrict__ col, int B)
+{
+    const int k = blockIdx.x, b = blockIdx.y, p = threadIdx.x;
+    float v = 0.f;
+    if (k < KPE) {
+        const int ci = k / 196, dy = (k % 196) / PATCH, dx = k % PATCH;
+        const int py = p >> 4, px = p & 15;
+        v = img[(((size_t)b * 3 + ci) * IMG + (py * PATCH + dy)) * IMG + px * PATCH + dx];
+    }
+    col[(size_t)k * (B * GP_P) + (size_t)b * GP_P + p] = v;
+}
+
+// ---- tokens = cat(cls, patches) + pos  (HF modeling_dinov2.py:108-112); zero the pad columns
+__global__ __launch_bounds__(320) void embed_kernel(const float* __restrict__ pe /*[C][B*256]*/,
+                                                     const float* __restrict__ cls_pos /*[C]*/,
+                                                     const float* __restrict__ pos_t /*[C][256]*/,
+                                                     float* __restrict__ X, int B, int Mpad)
+{
+    const int c = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    if (b == B) {  // extra block row: clear padding columns [B*T, Mpad)
+        for (int m = B * T_TOK + t; m < Mpad; m += 320) X[(size_t)c * Mpad + m] = 0.f;
+        return;
+    }
+    if (t >= T_TOK) return;
+    float v;
+    if (t == 0) v = cls_pos[c];
+    else v = pe[(size_t)c * (B * GP_P) + (size_t)b * GP_P + (t - 1)] + pos_t[(size_t)c * GP_P + (t - 1)];
+    X[(size_t)c * Mpad + (size_t)b * T_TOK + t] = v;
+}
+
+// ---- LayerNorm over C of channel-major X [C][Mpad]; thread = token column (coalesced)
+__global__ __launch_bounds__(128) void layernorm_kernel(const float* __restrict__ X, float* __restrict__ Y,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int C, int Mpad,
+                                                         float eps)
+{
+    const int m = blockIdx.x * 128 + threadIdx.x;
+    const float* x = X + m;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += x[(size_t)c * Mpad];
+    const float mean = s / (float)C;
+    float v = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float d = x[(size_t)c * Mpad] - mean;
+        v = __builtin_fmaf(d, d, v);
+    }
+    const float rstd = 1.0f / __builtin_sqrtf(v / (float)C + eps);
+    for (int c = 0; c < C; ++c)
+        Y[(size_t)c * Mpad + m] = (x[(size_t)c * Mpad] - mean) * rstd * gamma[c] + beta[c];
+}
+
+// ---- attention, one wave per (image, head, 32-query block); everything in registers.
+// S^T tile trick: compute D[i=key][j=query] = sum_d K[d][key] * Q[d][query] so that a lane owns ONE
+// query column and 16 key rows per tile: softmax over keys is in-register (+1 cross-half shuffle),
+// and the P values sit exactly where the P.V MFMA wants its B operand (k-slot = lane>>5), so P never
+// moves.  V is token-major (Vt[token][C]) so its A-operand loads are coalesced.
+// HF modeling_dinov2.py:207-229: softmax(q k^T * 64^-0.5) v   (0.125 is exact, so scaling after the
+// dot product equals scaling q first).
+constexpr int NKT = 9;  // ceil(257 / 32) key tiles
+
+__global__ __launch_bounds__(64, 1) void attention_kernel(const float* __restrict__ QK /*[2C][Mpad]*/,
+                                                           const float* __restrict__ Vt /*[Mpad][C]*/,
+                                                           float* __restrict__ O /*[C][Mpad]*/, int B, int H,
+                                                           int C, int Mpad, float scale)
+{
+    const int q = xcd_chunked_tile(blockIdx.x, B * H * NKT);
+    if (q < 0) return;
+    const int qb = q % NKT, bh = q / NKT, h = bh % H, b = bh / H;
+    const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
+    const float* Qp = QK + (size_t)(h * 64) * Mpad + (size_t)b * T_TOK;
+    const float* Kp = QK + (size_t)(C + h * 64) * Mpad + (size_t)b * T_TOK;
+    const float* Vp = Vt + (size_t)b * T_TOK * C + h * 64;
+    const int tq = qb * 32 + l31;
+    const int tq_c = tq < T_TOK ? tq : T_TOK - 1;
+
+    f32x16 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+
+    int tk_c[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int tk = kt * 32 + l31;
+        tk_c[kt] = tk < T_TOK ? tk : T_TOK - 1;
+    }
+#pragma unroll 4
+    for (int kk = 0; kk < 32; ++kk) {
+        const size_t drow = (size_t)(2 * kk + half) * Mpad;
+        const float qv = Qp[drow + tq_c];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const float kv = Kp[drow + tk_c[kt]];
+            s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv, s[kt], 0, 0, 0);
+        }
+    }
+    // scale, mask padded keys, row max (a "row" of the attention matrix = this lane's column)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tk = kt * 32 + frag_row(r, lane);
+            const float v = (tk < T_TOK) ? s[kt][r] * scale : -INFINITY;
+            s[kt][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = expf(s[kt][r] - mx);
+            s[kt][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+
+    // O[d][tq] = sum_tk V[tk][d] * P[tk][tq]; A operand lane (i = d, k-slot = half) reads
+    // V[tk = kt*32 + frag_row(r, lane)][d] -- the same key this lane's P register r belongs to.
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int tk = kt * 32 + frag_row(r, lane);
+                tk = tk < T_TOK ? tk : T_TOK - 1;  // P is 0 there; keep the load in bounds / finite
+                const float vv = Vp[(size_t)tk * C + dt * 32 + l31];
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[kt][r], o, 0, 0, 0);
+            }
+        if (tq < T_TOK) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = dt * 32 + frag_row(r, lane);
+                O[(size_t)(h * 64 + d) * Mpad + (size_t)b * T_TOK + tq] = o[r] * inv;
+            }
+        }
+    }
+}
+
+// ---- x_prenorm[:, 1:] -> (B, C, 256), F.normalize over C (ae_net.py:64-69); fixed fmaf order
+__global__ __launch_bounds__(256) void features_kernel(const float* __restrict__ X, float* __restrict__ out,
+                                                        int C, int Mpad, int normalize)
+{
+    const int b = blockIdx.x, p = threadIdx.x;
+    const float* x = X + (size_t)b * T_TOK + 1 + p;
+    float d = 1.f;
+    if (normalize) {
+        float ss = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float v = x[(size_t)c * Mpad];
+            ss = __builtin_fmaf(v, v, ss);
+        }
+        d = fmaxf(__builtin_sqrtf(ss), 1e-12f);
+    }
+    float* o = out + (size_t)b * C * GP_P + p;
+    for (int c = 0; c < C; ++c) o[(size_t)c * GP_P] = normalize ? x[(size_t)c * Mpad] / d : x[(size_t)c * Mpad];
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+// weight table layout (host array of device pointers), see include/gigapose_hip.h
+enum { W_PATCH_WT = 0, W_PATCH_B, W_CLS_POS, W_POS_T, W_HEADER = 4 };
+enum { L_LN1_G = 0, L_LN1_B, L_QK_WT, L_QK_B, L_V_WT, L_V_B, L_PROJ_WT, L_PROJ_B, L_LS1, L_LN2_G, L_LN2_B,
+       L_FC1_WT, L_FC1_B, L_FC2_WT, L_FC2_B, L_LS2, L_PER_LAYER = 16 };
+
+extern "C" {
+
+size_t gp_vit_workspace_bytes(int B, int dim, int mlp_dim)
+{
+    if (B <= 0 || dim <= 0 || mlp_dim <= 0) return 0;
+    const size_t Mpad = (size_t)round_up(B * T_TOK, 128);
+    // X, H (C each), QK (2C), Vt (C), F (mlp_dim; also hosts im2col + patch-embed output)
+    size_t f = (size_t)mlp_dim * Mpad;
+    const size_t pe_need = (size_t)KPE_PAD * B * GP_P + (size_t)dim * B * GP_P;
+    if (pe_need > f) f = pe_need;
+    return sizeof(float) * ((size_t)5 * dim * Mpad + f);
+}
+
+int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
+                   const float* const* weights, int n_weights, float* workspace, size_t workspace_bytes,
+                   float* out_features, int normalize, int stop_after_layers, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    GP_REQUIRE(B >= 0 && dim > 0 && depth > 0 && heads > 0, "gp_vit_forward: bad config");
+    if (B == 0) return GP_OK;
+    GP_REQUIRE(dim == heads * 64, "gp_vit_forward: head dim must be 64 (dim=%d heads=%d)", dim, heads);
+    GP_REQUIRE(dim % 128 == 0 && mlp_dim % 128 == 0, "gp_vit_forward: dim/mlp_dim must be multiples of 128");
+    GP_REQUIRE(n_weights == W_HEADER + depth * L_PER_LAYER, "gp_vit_forward: expected %d weight pointers, got %d",
+               W_HEADER + depth * L_PER_LAYER, n_weights);
+    GP_REQUIRE(images && weights && workspace && out_features, "gp_vit_forward: null pointer");
+    GP_REQUIRE(workspace_bytes >= gp_vit_workspace_bytes(B, dim, mlp_dim), "gp_vit_forward: workspace too small");
+    for (int i = 0; i < n_weights; ++i) GP_REQUIRE(weights[i], "gp_vit_forward: weight pointer %d is null", i);
+
+    const int C = dim, Mpad = round_up(B * T_TOK, 128), BP = B * GP_P;
+    float* X = workspace;
+    float* Hn = X + (size_t)C * Mpad;
+    float* QK = Hn + (size_t)C * Mpad;
+    float* Vt = QK + (size_t)2 * C * Mpad;
+    float* F = Vt + (size_t)C * Mpad;
+    float* col = F;                            // [592][B*256]
+    float* pe = F + (size_t)KPE_PAD * BP;      // [C][B*256]
+    int rc;
+
+    hipLaunchKernelGGL(im2col_kernel, dim3(KPE_PAD, B), dim3(256), 0, st, images, col, B);
+    GP_CHECK_LAUNCH("gp_vit_forward/im2col");
+    // BP = B*256 is a multiple of 128 only for even B... (256 is) -> always a multiple of 128
+    if ((rc = gp_gemm_launch(weights[W_PATCH_WT], C, col, BP, pe, BP, C, BP, KPE_PAD, 1 /*BIAS_I*/,
+                             weights[W_PATCH_B], nullptr, nullptr, 0, st)))
+        return rc;
+    hipLaunchKernelGGL(embed_kernel, dim3(C, B + 1), dim3(320), 0, st, pe, weights[W_CLS_POS], weights[W_POS_T],
+                       X, B, Mpad);
+    GP_CHECK_LAUNCH("gp_vit_forward/embed");
+
+    const int nl = (stop_after_layers >= 0 && stop_after_layers < depth) ? stop_after_layers : depth;
+    for (int l = 0; l < nl; ++l) {
+        const float* const* w = weights + W_HEADER + l * L_PER_LAYER;
+        hipLaunchKernelGGL(layernorm_kernel, dim3(Mpad / 128), dim3(128), 0, st, X, Hn, w[L_LN1_G], w[L_LN1_B], C,
+                           Mpad, ln_eps);
+        // Q,K channel-major [2C][Mpad]
+        if ((rc = gp_gemm_launch(w[L_QK_WT], 2 * C, Hn, Mpad, QK, Mpad, 2 * C, Mpad, C, 1, w[L_QK_B], nullptr,
+                                 nullptr, 0, st)))
+            return rc;
+        // V token-major [Mpad][C]: swap operand roles (A = activations, B = weights), bias along j
+        if ((rc = gp_gemm_launch(Hn, Mpad, w[L_V_WT], C, Vt, C, Mpad, C, C, 4 /*BIAS_J*/, w[L_V_B], nullptr,
+                                 nullptr, 0, st)))
+            return rc;
+        hipLaunchKernelGGL(attention_kernel, dim3(xcd_chunked_grid(B * heads * NKT)), dim3(64), 0, st, QK, Vt, Hn,
+                           B, heads, C, Mpad, 0.125f);
+        GP_CHECK_LAUNCH("gp_vit_forward/attention");
+        // x = x + ls1 * proj(attn)
+        if ((rc = gp_gemm_launch(w[L_PROJ_WT], C, Hn, Mpad, X, Mpad, C, Mpad, C, 3, w[L_PROJ_B], w[L_LS1], X, Mpad,
+                                 st)))
+            return rc;
+        hipLaunchKernelGGL(layernorm_kernel, dim3(Mpad / 128), dim3(128), 0, st, X, Hn, w[L_LN2_G], w[L_LN2_B], C,
+                           Mpad, ln_eps);
+        if ((rc = gp_gemm_launch(w[L_FC1_WT], mlp_dim, Hn, Mpad, F, Mpad, mlp_dim, Mpad, C, 2 /*GELU*/, w[L_FC1_B],
+                                 nullptr, nullptr, 0, st)))
+            return rc;
+        // x = x + ls2 * fc2(gelu(fc1))
+        if ((rc = gp_gemm_launch(w[L_FC2_WT], C, F, Mpad, X, Mpad, C, Mpad, mlp_dim, 3, w[L_FC2_B], w[L_LS2], X,
+                                 Mpad, st)))
+            return rc;
+    }
+    hipLaunchKernelGGL(features_kernel, dim3(B), dim3(256), 0, st, X, out_features, C, Mpad, normalize);
+    GP_CHECK_LAUNCH("gp_vit_forward/features");
+    return GP_OK;
+}
+
+}  // extern "C"

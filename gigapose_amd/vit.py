@@ -1,0 +1,183 @@
+"""DINOv2 ViT backbone on MI355X (libgigapose_hip.so: gp_vit_forward).
+
+Stands where the reference puts `torch.hub.load("facebookresearch/dinov2", "dinov2_vitl14")`
+(configs/model/ae_net/dinov2_l.yaml:4-7; called at ae_net.py:44-47 as
+`dinov2_model.forward_features(x)["x_prenorm"]`).  Parameters use the hub model's names
+(`patch_embed.proj`, `blocks.{i}.attn.qkv`, `ls1.gamma`, ...) so that the reference checkpoint's
+`ae_net.dinov2_model.*` keys load unchanged; `from_hf()` converts the HF `Dinov2Model` stand-in
+used as CPU oracle.  All arithmetic is in the HIP library; this class owns weights + workspace.
+"""
+import ctypes
+import math
+
+import torch
+from torch import nn
+
+from . import _lib
+
+VARIANTS = {  # name: (dim, depth, heads)
+    "dinov2_vits14": (384, 12, 6),
+    "dinov2_vitb14": (768, 12, 12),
+    "dinov2_vitl14": (1024, 24, 16),
+}
+T = 257
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, mlp_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = nn.Module()
+        self.attn.qkv = nn.Linear(dim, 3 * dim)
+        self.attn.proj = nn.Linear(dim, dim)
+        self.ls1 = nn.Module()
+        self.ls1.gamma = nn.Parameter(torch.ones(dim))
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = nn.Module()
+        self.mlp.fc1 = nn.Linear(dim, mlp_dim)
+        self.mlp.fc2 = nn.Linear(mlp_dim, dim)
+        self.ls2 = nn.Module()
+        self.ls2.gamma = nn.Parameter(torch.ones(dim))
+
+
+class Dinov2ViT(nn.Module):
+    """patch 14, 224x224 input (16x16 patches + CLS), head dim 64, MLP ratio 4, GELU(erf),
+    LayerScale, pre-norm; forward stops BEFORE the final LayerNorm (x_prenorm)."""
+
+    def __init__(self, dim=1024, depth=24, heads=16, mlp_ratio=4, num_pos=T):
+        super().__init__()
+        assert dim == heads * 64, "kernels are specialised for head dim 64"
+        self.dim, self.depth, self.heads, self.mlp_dim = dim, depth, heads, dim * mlp_ratio
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_pos, dim))
+        self.mask_token = nn.Parameter(torch.zeros(1, dim))  # unused at inference; keeps ckpt keys
+        self.patch_embed = nn.Module()
+        self.patch_embed.proj = nn.Conv2d(3, dim, kernel_size=14, stride=14)
+        self.blocks = nn.ModuleList([_Block(dim, self.mlp_dim) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=1e-6)  # final norm: present in checkpoints, not applied
+        self._packed = None
+        self._ws = None
+
+    # ---------------------------------------------------------------- construction helpers
+    @classmethod
+    def from_name(cls, name):
+        dim, depth, heads = VARIANTS[name]
+        return cls(dim, depth, heads)
+
+    @classmethod
+    def from_hf(cls, hf_model):
+        """Convert a transformers.Dinov2Model (separate q/k/v, `layer_scale1.lambda1` naming)."""
+        cfg = hf_model.config
+        m = cls(cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, int(cfg.mlp_ratio))
+        sd = hf_model.state_dict()
+        out = {
+            "cls_token": sd["embeddings.cls_token"],
+            "pos_embed": sd["embeddings.position_embeddings"],
+            "mask_token": sd["embeddings.mask_token"],
+            "patch_embed.proj.weight": sd["embeddings.patch_embeddings.projection.weight"],
+            "patch_embed.proj.bias": sd["embeddings.patch_embeddings.projection.bias"],
+            "norm.weight": sd["layernorm.weight"],
+            "norm.bias": sd["layernorm.bias"],
+        }
+        for i in range(m.depth):
+            p = f"encoder.layer.{i}."
+            a = p + "attention.attention."
+            out[f"blocks.{i}.norm1.weight"] = sd[p + "norm1.weight"]
+            out[f"blocks.{i}.norm1.bias"] = sd[p + "norm1.bias"]
+            out[f"blocks.{i}.attn.qkv.weight"] = torch.cat([sd[a + "query.weight"], sd[a + "key.weight"], sd[a + "value.weight"]])
+            out[f"blocks.{i}.attn.qkv.bias"] = torch.cat([sd[a + "query.bias"], sd[a + "key.bias"], sd[a + "value.bias"]])
+            out[f"blocks.{i}.attn.proj.weight"] = sd[p + "attention.output.dense.weight"]
+            out[f"blocks.{i}.attn.proj.bias"] = sd[p + "attention.output.dense.bias"]
+            out[f"blocks.{i}.ls1.gamma"] = sd[p + "layer_scale1.lambda1"]
+            out[f"blocks.{i}.norm2.weight"] = sd[p + "norm2.weight"]
+            out[f"blocks.{i}.norm2.bias"] = sd[p + "norm2.bias"]
+            out[f"blocks.{i}.mlp.fc1.weight"] = sd[p + "mlp.fc1.weight"]
+            out[f"blocks.{i}.mlp.fc1.bias"] = sd[p + "mlp.fc1.bias"]
+            out[f"blocks.{i}.mlp.fc2.weight"] = sd[p + "mlp.fc2.weight"]
+            out[f"blocks.{i}.mlp.fc2.bias"] = sd[p + "mlp.fc2.bias"]
+            out[f"blocks.{i}.ls2.gamma"] = sd[p + "layer_scale2.lambda1"]
+        m.load_state_dict(out)
+        return m.eval()
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """Checkpoints trained at 518x518 carry a 1+37*37 position table; resample it once on the
+        host to the 16x16 grid used at 224x224 (DINOv2 does this bicubically at run time)."""
+        key = prefix + "pos_embed"
+        if key in state_dict and state_dict[key].shape[1] != self.pos_embed.shape[1]:
+            pe = state_dict[key].float()
+            n = int(round(math.sqrt(pe.shape[1] - 1)))
+            grid = pe[:, 1:].reshape(1, n, n, -1).permute(0, 3, 1, 2)
+            grid = nn.functional.interpolate(grid, size=(16, 16), mode="bicubic", align_corners=False)
+            state_dict[key] = torch.cat([pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, 256, -1)], dim=1)
+        self._packed = None
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    # ---------------------------------------------------------------- weight packing
+    def invalidate(self):
+        self._packed = None
+
+    @torch.no_grad()
+    def _pack(self, device):
+        """Channel-major (pre-transposed) f32 copies of every weight + the host pointer table
+        gp_vit_forward expects (order documented in include/gigapose_hip.h)."""
+        def dev(t):
+            return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+        C = self.dim
+        w = self.patch_embed.proj.weight.detach().float().reshape(C, 588).t()
+        patch_wt = torch.zeros(592, C)
+        patch_wt[:588] = w.cpu()
+        tensors = [dev(patch_wt), dev(self.patch_embed.proj.bias),
+                   dev((self.cls_token[0, 0] + self.pos_embed[0, 0])),
+                   dev(self.pos_embed[0, 1:].t())]
+        for blk in self.blocks:
+            qkv_w, qkv_b = blk.attn.qkv.weight, blk.attn.qkv.bias
+            tensors += [dev(blk.norm1.weight), dev(blk.norm1.bias),
+                        dev(qkv_w[:2 * C].t()), dev(qkv_b[:2 * C]),
+                        dev(qkv_w[2 * C:].t()), dev(qkv_b[2 * C:]),
+                        dev(blk.attn.proj.weight.t()), dev(blk.attn.proj.bias), dev(blk.ls1.gamma),
+                        dev(blk.norm2.weight), dev(blk.norm2.bias),
+                        dev(blk.mlp.fc1.weight.t()), dev(blk.mlp.fc1.bias),
+                        dev(blk.mlp.fc2.weight.t()), dev(blk.mlp.fc2.bias), dev(blk.ls2.gamma)]
+        table = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        self._packed = (device, tensors, table)
+
+    def _workspace(self, B, device):
+        lib = _lib.lib()
+        lib.gp_vit_workspace_bytes.restype = ctypes.c_size_t
+        need = lib.gp_vit_workspace_bytes(_lib.i(B), _lib.i(self.dim), _lib.i(self.mlp_dim))
+        if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != device:
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+        return self._ws, need
+
+    # ---------------------------------------------------------------- forward
+    @torch.no_grad()
+    def patch_features(self, images, normalize=True, stop_after_layers=-1):
+        """images (B,3,224,224) f32 -> (B, C, 16, 16): x_prenorm[:, 1:] rearranged 'b (h w) c ->
+        b c h w' and (optionally) L2-normalised over C -- i.e. AENet.forward_by_chunk's result."""
+        if images.shape[1:] != (3, 224, 224):
+            raise ValueError(f"expected (B,3,224,224) crops, got {tuple(images.shape)}")
+        device = images.device
+        if self._packed is None or self._packed[0] != device:
+            self._pack(device)
+        B = images.shape[0]
+        x = images.contiguous().float()
+        out = torch.empty(B, self.dim, 16, 16, dtype=torch.float32, device=device)
+        if B == 0:
+            return out
+        ws, need = self._workspace(B, device)
+        _, tensors, table = self._packed
+        _lib.call("gp_vit_forward", _lib.ptr(x), _lib.i(B), _lib.i(self.dim), _lib.i(self.depth),
+                  _lib.i(self.heads), _lib.i(self.mlp_dim), _lib.f(1e-6), table, _lib.i(len(tensors)),
+                  _lib.ptr(ws), ctypes.c_size_t(need), _lib.ptr(out), _lib.i(1 if normalize else 0),
+                  _lib.i(stop_after_layers), _lib.stream_ptr())
+        return out
+
+    @torch.no_grad()
+    def forward_features(self, images):
+        """hub-API compatibility: {"x_prenorm": (B, 257, C)} (token-major view of the workspace)."""
+        B = images.shape[0]
+        self.patch_features(images, normalize=False)
+        mpad = (B * T + 127) // 128 * 128
+        xt = self._ws[: self.dim * mpad].view(self.dim, mpad)[:, : B * T]
+        return {"x_prenorm": xt.t().reshape(B, T, self.dim).contiguous()}

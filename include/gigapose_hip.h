@@ -14,6 +14,7 @@
  */
 #ifndef GIGAPOSE_HIP_H
 #define GIGAPOSE_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -55,6 +56,42 @@ int gp_gather_records(const int* ids, const uint8_t* idx_t2s, const float* score
  * tar_pts, src_pts int64 (rows,256,2) as (x,y), -1 where rec_mask == 0.  rows = B*k. */
 int gp_format_points(const uint8_t* rec_idx, const float* rec_mask, int rows, long long* tar_pts,
                      long long* src_pts, void* stream);
+
+/* ---- dense layers: k-major f32 MFMA GEMM ---------------------------------------------------- */
+
+/* D[i][j] = epi( sum_k A[k][i] * B[k][j] ), A (K,lda), B (K,ldb), D (I,ldd); accumulation is the
+ * sequential fmaf chain over k.  Stands for torch.nn.Linear on TRANSPOSED activations
+ * (A = W^T [in][out], B = X^T [in][tokens] -> D = Y^T [out][tokens]): DINOv2 qkv/proj/fc1/fc2 (the
+ * un-vendored backbone called at src/models/network/ae_net.py:44-47) and the IST regressor MLPs
+ * (src/models/network/ist_net.py:140-155).
+ * epilogue: 0 none | 1 +bias[i] | 2 gelu_erf(+bias[i]) | 3 residual[i][j] + scale[i]*(acc+bias[i])
+ *           (D may alias residual) | 4 +bias[j] | 5 relu(+bias[i]).
+ * Requires I % 128 == 0, J % 128 == 0, K % 16 == 0, lda/ldb % 4 == 0, 16-byte aligned A/B. */
+int gp_gemm_kmajor(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J,
+                   int K, int epilogue, const float* bias, const float* scale, const float* residual,
+                   int ldr, void* stream);
+
+/* ---- DINOv2 ViT patch features: AENet.forward (src/models/network/ae_net.py:44-73) ---------- */
+
+/* Bytes of device workspace gp_vit_forward needs for B crops. */
+size_t gp_vit_workspace_bytes(int B, int dim, int mlp_dim);
+
+/* images (B,3,224,224) f32 (CLIP-normalised crops) -> out_features (B, dim, 256):
+ * `forward_features(x)["x_prenorm"][:, 1:, :]` rearranged "b (h w) c -> b c h w" and, if
+ * normalize != 0, F.normalize(dim=1) (ae_net.py:64-69).  The final LayerNorm is not applied.
+ * patch 14, 257 tokens, head dim 64 (dim == 64*heads), GELU(erf), LayerScale, pre-norm, ln_eps 1e-6.
+ * `weights`: HOST array of n_weights = 4 + 16*depth DEVICE pointers, all f32, pre-transposed:
+ *   [0] patch_w^T (592, dim)  rows k = ci*196 + dy*14 + dx, rows 588..591 zero
+ *   [1] patch_b (dim)   [2] cls_token + pos_embed[0] (dim)   [3] pos_embed[1:]^T (dim, 256)
+ *   per layer l at 4 + 16*l:  ln1_g, ln1_b, Wqk^T (dim, 2dim), bqk (2dim), Wv^T (dim, dim), bv,
+ *                             Wproj^T (dim, dim), bproj, ls1, ln2_g, ln2_b, Wfc1^T (dim, mlp),
+ *                             bfc1, Wfc2^T (mlp, dim), bfc2, ls2
+ * stop_after_layers: < 0 = all layers (otherwise run only that many blocks; test hook).
+ * After the call the workspace's first dim*Mpad floats hold x_prenorm^T (dim, Mpad),
+ * column b*257 + t, Mpad = round_up(257*B, 128). */
+int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
+                   const float* const* weights, int n_weights, float* workspace, size_t workspace_bytes,
+                   float* out_features, int normalize, int stop_after_layers, void* stream);
 
 #ifdef __cplusplus
 }

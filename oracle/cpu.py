@@ -123,3 +123,20 @@ def local_similarity_test(src_feats, tar_feat, src_masks224, tar_mask224, labels
     return dict(id_src=ids.astype(np.int64), score_src=score_src, score_pts=score_pts,
                 tar_pts=tar_pts, src_pts=src_pts, sim_avg=avg, idx_t2s=idx, score_t2s=sc,
                 mask_all=ma)
+
+
+def gemm_kmajor(A, B, epi=0, bias=None, scale=None, res=None):
+    """D[i][j] = epi(sum_k A[k][i] B[k][j]) with the sequential-fmaf order of gp_gemm.hip."""
+    A, B = _f32(A), _f32(B)
+    K, I = A.shape
+    K2, J = B.shape
+    assert K == K2
+    D = np.empty((I, J), np.float32)
+    bias = None if bias is None else _f32(bias)
+    scale = None if scale is None else _f32(scale)
+    res = None if res is None else _f32(res)
+    lib().oracle_gemm_kmajor(_p(A), ctypes.c_int(I), _p(B), ctypes.c_int(J), _p(D), ctypes.c_int(J),
+                             ctypes.c_int(I), ctypes.c_int(J), ctypes.c_int(K), ctypes.c_int(epi),
+                             _p(bias) if bias is not None else None, _p(scale) if scale is not None else None,
+                             _p(res) if res is not None else None, ctypes.c_int(J))
+    return D

@@ -179,3 +179,36 @@ void oracle_gather_format(const int32_t* ids, const uint8_t* idx_t2s, const floa
             }
         }
 }
+
+/* ------------------------------------------------------------------------------------
+ * k-major GEMM with the epilogues of gigapose_amd/csrc/gp_gemm.hip:
+ *   D[i][j] = epi( fmaf-chain_k A[k][i]*B[k][j] ).
+ * Restates torch.nn.Linear as used by the DINOv2 block (HF modeling_dinov2.py:199-297) and the
+ * IST regressor (reference ist_net.py:140-155) with a FIXED accumulation order (k ascending).
+ * epi: 0 none, 1 +bias[i], 2 gelu_erf(+bias[i]), 3 res + scale[i]*(acc+bias[i]), 4 +bias[j],
+ *      5 relu(+bias[i]).
+ * ---------------------------------------------------------------------------------- */
+void oracle_gemm_kmajor(const float* A, int lda, const float* B, int ldb, float* D, int ldd,
+                        int I, int J, int K, int epi, const float* bias, const float* scale,
+                        const float* res, int ldr)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < I; ++i) {
+        float* acc = (float*)calloc((size_t)J, sizeof(float));
+        for (int k = 0; k < K; ++k) {
+            const float a = A[(size_t)k * lda + i];
+            const float* b = B + (size_t)k * ldb;
+            for (int j = 0; j < J; ++j) acc[j] = fmaf(a, b[j], acc[j]);
+        }
+        for (int j = 0; j < J; ++j) {
+            float v = acc[j];
+            if (epi == 1 || epi == 2 || epi == 3 || epi == 5) v = v + bias[i];
+            if (epi == 4) v = v + bias[j];
+            if (epi == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            if (epi == 5) v = fmaxf(v, 0.f);
+            if (epi == 3) v = res[(size_t)i * ldr + j] + scale[i] * v;
+            D[(size_t)i * ldd + j] = v;
+        }
+        free(acc);
+    }
+}

@@ -1,0 +1,119 @@
+"""GPU parity: k-major f32 MFMA GEMM (bit-exact vs the oracle's fmaf chain) and the HIP DINOv2
+forward vs the numpy restatement and the HF Dinov2Model stand-in (floating point: tolerance)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu as oracle
+from oracle import vit_numpy
+from test_oracle_vit import hf_model, sd_numpy
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def hip_gemm(A, B, epi=0, bias=None, scale=None, res=None):
+    from gigapose_amd import _lib
+
+    K, I = A.shape
+    J = B.shape[1]
+    tA, tB = torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV)
+    D = torch.empty(I, J, device=DEV)
+    tb = None if bias is None else torch.from_numpy(bias).to(DEV)
+    ts = None if scale is None else torch.from_numpy(scale).to(DEV)
+    tr = None if res is None else torch.from_numpy(res).to(DEV)
+    _lib.call("gp_gemm_kmajor", _lib.ptr(tA), _lib.i(I), _lib.ptr(tB), _lib.i(J), _lib.ptr(D), _lib.i(J),
+              _lib.i(I), _lib.i(J), _lib.i(K), _lib.i(epi), _lib.ptr(tb), _lib.ptr(ts), _lib.ptr(tr), _lib.i(J),
+              _lib.stream_ptr())
+    torch.cuda.synchronize()
+    return D.cpu().numpy()
+
+
+@pytest.mark.parametrize("epi", [0, 1, 3, 4, 5])
+def test_gemm_bit_exact_vs_fmaf_chain(epi):
+    rs = np.random.RandomState(40 + epi)
+    I, J, K = 256, 384, 80          # asymmetric everything: catches transposes / tile swaps
+    A = rs.standard_normal((K, I)).astype(np.float32)
+    B = rs.standard_normal((K, J)).astype(np.float32)
+    bias = rs.standard_normal(J if epi == 4 else I).astype(np.float32)
+    scale = rs.standard_normal(I).astype(np.float32)
+    res = rs.standard_normal((I, J)).astype(np.float32)
+    got = hip_gemm(A, B, epi, bias, scale, res)
+    ref = oracle.gemm_kmajor(A, B, epi, bias, scale, res)
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    np.testing.assert_allclose(got if epi == 0 else got, ref, rtol=1e-6)
+
+
+def test_gemm_gelu_and_errors():
+    from gigapose_amd import _lib
+
+    rs = np.random.RandomState(50)
+    A = rs.standard_normal((32, 128)).astype(np.float32)
+    B = rs.standard_normal((32, 128)).astype(np.float32)
+    bias = rs.standard_normal(128).astype(np.float32)
+    got = hip_gemm(A, B, 2, bias)
+    ref = torch.nn.functional.gelu(torch.from_numpy((A.T.astype(np.float64) @ B.astype(np.float64)).astype(np.float32)
+                                                    + bias[:, None])).numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)
+    with pytest.raises(_lib.GigaPoseHipError):
+        hip_gemm(A[:, :100].copy(), B)  # I not a multiple of 128
+
+
+def run_vit(dim, depth, heads, B, seed, stop=None):
+    from gigapose_amd.vit import Dinov2ViT
+
+    hf = hf_model(dim, depth, heads, seed=seed)
+    vit = Dinov2ViT.from_hf(hf).to(DEV)
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(seed + 1))
+    return hf, vit, x
+
+
+@pytest.mark.parametrize("stop", [0, 1, 2])
+def test_vit_layerwise_small(stop):
+    """dim 128 / depth 2: embeddings only, one block, two blocks -- localises any layout bug."""
+    hf, vit, x = run_vit(128, 2, 2, 3, seed=60)
+    got = vit.patch_features(x.to(DEV), normalize=False, stop_after_layers=stop).cpu().numpy()
+    ref = vit_numpy.patch_features(sd_numpy(vit.cpu()), x.numpy(), 2, 2, normalize=False, stop_after_layers=stop)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=3e-5)
+
+
+def test_vit_small_s14_vs_hf_and_numpy():
+    """ViT-S/14 (BASELINE config 1 backbone), B=3 (Mpad padding exercised: 771 -> 896)."""
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    hf, vit, x = run_vit(384, 12, 6, 3, seed=70)
+    feats = vit.patch_features(x.to(DEV)).cpu()
+    xp = vit.forward_features(x.to(DEV))["x_prenorm"].cpu()
+    with torch.no_grad():
+        ref = hf(pixel_values=x, output_hidden_states=True).hidden_states[-1]
+    np.testing.assert_allclose(xp.numpy(), ref.numpy(), rtol=2e-4, atol=1e-4)
+    ref_f = torch.nn.functional.normalize(ref[:, 1:].permute(0, 2, 1), dim=1).reshape(3, 384, 16, 16)
+    np.testing.assert_allclose(feats.numpy(), ref_f.numpy(), rtol=0, atol=2e-5)
+    ref_np = vit_numpy.patch_features(sd_numpy(vit.cpu()), x.numpy(), 12, 6)
+    np.testing.assert_allclose(feats.numpy(), ref_np, rtol=0, atol=2e-5)
+
+
+def test_vit_large_l14_vs_hf():
+    """ViT-L/14 (the north-star backbone), B=2, against HF on the host CPU."""
+    hf, vit, x = run_vit(1024, 24, 16, 2, seed=80)
+    feats = vit.patch_features(x.to(DEV)).cpu()
+    with torch.no_grad():
+        ref = hf(pixel_values=x, output_hidden_states=True).hidden_states[-1]
+    ref_f = torch.nn.functional.normalize(ref[:, 1:].permute(0, 2, 1), dim=1).reshape(2, 1024, 16, 16)
+    np.testing.assert_allclose(feats.numpy(), ref_f.numpy(), rtol=0, atol=3e-5)
+    # chunking / batch-size independence: same crop alone gives the same features bit-for-bit
+    one = vit.to(DEV).patch_features(x[:1].to(DEV)).cpu()
+    np.testing.assert_array_equal(one.numpy().view(np.uint32), feats[:1].numpy().view(np.uint32))
+
+
+def test_aenet_interface_chunks():
+    from gigapose_amd.ae_net import AENet
+
+    hf, vit, x = run_vit(128, 2, 2, 5, seed=90)
+    net = AENet("dinov2_vits14", vit.to(DEV), descriptor_size=128, max_batch_size=2)
+    a = net(x.to(DEV))
+    b = vit.patch_features(x.to(DEV))
+    assert tuple(a.shape) == (5, 128, 16, 16)
+    np.testing.assert_array_equal(a.cpu().numpy().view(np.uint32), b.cpu().numpy().view(np.uint32))
+    assert tuple(net(x[:0].to(DEV)).shape) == (0, 128, 16, 16)

@@ -1,0 +1,34 @@
+"""GPU probe: time the HIP ViT forward (ViT-L/14, B=64) and a few GEMM shapes."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gigapose_amd.vit import Dinov2ViT
+from gigapose_amd import _lib
+
+dev = "cuda"
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+for (I, J, K) in [(1024, 16512, 1024), (4096, 16512, 1024), (1024, 16512, 4096), (2048, 16512, 1024)]:
+    A = torch.randn(K, I, device=dev); Bm = torch.randn(K, J, device=dev); D = torch.empty(I, J, device=dev)
+    ms = timeit(lambda: _lib.call("gp_gemm_kmajor", _lib.ptr(A), _lib.i(I), _lib.ptr(Bm), _lib.i(J), _lib.ptr(D), _lib.i(J),
+                                  _lib.i(I), _lib.i(J), _lib.i(K), _lib.i(0), None, None, None, _lib.i(J), _lib.stream_ptr()))
+    print(f"gemm I={I} J={J} K={K}: {ms:.3f} ms {2.0*I*J*K/ms/1e9:.1f} TF")
+
+name = sys.argv[1] if len(sys.argv) > 1 else "dinov2_vitl14"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+torch.manual_seed(0)
+vit = Dinov2ViT.from_name(name)
+for p in vit.parameters():
+    torch.nn.init.normal_(p, std=0.02)
+vit = vit.to(dev)
+x = torch.randn(B, 3, 224, 224, device=dev)
+ms = timeit(lambda: vit.patch_features(x), iters=3, warm=1)
+fl = {"dinov2_vitl14": 162.0e9, "dinov2_vits14": 12.25e9, "dinov2_vitb14": 0}[name] * B
+print(f"{name} B={B}: {ms:.2f} ms/forward -> {B/ms*1e3:.1f} crops/s, {fl/ms/1e9:.1f} TFLOP/s (f32 peak 157.3)")

@@ -1,0 +1,124 @@
+// IST per-correspondence regressor on gfx950: gather + concat + two 3-layer MLP heads.
+// Reference: ISTNet.inference (src/models/network/ist_net.py:97-120), gather
+// (src/utils/batch.py:46-73), Regressor (ist_net.py:123-162).
+//
+// The reference compacts valid correspondences, runs the MLPs, and scatters the results into
+// (B,P)/(B,P,2) tensors pre-filled with -1000.  Here every (detection, hypothesis, patch) row is
+// evaluated (rows are independent, so results for valid rows are identical) and invalid rows get
+// -1000 in the head kernel: no data-dependent sizes, no host sync.  The two hidden layers are the
+// k-major f32 MFMA GEMM of gp_gemm.hip on the transposed feature matrix X^T [2D][rows].
+#include "gp_common.h"
+
+int gp_gemm_launch(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J,
+                   int K, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
+                   hipStream_t st);
+
+namespace {
+
+// X[c][r]: c < D -> tar_feat[b][c][ti],  c >= D -> src_bank[obj][view][c-D][si]     ("cat([tar, src])",
+// ist_net.py:100).  Row r = (b*k + j)*256 + t.  Invalid rows (-1 points) read index 0 (finite, unused).
+__global__ __launch_bounds__(256) void ist_gather_kernel(
+    const float* __restrict__ tar_feat,  // (B, D, 256)
+    const float* __restrict__ src_bank,  // (O, N, D, 256)
+    const int* __restrict__ labels, const long long* __restrict__ id_src,  // (B), (B,k)
+    const long long* __restrict__ tar_pts, const long long* __restrict__ src_pts,  // (B,k,256,2)
+    int N, int k, int D, size_t R, float* __restrict__ X)
+{
+    const int bk = blockIdx.x, b = bk / k, t = threadIdx.x;
+    const size_t r = (size_t)bk * GP_P + t;
+    const long long tx = tar_pts[2 * r], ty = tar_pts[2 * r + 1];
+    const long long sx = src_pts[2 * r], sy = src_pts[2 * r + 1];
+    const bool valid = (tx != -1) && (ty != -1) && (sx != -1) && (sy != -1);
+    const int ti = valid ? (int)(ty * GP_G + tx) : 0;  // index = y * W + x   (batch.py:63)
+    const int si = valid ? (int)(sy * GP_G + sx) : 0;
+    const float* tf = tar_feat + (size_t)b * D * GP_P + ti;
+    const float* sf = src_bank + (((size_t)labels[b] * N + (size_t)id_src[bk]) * D) * GP_P + si;
+    for (int c = 0; c < D; ++c) X[(size_t)c * R + r] = tf[(size_t)c * GP_P];
+    for (int c = 0; c < D; ++c) X[(size_t)(D + c) * R + r] = sf[(size_t)c * GP_P];
+}
+
+// Final Linear(H -> nout) (+ tanh) and the -1000 fill of invalid rows (ist_net.py:109-119).
+// out layout (R, nout).  Accumulation: sequential fmaf over the H hidden units, then + bias.
+template <int NOUT>
+__global__ __launch_bounds__(256) void ist_head_kernel(const float* __restrict__ Hid /*[H][R]*/,
+                                                        const float* __restrict__ W3 /*[NOUT][H]*/,
+                                                        const float* __restrict__ b3,
+                                                        const long long* __restrict__ tar_pts,
+                                                        const long long* __restrict__ src_pts, int H, size_t R,
+                                                        int use_tanh, float* __restrict__ out)
+{
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float acc[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) acc[o] = 0.f;
+    for (int h = 0; h < H; ++h) {
+        const float x = Hid[(size_t)h * R + r];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) acc[o] = __builtin_fmaf(W3[o * H + h], x, acc[o]);
+    }
+    // validity as the reference computes it (ist_net.py:114-115): both coordinates != -1
+    const bool sv = (src_pts[2 * r] != -1) && (src_pts[2 * r + 1] != -1);
+    const bool tv = (tar_pts[2 * r] != -1) && (tar_pts[2 * r + 1] != -1);
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        float v = acc[o] + b3[o];
+        if (use_tanh) v = tanhf(v);
+        out[r * NOUT + o] = (sv && tv) ? v : -1000.0f;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gp_ist_workspace_bytes(int B, int k, int D, int H)
+{
+    if (B <= 0 || k <= 0) return 0;
+    const size_t R = (size_t)B * k * GP_P;
+    return sizeof(float) * R * ((size_t)2 * D + 2 * H + H);  // X, H1, H2
+}
+
+int gp_ist_regress(const float* tar_feat, const float* src_bank, const int* labels, const long long* id_src,
+                   const long long* tar_pts, const long long* src_pts, int B, int O, int N, int k, int D,
+                   int H, const float* const* weights, int n_weights, int use_tanh, float* workspace,
+                   size_t workspace_bytes, float* scales, float* cos_sin, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    GP_REQUIRE(B >= 0 && O > 0 && N > 0 && k > 0, "gp_ist_regress: bad sizes");
+    GP_REQUIRE(D > 0 && (2 * D) % 16 == 0 && H % 128 == 0 && H > 0,
+               "gp_ist_regress: descriptor %d / hidden %d not supported (2D %% 16, H %% 128)", D, H);
+    GP_REQUIRE(n_weights == 12, "gp_ist_regress: expected 12 weight pointers, got %d", n_weights);
+    if (B == 0) return GP_OK;
+    GP_REQUIRE(tar_feat && src_bank && labels && id_src && tar_pts && src_pts && weights && workspace && scales &&
+                   cos_sin, "gp_ist_regress: null pointer");
+    GP_REQUIRE(workspace_bytes >= gp_ist_workspace_bytes(B, k, D, H), "gp_ist_regress: workspace too small");
+    for (int i = 0; i < 12; ++i) GP_REQUIRE(weights[i], "gp_ist_regress: weight pointer %d is null", i);
+    const size_t R = (size_t)B * k * GP_P;
+    GP_REQUIRE(R < (size_t)1 << 31, "gp_ist_regress: too many rows");
+    float* X = workspace;
+    float* H1 = X + (size_t)2 * D * R;
+    float* H2 = H1 + (size_t)2 * H * R;
+    hipLaunchKernelGGL(ist_gather_kernel, dim3(B * k), dim3(256), 0, st, tar_feat, src_bank, labels, id_src,
+                       tar_pts, src_pts, N, k, D, R, X);
+    GP_CHECK_LAUNCH("gp_ist_regress/gather");
+    int rc;
+    for (int head = 0; head < 2; ++head) {  // 0: scale_predictor, 1: inplane_predictor (ist_net.py:140-155)
+        const float* const* w = weights + head * 6;  // W1^T [2D][2H], b1, W2^T [2H][H], b2, W3 [nout][H], b3
+        if ((rc = gp_gemm_launch(w[0], 2 * H, X, (int)R, H1, (int)R, 2 * H, (int)R, 2 * D, 5, w[1], nullptr, nullptr,
+                                 0, st)))
+            return rc;
+        if ((rc = gp_gemm_launch(w[2], H, H1, (int)R, H2, (int)R, H, (int)R, 2 * H, 5, w[3], nullptr, nullptr, 0,
+                                 st)))
+            return rc;
+        if (head == 0)
+            hipLaunchKernelGGL(ist_head_kernel<1>, dim3((unsigned)(R / 256)), dim3(256), 0, st, H2, w[4], w[5],
+                               tar_pts, src_pts, H, R, 0, scales);
+        else
+            hipLaunchKernelGGL(ist_head_kernel<2>, dim3((unsigned)(R / 256)), dim3(256), 0, st, H2, w[4], w[5],
+                               tar_pts, src_pts, H, R, use_tanh, cos_sin);
+        GP_CHECK_LAUNCH("gp_ist_regress/head");
+    }
+    return GP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+"""`GigaPose` inference orchestration behind the reference interface
+(src/models/gigaPose.py:34-77 ctor, :357-398 set_template_data, :481-633 eval_retrieval,
+:400-449 filter_and_save, :635-653 test_step / on_test_epoch_end; Hydra target
+configs/model/large.yaml:1).  Training/validation steps are out of scope.
+
+What changes relative to the reference control flow (results are identical):
+  * the template bank stays resident, matcher-normalised once (MatchBank); kernels index it by
+    label -- no `ae_features[label-1]` gather (gigaPose.py:520), no per-batch re-normalisation;
+  * the IST backbone runs once per crop, not k times (gigaPose.py:553);
+  * IST regression, RANSAC and pose recovery run for all k hypotheses in one launch each;
+  * the only host syncs per image are the label upload and the final result download.
+"""
+import os
+import os.path as osp
+import time
+
+import numpy as np
+import pandas as pd
+import torch
+from torch import nn
+
+from .matching import MatchBank
+from .poses import ObjectPoseRecovery
+from .tensor_collection import PandasTensorCollection
+
+try:  # drop into pytorch_lightning.Trainer.test() when Lightning is installed
+    import pytorch_lightning as pl
+
+    _Base = pl.LightningModule
+except Exception:  # pragma: no cover - Lightning is absent in this image
+    class _Base(nn.Module):
+        global_rank = 0
+        logger = None
+
+        @property
+        def device(self):
+            try:
+                return next(self.parameters()).device
+            except StopIteration:
+                return torch.device("cpu")
+
+
+def stable_argsort_desc(score):
+    """argsort(score, dim=1, descending=True) with ties -> lower hypothesis index first
+    (the reference's torch.argsort leaves tie order unspecified, gigaPose.py:591)."""
+    return torch.sort(score, dim=1, descending=True, stable=True).indices
+
+
+class GigaPose(_Base):
+    def __init__(self, model_name, ae_net, ist_net, training_loss, testing_metric, optim_config, log_interval,
+                 log_dir, max_num_dets_per_forward=None, test_setting="localization", **kwargs):
+        super().__init__()
+        self.model_name = model_name
+        self.ae_net = ae_net
+        self.ist_net = ist_net
+        self.training_loss = training_loss
+        self.testing_metric = testing_metric
+        self.max_num_dets_per_forward = max_num_dets_per_forward
+        self.test_setting = test_setting
+        self.log_interval = log_interval
+        self.log_dir = log_dir
+        os.makedirs(osp.join(self.log_dir, "predictions"), exist_ok=True)
+        self.optim_config = optim_config
+        self.template_datas = {}
+        self.match_banks = {}
+        self.pose_recovery = {}
+        self.run_id = None
+        self.template_datasets = None
+        self.test_dataset_name = None
+        self.last_predictions = None  # full (unfiltered) predictions of the last eval_retrieval call
+
+    # ------------------------------------------------------------------ onboarding
+    @torch.no_grad()
+    def set_template_data(self, dataset_name):
+        """Build the resident template bank (reference gigaPose.py:357-398)."""
+        t0 = time.time()
+        template_dataset = self.template_datasets[dataset_name]
+        dev = self.device
+        cols = {n: [] for n in ["mask", "K", "M", "poses", "ae_features", "ist_features"]}
+        for idx in range(len(template_dataset)):
+            item = template_dataset[idx]
+            templates = item.rgb.to(dev)
+            cols["ae_features"].append(self.ae_net(templates))
+            cols["ist_features"].append(self.ist_net.forward_by_chunk(templates))
+            for n in ["mask", "K", "M", "poses"]:
+                cols[n].append(getattr(item, n).to(dev))
+        data = {n: torch.stack(v, dim=0) for n, v in cols.items()}
+        self.template_datas[dataset_name] = PandasTensorCollection(infos=pd.DataFrame(), **data)
+        self.match_banks[dataset_name] = MatchBank(data["ae_features"], data["mask"])
+        self.pose_recovery[dataset_name] = ObjectPoseRecovery(template_K=data["K"], template_Ms=data["M"],
+                                                              template_poses=data["poses"])
+        torch.cuda.synchronize()
+        self.onboarding_time = (time.time() - t0) / max(1, len(template_dataset))
+
+    # ------------------------------------------------------------------ the hot loop
+    @torch.no_grad()
+    def predict(self, tar_img, tar_mask, tar_K, tar_M, labels, dataset_name, sort_pred_by_inliers=True):
+        """Device-only part of eval_retrieval (gigaPose.py:511-604): crops -> sorted pose hypotheses.
+        labels: (B) int tensor of 1-based object labels.  Returns a PandasTensorCollection with
+        id_src, score_src, score_pts, tar_pts, src_pts, relScale, relInplane, idx_failed, M,
+        ransac_*, scores (B,k), pred_poses (B,k,4,4)."""
+        bank = self.match_banks[dataset_name]
+        template_data = self.template_datas[dataset_name]
+        labels0 = (labels.to(tar_img.device) - 1).to(torch.int32).contiguous()
+        tar_ae = self.ae_net(tar_img)                                            # stage 1: ViT features
+        pred = self.testing_metric.test_bank(bank, tar_ae, tar_mask, labels0)    # stage 3: matching
+        tar_ist = self.ist_net.forward_by_chunk(tar_img)                         # stage 4a: IST backbone (once)
+        rel_scale, rel_inplane = self.ist_net.regress_bank(template_data.ist_features, labels0, pred.id_src,
+                                                           tar_ist, pred.src_pts, pred.tar_pts)
+        pred.register_tensor("relScale", rel_scale)
+        pred.register_tensor("relInplane", rel_inplane)
+        pred = self.pose_recovery[dataset_name].forward_ransac(predictions=pred)  # stage 5
+        num_patches = pred.src_pts.shape[2]
+        score = torch.sum(pred.ransac_scores, dim=2) / num_patches               # gigaPose.py:588
+        pred.register_tensor("scores", score)
+        if sort_pred_by_inliers:
+            order = stable_argsort_desc(score)
+            rows = torch.arange(score.shape[0], device=score.device)[:, None]
+            for name, v in list(pred.tensors.items()):
+                pred.register_tensor(name, v[rows, order])
+        poses = self.pose_recovery[dataset_name].forward_recovery(                # stage 6
+            tar_label=labels, tar_K=tar_K, tar_M=tar_M, pred_src_views=pred.id_src, pred_M=pred.M)
+        pred.register_tensor("pred_poses", poses)
+        return pred
+
+    def eval_retrieval(self, batch, idx_batch, dataset_name, sort_pred_by_inliers=True):
+        if dataset_name not in self.template_datas:
+            self.set_template_data(dataset_name)
+        t0 = time.time()
+        labels_np = np.asarray(batch.infos.label).astype(np.int32)
+        labels = torch.from_numpy(labels_np)
+        predictions = self.predict(batch.tar_img, batch.tar_mask, batch.tar_K, batch.tar_M, labels, dataset_name,
+                                   sort_pred_by_inliers)
+        predictions.infos = batch.infos
+        torch.cuda.synchronize()
+        total_time = time.time() - t0
+        self.last_predictions = predictions
+        save_path = osp.join(self.log_dir, "predictions", f"{idx_batch}.npz")
+        if getattr(batch, "test_list", None) is not None:
+            return self.filter_and_save(predictions, test_list=batch.test_list, time=total_time, save_path=save_path,
+                                        keep_only_testing_instances=(self.test_setting == "localization"))
+        return None, predictions
+
+    def filter_and_save(self, predictions, test_list, time, save_path, keep_only_testing_instances=True):
+        """Keep the top-`inst_count` detections per target object and write the per-image npz the
+        BOP writer consumes (reference gigaPose.py:400-449)."""
+        labels = np.asarray(predictions.infos.label).astype(np.int32)
+        assert len(np.unique(labels)) == len(np.unique(test_list.infos.obj_id))
+        top_scores = predictions.scores[:, 0].cpu().numpy()
+        selected, detection_times = list(range(len(labels))), [0.0] * len(labels)
+        if keep_only_testing_instances:
+            selected, detection_times = [], []
+            for row, obj_id in enumerate(test_list.infos.obj_id):
+                num_inst = int(test_list.infos.inst_count[row])
+                cand = np.flatnonzero(labels == obj_id)
+                best = cand[np.argsort(-top_scores[cand], kind="stable")[:num_inst]]
+                selected.extend(best.tolist())
+                detection_times.extend([test_list.infos.detection_time[row]] * num_inst)
+        predictions = predictions[selected]
+        det_t = torch.from_numpy(np.asarray(detection_times, dtype=np.float64)).to(predictions.scores.device)
+        predictions.register_tensor("detection_time", det_t)
+        predictions.register_tensor("time", torch.ones_like(det_t) * time)
+        np.savez(save_path,
+                 scene_id=np.asarray(predictions.infos.scene_id).astype(np.int32),
+                 im_id=np.asarray(predictions.infos.view_id).astype(np.int32),
+                 object_id=np.asarray(predictions.infos.label).astype(np.int32),
+                 time=predictions.time.cpu().numpy(), detection_time=predictions.detection_time.cpu().numpy(),
+                 poses=predictions.pred_poses.cpu().numpy(), scores=predictions.scores.cpu().numpy())
+        return selected, predictions
+
+    @torch.no_grad()
+    def test_step(self, batch, idx_batch):
+        self.eval_retrieval(batch, idx_batch=idx_batch, dataset_name=self.test_dataset_name)
+        return 0
+
+    def on_test_epoch_end(self):
+        """BOP csv aggregation lives in the reference's src/utils/inout.py (not
+        rebuilt): when the reference package is importable it is called exactly as the reference does
+        (gigaPose.py:644-653); otherwise the per-image npz files are left for it."""
+        if self.global_rank != 0:
+            return
+        try:
+            from src.utils.inout import save_predictions_from_batched_predictions
+        except Exception:
+            return
+        save_predictions_from_batched_predictions(osp.join(self.log_dir, "predictions"),
+                                                  dataset_name=self.test_dataset_name, model_name=self.model_name,
+                                                  run_id=self.run_id, is_refined=False)

@@ -1,0 +1,172 @@
+"""IST network behind the reference interface (src/models/network/ist_net.py:11-162,
+src/models/network/resnet.py:26-50, 318-381; Hydra targets in configs/model/ist_net/resnet.yaml).
+
+* `ResNet`  -- LoFTR-style stride-16 CNN on the 256x256-resized crop -> (b,256,16,16).  Round-1
+  status: parameters/state-dict names mirror the reference and the forward runs through
+  PyTorch-ROCm (MIOpen convolutions) -- SURVEY 2b allows "MIOpen via PyTorch-ROCm first"; a HIP
+  implicit-GEMM replacement is SURVEY 8(f) row 4.  It is evaluated ONCE per crop (the reference
+  recomputes it k=5 times with identical input, gigaPose.py:553).
+* `Regressor` / `ISTNet.inference*` -- gather + concat + two MLP heads run in libgigapose_hip.so
+  (gp_ist_regress) for every (detection, hypothesis, patch) row at once.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+
+P = 256
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, in_planes, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=1, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1:
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(planes))
+
+    def forward(self, x):
+        y = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+        return self.relu((x if self.downsample is None else self.downsample(x)) + y)
+
+
+class ResNet(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        if config["n_heads"] > 0:
+            raise NotImplementedError("attention branches are disabled in the released config (n_heads: 0)")
+        self.input_size = config["input_size"]
+        dims, c0 = list(config["block_dims"]), config["initial_dim"]
+        self.conv1 = nn.Conv2d(config["input_dim"], c0, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(c0)
+        self.relu = nn.ReLU(inplace=True)
+        chans = [c0] + dims
+        for i, stride in enumerate([1, 2, 2, 2]):
+            setattr(self, f"layer{i + 1}", nn.Sequential(BasicBlock(chans[i], chans[i + 1], stride),
+                                                         BasicBlock(chans[i + 1], chans[i + 1], 1)))
+        self.layer4_outconv = nn.Conv2d(dims[3], config["descriptor_size"], 1, bias=False)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        x = F.interpolate(x, (self.input_size, self.input_size), mode="bilinear", align_corners=True)
+        x = self.relu(self.bn1(self.conv1(x)))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.layer4_outconv(x)
+
+
+class Regressor(nn.Module):
+    def __init__(self, descriptor_size, hidden_dim, use_tanh_act, normalize_output):
+        super().__init__()
+        self.descriptor_size, self.hidden_dim = descriptor_size, hidden_dim
+        self.normalize_output, self.use_tanh_act = normalize_output, use_tanh_act
+
+        def mlp(nout, tail):
+            return nn.Sequential(nn.Linear(descriptor_size * 2, hidden_dim * 2), nn.ReLU(inplace=True),
+                                 nn.Linear(hidden_dim * 2, hidden_dim), nn.ReLU(inplace=True),
+                                 nn.Linear(hidden_dim, nout), *tail)
+
+        self.scale_predictor = mlp(1, [])
+        self.inplane_predictor = mlp(2, [nn.Tanh() if use_tanh_act else nn.Identity()])
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+
+class ISTNet(nn.Module):
+    def __init__(self, model_name, backbone, regressor, max_batch_size, patch_size=14, **kwargs):
+        super().__init__()
+        self.model_name, self.patch_size = model_name, patch_size
+        self.backbone, self.regressor = backbone, regressor
+        self.max_batch_size = max_batch_size
+        for m in self.modules():  # reference ist_net.py:33-42
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.kaiming_normal_(m.weight, mode="fan_in", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        self._packed = None
+        self._ws = None
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    @torch.no_grad()
+    def forward_by_chunk(self, processed_rgbs):
+        outs = [self.backbone(processed_rgbs[s:s + self.max_batch_size])
+                for s in range(0, processed_rgbs.shape[0], self.max_batch_size)]
+        if not outs:
+            return torch.empty(0, self.regressor.descriptor_size, 16, 16, device=processed_rgbs.device)
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+    # ------------------------------------------------------------------ HIP regressor
+    @torch.no_grad()
+    def _pack(self, device):
+        def dev(t):
+            return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+        tensors = []
+        for seq in (self.regressor.scale_predictor, self.regressor.inplane_predictor):
+            l1, l2, l3 = seq[0], seq[2], seq[4]
+            tensors += [dev(l1.weight.t()), dev(l1.bias), dev(l2.weight.t()), dev(l2.bias), dev(l3.weight), dev(l3.bias)]
+        table = (ctypes.c_void_p * 12)(*[t.data_ptr() for t in tensors])
+        self._packed = (device, tensors, table)
+
+    @torch.no_grad()
+    def regress_bank(self, ist_bank, labels0, id_src, tar_feat, src_pts, tar_pts):
+        """All hypotheses at once against a resident IST bank.
+        ist_bank (O,N,D,16,16); labels0 (B) int32 0-based; id_src (B,k) int64; tar_feat (B,D,16,16);
+        src_pts / tar_pts (B,k,256,2) int64 -> relScale (B,k,256), relInplane (B,k,256,2)."""
+        dev = tar_feat.device
+        if self._packed is None or self._packed[0] != dev:
+            self._pack(dev)
+        B, k = id_src.shape
+        O, N, D = ist_bank.shape[:3]
+        H = self.regressor.hidden_dim
+        scales = torch.empty(B, k, P, dtype=torch.float32, device=dev)
+        cos_sin = torch.empty(B, k, P, 2, dtype=torch.float32, device=dev)
+        if B == 0:
+            return scales, cos_sin
+        lib = _lib.lib()
+        lib.gp_ist_workspace_bytes.restype = ctypes.c_size_t
+        need = lib.gp_ist_workspace_bytes(_lib.i(B), _lib.i(k), _lib.i(D), _lib.i(H))
+        if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != dev:
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+        _, tensors, table = self._packed
+        _lib.call("gp_ist_regress", _lib.ptr(tar_feat.contiguous().float()), _lib.ptr(ist_bank.contiguous()),
+                  _lib.ptr(labels0.to(torch.int32).contiguous()), _lib.ptr(id_src.contiguous()),
+                  _lib.ptr(tar_pts.contiguous()), _lib.ptr(src_pts.contiguous()), _lib.i(B), _lib.i(O), _lib.i(N),
+                  _lib.i(k), _lib.i(D), _lib.i(H), table, _lib.i(12), _lib.i(1 if self.regressor.use_tanh_act else 0),
+                  _lib.ptr(self._ws), ctypes.c_size_t(need), _lib.ptr(scales), _lib.ptr(cos_sin), _lib.stream_ptr())
+        return scales, cos_sin
+
+    @torch.no_grad()
+    def inference(self, src_feat, tar_feat, src_pts, tar_pts):
+        """Reference signature (ist_net.py:97): src_feat/tar_feat (B,D,16,16), pts (B,P,2) ->
+        (B,P) scales and (B,P,2) cos/sin, -1000 where the correspondence is invalid.  As in the
+        reference, cos/sin are NOT re-normalised here although normalize_output is set."""
+        B = src_feat.shape[0]
+        dev = src_feat.device
+        sv = (src_pts[..., 0] != -1) & (src_pts[..., 1] != -1)
+        tv = (tar_pts[..., 0] != -1) & (tar_pts[..., 1] != -1)
+        assert int(sv.sum()) == int(tv.sum())  # reference ist_net.py:116
+        labels0 = torch.arange(B, dtype=torch.int32, device=dev)
+        id_src = torch.zeros(B, 1, dtype=torch.int64, device=dev)
+        s, c = self.regress_bank(src_feat.unsqueeze(1), labels0, id_src, tar_feat, src_pts.unsqueeze(1),
+                                 tar_pts.unsqueeze(1))
+        return s[:, 0], c[:, 0]
+
+    def inference_by_chunk(self, src_feat, tar_feat, src_pts, tar_pts, max_batch_size):
+        outs = [self.inference(src_feat[s:s + max_batch_size], tar_feat[s:s + max_batch_size],
+                               src_pts[s:s + max_batch_size], tar_pts[s:s + max_batch_size])
+                for s in range(0, src_feat.shape[0], max_batch_size)]
+        return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])

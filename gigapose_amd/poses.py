@@ -1,0 +1,89 @@
+"""2-D similarity voting + 6-D pose recovery behind the reference interfaces
+`RANSAC` (src/models/ransac.py:9-172) and `ObjectPoseRecovery` (src/models/poses.py:12-163).
+One workgroup per (detection, hypothesis) in libgigapose_hip.so (gp_ransac, gp_recover_poses)
+replaces the reference's Python loops over detections x hypotheses."""
+import pandas as pd
+import torch
+
+from . import _lib
+from .tensor_collection import PandasTensorCollection
+
+P = 256
+
+
+class RANSAC(torch.nn.Module):
+    def __init__(self, pixel_threshold, patch_size=14):
+        super().__init__()
+        self.patch_size = patch_size
+        self.pixel_threshold = pixel_threshold
+
+    @torch.no_grad()
+    def run(self, src_pts, tar_pts, rel_scale, rel_inplane):
+        """src_pts/tar_pts (...,256,2) int64, rel_scale (...,256), rel_inplane (...,256,2) ->
+        M (...,3,3), failed (...) bool, inlier src/tar pts (...,256,2) int64, inlier scores (...,256) int64."""
+        lead = tuple(src_pts.shape[:-2])
+        R = 1
+        for d in lead:
+            R *= d
+        dev = src_pts.device
+        M = torch.empty(*lead, 3, 3, dtype=torch.float32, device=dev)
+        failed = torch.empty(*lead, dtype=torch.uint8, device=dev)
+        isrc = torch.empty(*lead, P, 2, dtype=torch.int64, device=dev)
+        itar = torch.empty(*lead, P, 2, dtype=torch.int64, device=dev)
+        isc = torch.empty(*lead, P, dtype=torch.int64, device=dev)
+        _lib.call("gp_ransac", _lib.ptr(src_pts.contiguous()), _lib.ptr(tar_pts.contiguous()),
+                  _lib.ptr(rel_scale.contiguous().float()), _lib.ptr(rel_inplane.contiguous().float()), _lib.i(R),
+                  _lib.f(self.patch_size), _lib.f(self.pixel_threshold), _lib.ptr(M), _lib.ptr(failed),
+                  _lib.ptr(isrc), _lib.ptr(itar), _lib.ptr(isc), _lib.stream_ptr())
+        return M, failed.bool(), isrc, itar, isc
+
+    def forward(self, batch, scores=None, direction="src2tar"):
+        """Reference signature (ransac.py:108): batch has src_pts/tar_pts (B,P,2), relScale, relInplane."""
+        if direction != "src2tar" or scores is not None:
+            raise NotImplementedError("only the src2tar / unit-score path used at inference is built")
+        M, failed, isrc, itar, isc = self.run(batch.src_pts, batch.tar_pts, batch.relScale, batch.relInplane)
+        out = PandasTensorCollection(src_pts=isrc, tar_pts=itar, scores=isc, infos=batch.infos)
+        return M, failed, out
+
+
+class ObjectPoseRecovery(torch.nn.Module):
+    def __init__(self, template_K, template_Ms, template_poses, pixel_threshold=14):
+        super().__init__()
+        self.template_K = template_K.contiguous().float()          # (O,3,3)
+        self.template_Ms = template_Ms.contiguous().float()        # (O,N,3,3)
+        self.template_poses = template_poses.contiguous().float()  # (O,N,4,4)
+        self.ransac = RANSAC(pixel_threshold=pixel_threshold)
+        self.check_asserts = True
+
+    @torch.no_grad()
+    def forward_recovery(self, tar_label, tar_K, tar_M, pred_src_views, pred_M):
+        """tar_label (B) 1-based object labels (reference indexes template tensors with label-1,
+        poses.py:111-113); returns pred_poses (B,k,4,4)."""
+        B, k = pred_src_views.shape
+        O, N = self.template_Ms.shape[:2]
+        dev = pred_M.device
+        labels0 = (tar_label.to(dev) - 1).to(torch.int32).contiguous()
+        poses = torch.empty(B, k, 4, 4, dtype=torch.float32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.call("gp_recover_poses", _lib.ptr(labels0), _lib.ptr(tar_K.contiguous().float()),
+                  _lib.ptr(tar_M.contiguous().float()), _lib.ptr(pred_src_views.contiguous().long()),
+                  _lib.ptr(pred_M.contiguous().float()), _lib.ptr(self.template_K), _lib.ptr(self.template_Ms),
+                  _lib.ptr(self.template_poses), _lib.i(B), _lib.i(O), _lib.i(N), _lib.i(k), _lib.ptr(poses),
+                  _lib.ptr(flag), _lib.stream_ptr())
+        if self.check_asserts and B > 0:
+            # reference lib3d/torch.py:54-55 asserts the crop transform is isotropic scale + translation
+            assert int(flag.item()) == 0, "tar_M must be an isotropic scale + translation"
+        return poses
+
+    @torch.no_grad()
+    def forward_ransac(self, predictions):
+        """predictions: src_pts/tar_pts (B,k,P,2), relScale (B,k,P), relInplane (B,k,P,2); registers
+        idx_failed, M, ransac_scores, ransac_src_pts, ransac_tar_pts (poses.py:124-163)."""
+        M, failed, isrc, itar, isc = self.ransac.run(predictions.src_pts, predictions.tar_pts,
+                                                     predictions.relScale, predictions.relInplane)
+        predictions.register_tensor("idx_failed", failed)
+        predictions.register_tensor("M", M)
+        predictions.register_tensor("ransac_scores", isc)
+        predictions.register_tensor("ransac_src_pts", isrc)
+        predictions.register_tensor("ransac_tar_pts", itar)
+        return predictions

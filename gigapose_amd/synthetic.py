@@ -172,3 +172,67 @@ def template_geometry(seed, O, N):
             poses[o, n, :3, 3] = [rs.uniform(-20, 20), rs.uniform(-20, 20), rs.uniform(350, 450)]
             poses[o, n, 3, 3] = 1
     return K, M, poses
+
+
+def fill_state_dict(module, seed):
+    """Deterministic (numpy-stream) weights for any torch module, keyed by parameter NAME order, so
+    the reference modules (golden generation) and gigapose_amd's mirrors (tests, bench) get identical
+    weights wherever their state-dict names/shapes agree -- which also checks checkpoint-key parity.
+    Scales: weights ~ N(0, 2/fan_in) (0.02 for tokens/pos-embed), norm scales / LayerScale in
+    [0.8,1.2], running_var in [0.5,1.5], biases / running_mean ~ N(0, 0.05)."""
+    import torch
+
+    rs = np.random.RandomState(seed)
+    sd = module.state_dict()
+    new = {}
+    for name in sorted(sd):
+        t = sd[name]
+        shape = tuple(t.shape)
+        if name.endswith("num_batches_tracked"):
+            new[name] = t.clone()
+            continue
+        if name.endswith("running_var"):
+            v = rs.uniform(0.5, 1.5, shape)
+        elif t.dim() >= 2 and not any(k in name for k in ("cls_token", "pos_embed", "position_embeddings", "mask_token")):
+            fan_in = int(np.prod(shape[1:]))
+            v = rs.standard_normal(shape) * np.sqrt(2.0 / fan_in)
+        elif t.dim() >= 2:
+            v = rs.standard_normal(shape) * 0.02
+        elif name.endswith("weight") or name.endswith("gamma") or name.endswith("lambda1"):
+            v = rs.uniform(0.8, 1.2, shape)
+        else:
+            v = rs.standard_normal(shape) * 0.05
+        new[name] = torch.from_numpy(np.asarray(v, dtype=np.float32)).reshape(shape)
+    module.load_state_dict(new)
+    return module
+
+
+def correspondences_case(seed, B, k):
+    """Synthetic post-matcher state for the IST / RANSAC / recovery stages: (x,y) correspondences
+    with -1 padding that mostly follow one similarity per (b,k) plus outliers; IST features random.
+    Includes the edge cases N=0 (b=0,k=0) and N=1 (b=0,k=1)."""
+    rs = np.random.RandomState(seed)
+    src_pts = -np.ones((B, k, P, 2), np.int64)
+    tar_pts = -np.ones((B, k, P, 2), np.int64)
+    rel_scale = np.full((B, k, P), -1000, np.float32)
+    rel_inplane = np.full((B, k, P, 2), -1000, np.float32)
+    for b in range(B):
+        for j in range(k):
+            n = 0 if (b, j) == (0, 0) else 1 if (b, j) == (0, 1) else int(rs.randint(2, 120))
+            pos = np.sort(rs.choice(P, n, replace=False))
+            s = rs.uniform(0.6, 1.6)
+            a = rs.uniform(-0.6, 0.6)
+            for p in pos:
+                tx, ty = p % G, p // G
+                # template location = inverse similarity of the query location about the centre
+                cx, cy = tx - 7.5, ty - 7.5
+                sxf = (np.cos(a) * cx + np.sin(a) * cy) / s + 7.5
+                syf = (-np.sin(a) * cx + np.cos(a) * cy) / s + 7.5
+                if rs.rand() < 0.25:
+                    sxf, syf = rs.uniform(0, 15, 2)
+                tar_pts[b, j, p] = (tx, ty)
+                src_pts[b, j, p] = (int(np.clip(round(sxf), 0, 15)), int(np.clip(round(syf), 0, 15)))
+                rel_scale[b, j, p] = s * rs.uniform(0.9, 1.1)
+                ang = a + rs.normal(0, 0.08)
+                rel_inplane[b, j, p] = (np.cos(ang), np.sin(ang))
+    return dict(src_pts=src_pts, tar_pts=tar_pts, rel_scale=rel_scale, rel_inplane=rel_inplane)

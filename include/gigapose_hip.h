@@ -93,6 +93,45 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
                    const float* const* weights, int n_weights, float* workspace, size_t workspace_bytes,
                    float* out_features, int normalize, int stop_after_layers, void* stream);
 
+/* ---- IST regressor: ISTNet.inference (src/models/network/ist_net.py:97-120) ----------------- */
+
+size_t gp_ist_workspace_bytes(int B, int k, int D, int H);
+
+/* For every (detection b, hypothesis j, patch t) row: gather tar_feat[b][:, tar_pt] and
+ * src_bank[labels[b]][id_src[b][j]][:, src_pt] (src/utils/batch.py:46-73, index = y*16+x), concat
+ * [tar, src] (2D), run scale MLP 2D->2H->H->1 and in-plane MLP 2D->2H->H->2 (+tanh)
+ * (ist_net.py:140-155).  Rows whose points are -1 get -1000 (ist_net.py:109-119).
+ *   tar_feat (B,D,256)  src_bank (O,N,D,256)  labels (B) int32  id_src (B,k) int64
+ *   tar_pts, src_pts (B,k,256,2) int64   ->  scales (B,k,256)  cos_sin (B,k,256,2)
+ * weights: HOST array of 12 DEVICE pointers: for scale then in-plane head:
+ *   W1^T (2D,2H), b1 (2H), W2^T (2H,H), b2 (H), W3 (nout,H), b3 (nout).
+ * Requires 2D % 16 == 0, H % 128 == 0. */
+int gp_ist_regress(const float* tar_feat, const float* src_bank, const int* labels, const long long* id_src,
+                   const long long* tar_pts, const long long* src_pts, int B, int O, int N, int k, int D,
+                   int H, const float* const* weights, int n_weights, int use_tanh, float* workspace,
+                   size_t workspace_bytes, float* scales, float* cos_sin, void* stream);
+
+/* ---- 2-D similarity voting: RANSAC.forward (src/models/ransac.py:108-172) -------------------- */
+
+/* R independent problems of 256 padded correspondences (valid where src_pts.x != -1).  Each valid
+ * correspondence proposes M = [s*R | t]; inliers = other correspondences within pixel_threshold;
+ * first maximum wins.  Outputs: M (R,3,3); failed (R) u8 = (best count == 0); the winner's inliers
+ * packed at the front of inl_src/inl_tar (R,256,2) int64 (pad -1) and inl_score (R,256) int64 (pad 0).
+ * No valid correspondence: M = I, failed = 0. */
+int gp_ransac(const long long* src_pts, const long long* tar_pts, const float* rel_scale,
+              const float* rel_inplane, int R, float patch_size, float pixel_threshold, float* M,
+              unsigned char* failed, long long* inl_src, long long* inl_tar, long long* inl_score, void* stream);
+
+/* ---- pose recovery: ObjectPoseRecovery.forward_recovery (src/models/poses.py:26-122) --------- */
+
+/* labels (B) int32 0-based, tar_K, tar_M (B,3,3), id_src (B,k) int64, pred_M (B,k,3,3),
+ * tmpl_K (O,3,3), tmpl_M (O,N,3,3), tmpl_pose (O,N,4,4) -> poses (B,k,4,4).
+ * *bad_crop_M (device int, caller zeroes it) is OR-ed with 1 when a tar_M violates the reference's
+ * assert (src/lib3d/torch.py:54-55: isotropic scale + translation). */
+int gp_recover_poses(const int* labels, const float* tar_K, const float* tar_M, const long long* id_src,
+                     const float* pred_M, const float* tmpl_K, const float* tmpl_M, const float* tmpl_pose, int B,
+                     int O, int N, int k, float* poses, int* bad_crop_M, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

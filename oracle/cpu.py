@@ -140,3 +140,75 @@ def gemm_kmajor(A, B, epi=0, bias=None, scale=None, res=None):
                              _p(bias) if bias is not None else None, _p(scale) if scale is not None else None,
                              _p(res) if res is not None else None, ctypes.c_int(J))
     return D
+
+
+def gather_rows(feat, pts):
+    """batch.py:46-73 `gather` WITHOUT the compaction: feat (B,D,256), pts (B,...,256,2) ->
+    rows (B,...,256, D) and valid (B,...,256).  Invalid rows take index 0."""
+    feat = _f32(feat)
+    pts = np.asarray(pts)
+    x, y = pts[..., 0], pts[..., 1]
+    valid = (x != -1) & (y != -1)
+    idx = np.where(valid, y * 16 + x, 0)
+    return idx, valid
+
+
+def ist_inference(tar_feat, src_feat_sel, tar_pts, src_pts, weights, use_tanh=True):
+    """ISTNet.inference (ist_net.py:97-120) for all hypotheses at once.
+
+    tar_feat (B,D,256); src_feat_sel (B,k,D,256) = ist bank rows of the selected templates;
+    tar_pts/src_pts (B,k,256,2); weights: dict scale/inplane -> [W1,b1,W2,b2,W3,b3] torch layout.
+    Returns scales (B,k,256), cos_sin (B,k,256,2)."""
+    B, k = src_pts.shape[:2]
+    D = tar_feat.shape[1]
+    ti, tv = gather_rows(tar_feat, tar_pts)
+    si, sv = gather_rows(tar_feat, src_pts)
+    tar_feat, src_feat_sel = _f32(tar_feat), _f32(src_feat_sel)
+    R = B * k * P
+    feats = np.empty((B, k, P, 2 * D), np.float32)
+    for b in range(B):
+        for j in range(k):
+            feats[b, j, :, :D] = tar_feat[b][:, ti[b, j]].T
+            feats[b, j, :, D:] = src_feat_sel[b, j][:, si[b, j]].T
+    valid = np.ascontiguousarray((tv & sv).reshape(R).astype(np.uint8))
+    feats = feats.reshape(R, 2 * D)
+    outs = []
+    for name, nout, th in (("scale", 1, 0), ("inplane", 2, 1 if use_tanh else 0)):
+        W1, b1, W2, b2, W3, b3 = [_f32(w) for w in weights[name]]
+        out = np.empty((R, nout), np.float32)
+        lib().oracle_ist_head(_p(feats), _p(valid), ctypes.c_int(R), ctypes.c_int(2 * D),
+                              ctypes.c_int(W1.shape[0]), ctypes.c_int(W2.shape[0]), ctypes.c_int(nout),
+                              _p(W1), _p(b1), _p(W2), _p(b2), _p(W3), _p(b3), ctypes.c_int(th), _p(out))
+        outs.append(out)
+    return outs[0].reshape(B, k, P), outs[1].reshape(B, k, P, 2)
+
+
+def ransac(src_pts, tar_pts, rel_scale, rel_inplane, patch_size=14.0, thr=14.0):
+    """RANSAC.forward (ransac.py:108-172) over leading dims (...,256,2)."""
+    src_pts = np.ascontiguousarray(src_pts, np.int64)
+    tar_pts = np.ascontiguousarray(tar_pts, np.int64)
+    lead = src_pts.shape[:-2]
+    R = int(np.prod(lead))
+    rs, ri = _f32(rel_scale), _f32(rel_inplane)
+    M = np.empty((R, 3, 3), np.float32)
+    failed = np.empty(R, np.uint8)
+    isrc = np.empty((R, P, 2), np.int64)
+    itar = np.empty((R, P, 2), np.int64)
+    isc = np.empty((R, P), np.int64)
+    lib().oracle_ransac(_p(src_pts), _p(tar_pts), _p(rs), _p(ri), ctypes.c_int(R), ctypes.c_float(patch_size),
+                        ctypes.c_float(thr), _p(M), _p(failed), _p(isrc), _p(itar), _p(isc))
+    return (M.reshape(*lead, 3, 3), failed.reshape(lead).astype(bool), isrc.reshape(*lead, P, 2),
+            itar.reshape(*lead, P, 2), isc.reshape(*lead, P))
+
+
+def recover(labels, tar_K, tar_M, id_src, pred_M, tmpl_K, tmpl_M, tmpl_pose):
+    """ObjectPoseRecovery.forward_recovery (poses.py:103-122); labels 0-based."""
+    labels = np.ascontiguousarray(labels, np.int32)
+    id_src = np.ascontiguousarray(id_src, np.int64)
+    B, k = id_src.shape
+    N = tmpl_M.shape[1]
+    out = np.empty((B, k, 4, 4), np.float32)
+    lib().oracle_recover(_p(labels), _p(_f32(tar_K)), _p(_f32(tar_M)), _p(id_src), _p(_f32(pred_M)),
+                         _p(_f32(tmpl_K)), _p(_f32(tmpl_M)), _p(_f32(tmpl_pose)), ctypes.c_int(B),
+                         ctypes.c_int(N), ctypes.c_int(k), _p(out))
+    return out

@@ -212,3 +212,176 @@ void oracle_gemm_kmajor(const float* A, int lda, const float* B, int ldb, float*
         free(acc);
     }
 }
+
+/* ------------------------------------------------------------------------------------
+ * ISTNet.inference (reference ist_net.py:97-120) for ONE head on gathered features.
+ * feats (R, 2D) row-major = cat([tar_feat_, src_feat_], dim=1) of batch.py:46-73 for EVERY row
+ * (invalid rows carry anything); valid (R) flags.  MLP 2D -> 2H -> H -> nout, ReLU between,
+ * optional tanh (ist_net.py:140-155).  Accumulation fixed as in gp_gemm.hip / gp_ist.hip:
+ * sequential fmaf over the input units, then + bias.  Invalid rows -> -1000 (ist_net.py:109-119).
+ * weights are torch-layout: W1 (2H,2D), b1, W2 (H,2H), b2, W3 (nout,H), b3.
+ * ---------------------------------------------------------------------------------- */
+void oracle_ist_head(const float* feats, const uint8_t* valid, int R, int D2, int H2, int H, int nout,
+                     const float* W1, const float* b1, const float* W2, const float* b2,
+                     const float* W3, const float* b3, int use_tanh, float* out)
+{
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < R; ++r) {
+        float* o = out + (size_t)r * nout;
+        if (!valid[r]) { for (int j = 0; j < nout; ++j) o[j] = -1000.0f; continue; }
+        const float* x = feats + (size_t)r * D2;
+        float* h1 = (float*)malloc(sizeof(float) * (H2 + H));
+        float* h2 = h1 + H2;
+        for (int i = 0; i < H2; ++i) {
+            float a = 0.f;
+            for (int c = 0; c < D2; ++c) a = fmaf(W1[(size_t)i * D2 + c], x[c], a);
+            h1[i] = fmaxf(a + b1[i], 0.f);
+        }
+        for (int i = 0; i < H; ++i) {
+            float a = 0.f;
+            for (int c = 0; c < H2; ++c) a = fmaf(W2[(size_t)i * H2 + c], h1[c], a);
+            h2[i] = fmaxf(a + b2[i], 0.f);
+        }
+        for (int j = 0; j < nout; ++j) {
+            float a = 0.f;
+            for (int c = 0; c < H; ++c) a = fmaf(W3[(size_t)j * H + c], h2[c], a);
+            a = a + b3[j];
+            o[j] = use_tanh ? tanhf(a) : a;
+        }
+        free(h1);
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * RANSAC.forward / forward_ / _sample (reference ransac.py:108-172, 37-106, 19-35) for R
+ * independent problems of P=256 padded correspondences; arithmetic order as gp_pose.hip.
+ * ---------------------------------------------------------------------------------- */
+typedef struct { float m00, m01, m10, m11, t0, t1; } cand_t;
+
+static cand_t make_cand(const float* sx, const float* sy, const float* tx, const float* ty,
+                        const float* sc, const float* cs, const float* sn, int i)
+{
+    cand_t c;
+    c.m00 = cs[i] * sc[i];
+    c.m01 = (-sn[i]) * sc[i];
+    c.m10 = sn[i] * sc[i];
+    c.m11 = cs[i] * sc[i];
+    float a0 = c.m00 * sx[i] + c.m01 * sy[i];
+    float a1 = c.m10 * sx[i] + c.m11 * sy[i];
+    c.t0 = tx[i] - a0;
+    c.t1 = ty[i] - a1;
+    return c;
+}
+static int cand_inlier(const cand_t* c, float sx, float sy, float tx, float ty, float thr)
+{
+    float v0 = (c->m00 * sx + c->m01 * sy) + c->t0;
+    float v1 = (c->m10 * sx + c->m11 * sy) + c->t1;
+    float d0 = tx - v0, d1 = ty - v1;
+    return sqrtf(d0 * d0 + d1 * d1) <= thr;
+}
+
+void oracle_ransac(const int64_t* src_pts, const int64_t* tar_pts, const float* rel_scale,
+                   const float* rel_inplane, int R, float patch_size, float thr,
+                   float* M, uint8_t* failed, int64_t* inl_src, int64_t* inl_tar, int64_t* inl_score)
+{
+#pragma omp parallel for schedule(dynamic)
+    for (int r = 0; r < R; ++r) {
+        float sx[P], sy[P], tx[P], ty[P], sc[P], cs[P], sn[P]; int orig[P];
+        int n = 0;
+        for (int p = 0; p < P; ++p) {
+            size_t rp = (size_t)r * P + p;
+            inl_src[2 * rp] = inl_src[2 * rp + 1] = -1;
+            inl_tar[2 * rp] = inl_tar[2 * rp + 1] = -1;
+            inl_score[rp] = 0;
+            if (src_pts[2 * rp] == -1) continue;                     /* ransac.py:141 */
+            sx[n] = (float)src_pts[2 * rp] * patch_size;             /* :57-58 */
+            sy[n] = (float)src_pts[2 * rp + 1] * patch_size;
+            tx[n] = (float)tar_pts[2 * rp] * patch_size;
+            ty[n] = (float)tar_pts[2 * rp + 1] * patch_size;
+            sc[n] = rel_scale[rp]; cs[n] = rel_inplane[2 * rp]; sn[n] = rel_inplane[2 * rp + 1];
+            orig[n] = p; ++n;
+        }
+        float* Mr = M + (size_t)r * 9;
+        if (n == 0) {                                               /* :128-129, :142 */
+            for (int i = 0; i < 9; ++i) Mr[i] = (i % 4 == 0) ? 1.f : 0.f;
+            failed[r] = 0; continue;
+        }
+        int best = 0, bc = -1;
+        for (int i = 0; i < n; ++i) {
+            cand_t c = make_cand(sx, sy, tx, ty, sc, cs, sn, i);
+            int cnt = 0;
+            for (int j = 0; j < n; ++j) if (j != i && cand_inlier(&c, sx[j], sy[j], tx[j], ty[j], thr)) ++cnt;
+            if (cnt > bc) { bc = cnt; best = i; }                   /* first max (:99) */
+        }
+        cand_t c = make_cand(sx, sy, tx, ty, sc, cs, sn, best);
+        Mr[0] = c.m00; Mr[1] = c.m01; Mr[2] = c.t0; Mr[3] = c.m10; Mr[4] = c.m11; Mr[5] = c.t1;
+        Mr[6] = 0.f; Mr[7] = 0.f; Mr[8] = 1.f;
+        failed[r] = (bc == 0);                                      /* :100 */
+        int q = 0;
+        for (int j = 0; j < n; ++j) {
+            if (j == best || !cand_inlier(&c, sx[j], sy[j], tx[j], ty[j], thr)) continue;
+            size_t o = (size_t)r * P + q, s = (size_t)r * P + orig[j];
+            inl_src[2 * o] = src_pts[2 * s]; inl_src[2 * o + 1] = src_pts[2 * s + 1];
+            inl_tar[2 * o] = tar_pts[2 * s]; inl_tar[2 * o + 1] = tar_pts[2 * s + 1];
+            inl_score[o] = 1; ++q;                                   /* :160-163 */
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * ObjectPoseRecovery.forward_recovery / _forward_recovery (reference poses.py:26-122) with
+ * lib3d/torch.py:47-65 (inverse_affine) and :150-162 (normalize_affine_transform).
+ * ---------------------------------------------------------------------------------- */
+static void m3mul(const float* a, const float* b, float* c)
+{
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+        c[i * 3 + j] = (a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j]) + a[i * 3 + 2] * b[6 + j];
+}
+static void m3vec(const float* a, const float* v, float* o)
+{
+    for (int i = 0; i < 3; ++i) o[i] = (a[i * 3] * v[0] + a[i * 3 + 1] * v[1]) + a[i * 3 + 2] * v[2];
+}
+static void m3inv(const float* m, float* o)
+{
+    float c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    float det = (m[0] * c00 + m[1] * c01) + m[2] * c02;
+    float id = 1.0f / det;
+    o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+void oracle_recover(const int32_t* labels, const float* tar_K, const float* tar_M, const int64_t* id_src,
+                    const float* pred_M, const float* tmpl_K, const float* tmpl_M, const float* tmpl_pose,
+                    int B, int N, int k, float* out)
+{
+    for (int bk = 0; bk < B * k; ++bk) {
+        int b = bk / k;
+        size_t on = (size_t)labels[b] * N + (size_t)id_src[bk];
+        const float *qM = tar_M + (size_t)b * 9, *qK = tar_K + (size_t)b * 9, *M = pred_M + (size_t)bk * 9;
+        const float *tK = tmpl_K + (size_t)labels[b] * 9, *tM = tmpl_M + on * 9, *tP = tmpl_pose + on * 16;
+        float sc = sqrtf(M[0] * M[0] + M[3] * M[3]);
+        float Rin[9] = {M[0] / sc, M[1] / sc, 0.f, M[3] / sc, M[4] / sc, 0.f, 0.f, 0.f, 1.f};
+        float Rt[9] = {tP[0], tP[1], tP[2], tP[4], tP[5], tP[6], tP[8], tP[9], tP[10]};
+        float Rm[9]; m3mul(Rin, Rt, Rm);
+        float temp_z = tP[11];
+        float tt[3] = {tP[3], tP[7], tP[11]};
+        float c2d[3]; m3vec(tK, tt, c2d);
+        float cz = c2d[2]; c2d[0] = c2d[0] / cz; c2d[1] = c2d[1] / cz; c2d[2] = c2d[2] / cz;
+        float qs = qM[0];
+        float inv_qM[9] = {1.0f / qs, 0.f, -qM[2] / qs, 0.f, 1.0f / qs, -qM[5] / qs, 0.f, 0.f, 1.f};
+        float tmp[9], aff[9]; m3mul(inv_qM, M, tmp); m3mul(tmp, tM, aff);
+        float qc[3]; m3vec(aff, c2d, qc);
+        float iK[9]; m3inv(qK, iK);
+        float scale2d = sqrtf(aff[0] * aff[0] + aff[3] * aff[3]);
+        float focal_ratio = qK[0] / tK[0];
+        float qz = (temp_z / scale2d) * focal_ratio;
+        float qt[3]; m3vec(iK, qc, qt);
+        float w = qt[2]; qt[0] = qt[0] / w; qt[1] = qt[1] / w; qt[2] = qt[2] / w;
+        float* o = out + (size_t)bk * 16;
+        o[0] = Rm[0]; o[1] = Rm[1]; o[2] = Rm[2]; o[3] = qt[0] * qz;
+        o[4] = Rm[3]; o[5] = Rm[4]; o[6] = Rm[5]; o[7] = qt[1] * qz;
+        o[8] = Rm[6]; o[9] = Rm[7]; o[10] = Rm[8]; o[11] = qt[2] * qz;
+        o[12] = tP[12]; o[13] = tP[13]; o[14] = tP[14]; o[15] = tP[15];
+    }
+}

@@ -49,7 +49,169 @@ def gen_matcher():
               "valid pts:", int((out.tar_pts[..., 0] >= 0).sum()))
 
 
-STAGES = {"matcher": gen_matcher}
+IST_CFG = dict(n_heads=0, input_dim=3, input_size=256, initial_dim=128, block_dims=[128, 192, 256, 512],
+               descriptor_size=256)
+
+
+def build_ref_ist(seed):
+    ref_shim.install()
+    from src.models.network.ist_net import ISTNet, Regressor
+    from src.models.network.resnet import ResNet
+
+    net = ISTNet("resnet", ResNet(dict(IST_CFG)), Regressor(256, 256, True, True), 64).eval()
+    return syn.fill_state_dict(net, seed)
+
+
+def gen_ist():
+    """ISTNet.forward_by_chunk (ResNet, resnet.py:364-381) and ISTNet.inference (ist_net.py:97-120)."""
+    torch.set_num_threads(8)
+    net = build_ref_ist(seed=101)
+    tmpl, masks = syn.template_images(102, 2)
+    with torch.no_grad():
+        feat = net.forward_by_chunk(torch.from_numpy(tmpl))           # (2,256,16,16)
+    rs = np.random.RandomState(103)
+    B = 3
+    src_feat = rs.standard_normal((B, 256, 16, 16)).astype(np.float32)
+    tar_feat = rs.standard_normal((B, 256, 16, 16)).astype(np.float32)
+    corr = syn.correspondences_case(104, B, 1)
+    with torch.no_grad():
+        sc, cs = net.inference(torch.from_numpy(src_feat), torch.from_numpy(tar_feat),
+                               torch.from_numpy(corr["src_pts"][:, 0]), torch.from_numpy(corr["tar_pts"][:, 0]))
+    np.savez_compressed(os.path.join(GOLD, "ist.npz"), resnet_feat=feat.numpy(), scales=sc.numpy(),
+                        cos_sin=cs.numpy(), n_state=len(net.state_dict()),
+                        state_names="|".join(sorted(net.state_dict())))
+    print("ist: resnet feat", tuple(feat.shape), float(feat.abs().mean()), "valid rows", int((sc > -999).sum()))
+
+
+def gen_pose():
+    """RANSAC.forward per hypothesis (ransac.py:108-172) via ObjectPoseRecovery.forward_ransac
+    (poses.py:124-163) and forward_recovery (poses.py:103-122)."""
+    ref_shim.install()
+    import pandas as pd
+    from src.megapose.utils.tensor_collection import PandasTensorCollection
+    from src.models.poses import ObjectPoseRecovery
+
+    B, k, O, N = 4, 5, 2, 6
+    corr = syn.correspondences_case(201, B, k)
+    tK, tM, tP = syn.template_geometry(202, O, N)
+    qK, qM = syn.crop_geometry(203, B)
+    rs = np.random.RandomState(204)
+    labels = rs.randint(1, O + 1, B)
+    id_src = rs.randint(0, N, (B, k))
+    rec = ObjectPoseRecovery(torch.from_numpy(tK), torch.from_numpy(tM), torch.from_numpy(tP))
+    pred = PandasTensorCollection(infos=pd.DataFrame(), src_pts=torch.from_numpy(corr["src_pts"]),
+                                  tar_pts=torch.from_numpy(corr["tar_pts"]),
+                                  relScale=torch.from_numpy(corr["rel_scale"]),
+                                  relInplane=torch.from_numpy(corr["rel_inplane"]))
+    pred = rec.forward_ransac(pred)
+    poses = rec.forward_recovery(torch.from_numpy(labels), torch.from_numpy(qK), torch.from_numpy(qM),
+                                 torch.from_numpy(id_src), pred.M.clone())
+    np.savez_compressed(os.path.join(GOLD, "pose.npz"), labels=labels, id_src=id_src, M=pred.M.numpy(),
+                        idx_failed=pred.idx_failed.numpy(), ransac_scores=pred.ransac_scores.numpy().astype(np.int8),
+                        ransac_src_pts=pred.ransac_src_pts.numpy().astype(np.int16),
+                        ransac_tar_pts=pred.ransac_tar_pts.numpy().astype(np.int16), poses=poses.numpy())
+    print("pose: inlier counts", pred.ransac_scores.sum(-1).tolist(), "failed", pred.idx_failed.tolist())
+
+
+class _FakeTemplates:
+    def __init__(self, items):
+        self.items = items
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def e2e_inputs(seed, O, N, B):
+    """Config-1-like end-to-end inputs: templates, crops = noisy templates, geometry."""
+    import types
+
+    rs = np.random.RandomState(seed)
+    tK, tM, tP = syn.template_geometry(seed + 1, O, N)
+    items, all_t, all_m = [], [], []
+    for o in range(O):
+        t, m = syn.template_images(seed + 10 + o, N)
+        all_t.append(t)
+        all_m.append(m)
+        items.append(types.SimpleNamespace(rgb=torch.from_numpy(t), mask=torch.from_numpy(m),
+                                           K=torch.from_numpy(tK[o]), M=torch.from_numpy(tM[o]),
+                                           poses=torch.from_numpy(tP[o])))
+    labels = rs.randint(1, O + 1, B)
+    views = rs.randint(0, N, B)
+    imgs = np.stack([all_t[l - 1][v] for l, v in zip(labels, views)])
+    msk = np.stack([all_m[l - 1][v] for l, v in zip(labels, views)])
+    imgs = (imgs + 0.1 * rs.standard_normal(imgs.shape).astype(np.float32)) * msk[:, None]
+    qK, qM = syn.crop_geometry(seed + 2, B)
+    return items, dict(tar_img=imgs.astype(np.float32), tar_mask=msk, tar_K=qK, tar_M=qM, labels=labels, views=views)
+
+
+E2E = dict(seed=301, O=2, N=6, B=3, k=4, vit=(384, 12, 6))
+
+
+def gen_e2e():
+    """Whole GigaPose.eval_retrieval (gigaPose.py:481-633) of the unmodified reference: ViT-S/14
+    stand-in backbone, reference ISTNet/LocalSimilarity/ObjectPoseRecovery, CPU."""
+    import tempfile
+
+    import pandas as pd
+    ref_shim.install()
+    torch.set_num_threads(8)
+    from src.megapose.utils.tensor_collection import PandasTensorCollection
+    from src.models.gigaPose import GigaPose
+    from src.models.matching import LocalSimilarity
+    from src.models.network.ae_net import AENet
+
+    cfg = E2E
+    dim, depth, heads = cfg["vit"]
+    backbone = ref_shim.HFDinov2Backbone.build(dim, depth, heads, seed=0)
+    syn.fill_state_dict(backbone.m, 302)
+    ae = AENet("dinov2_vits14", backbone, dim, 64)
+    ist = build_ref_ist(seed=303)
+    metric = LocalSimilarity(k=cfg["k"], sim_threshold=0.5, patch_threshold=3)
+    tmp = tempfile.mkdtemp()
+    model = GigaPose("large", ae, ist, None, metric, None, 1000, tmp, max_num_dets_per_forward=4).eval()
+    items, q = e2e_inputs(cfg["seed"], cfg["O"], cfg["N"], cfg["B"])
+    model.template_datasets = {"syn": _FakeTemplates(items)}
+    infos = pd.DataFrame(dict(label=[str(l) for l in q["labels"]], scene_id=[1] * cfg["B"], view_id=[7] * cfg["B"]))
+    batch = PandasTensorCollection(infos=infos, tar_img=torch.from_numpy(q["tar_img"]),
+                                   tar_mask=torch.from_numpy(q["tar_mask"]), tar_K=torch.from_numpy(q["tar_K"]),
+                                   tar_M=torch.from_numpy(q["tar_M"]))
+    objs = sorted(set(int(l) for l in q["labels"]))
+    batch.test_list = PandasTensorCollection(infos=pd.DataFrame(dict(
+        im_id=[7] * len(objs), scene_id=[1] * len(objs), obj_id=objs,
+        inst_count=[int((q["labels"] == o).sum()) for o in objs], detection_time=[0.1] * len(objs))))
+    # tie order of torch.argsort is unspecified (gigaPose.py:591): pin it to stable in the HARNESS only
+    orig_argsort = torch.argsort
+    torch.argsort = lambda x, dim=-1, descending=False, stable=False: orig_argsort(x, dim=dim, descending=descending, stable=True)
+    captured = {}
+    orig_fs = model.filter_and_save
+
+    def spy(predictions, **kw):
+        captured["pred"] = predictions.clone()
+        return orig_fs(predictions, **kw)
+
+    model.filter_and_save = spy
+    try:
+        with torch.no_grad():
+            model.eval_retrieval(batch, 0, "syn")
+    finally:
+        torch.argsort = orig_argsort
+    out = np.load(os.path.join(tmp, "predictions", "0.npz"))
+    p = captured["pred"]
+    td = model.template_datas["syn"]
+    np.savez_compressed(os.path.join(GOLD, "e2e.npz"), poses=out["poses"], scores=out["scores"],
+                        object_id=out["object_id"], id_src=p.id_src.numpy(), score_src=p.score_src.numpy(),
+                        all_scores=p.scores.numpy(), all_poses=p.pred_poses.numpy(), M=p.M.numpy(),
+                        relScale=p.relScale.numpy(), relInplane=p.relInplane.numpy(),
+                        src_pts=p.src_pts.numpy().astype(np.int16), tar_pts=p.tar_pts.numpy().astype(np.int16),
+                        tmpl_ae_feat_sample=td.ae_features[0, 0].numpy())
+    print("e2e: id_src", p.id_src.tolist(), "scores", np.round(p.scores.numpy(), 4).tolist())
+    print("     valid corr", (p.src_pts[..., 0] >= 0).sum(-1).tolist())
+
+
+STAGES = {"matcher": gen_matcher, "ist": gen_ist, "pose": gen_pose, "e2e": gen_e2e}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

@@ -1,0 +1,124 @@
+"""GPU end-to-end parity: gigapose_amd.GigaPose.eval_retrieval vs the golden written by the
+UNMODIFIED reference GigaPose.eval_retrieval (oracle/make_goldens.py: gen_e2e; BASELINE config-1
+shape: ViT-S/14 stand-in, few templates, CPU reference path)."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from gigapose_amd import synthetic as syn
+from test_oracle_pose_ist import build_ist
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+E2E = dict(seed=301, O=2, N=6, B=3, k=4, vit=(384, 12, 6))
+
+
+class FakeTemplates:
+    def __init__(self, items):
+        self.items = items
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def e2e_inputs(seed, O, N, B):
+    import types
+
+    rs = np.random.RandomState(seed)
+    tK, tM, tP = syn.template_geometry(seed + 1, O, N)
+    items, all_t, all_m = [], [], []
+    for o in range(O):
+        t, m = syn.template_images(seed + 10 + o, N)
+        all_t.append(t)
+        all_m.append(m)
+        items.append(types.SimpleNamespace(rgb=torch.from_numpy(t), mask=torch.from_numpy(m), K=torch.from_numpy(tK[o]),
+                                           M=torch.from_numpy(tM[o]), poses=torch.from_numpy(tP[o])))
+    labels = rs.randint(1, O + 1, B)
+    views = rs.randint(0, N, B)
+    imgs = np.stack([all_t[l - 1][v] for l, v in zip(labels, views)])
+    msk = np.stack([all_m[l - 1][v] for l, v in zip(labels, views)])
+    imgs = (imgs + 0.1 * rs.standard_normal(imgs.shape).astype(np.float32)) * msk[:, None]
+    qK, qM = syn.crop_geometry(seed + 2, B)
+    return items, dict(tar_img=imgs.astype(np.float32), tar_mask=msk, tar_K=qK, tar_M=qM, labels=labels, views=views)
+
+
+def build_model(hf_features=False):
+    """gigapose_amd model with the same deterministic weights the golden generator gave the
+    reference (synthetic.fill_state_dict keyed by parameter names)."""
+    from transformers import Dinov2Config, Dinov2Model
+
+    from gigapose_amd.ae_net import AENet
+    from gigapose_amd.gigaPose import GigaPose
+    from gigapose_amd.matching import LocalSimilarity
+    from gigapose_amd.vit import Dinov2ViT
+
+    dim, depth, heads = E2E["vit"]
+    hf = Dinov2Model(Dinov2Config(hidden_size=dim, num_hidden_layers=depth, num_attention_heads=heads,
+                                  image_size=224, patch_size=14)).eval()
+    syn.fill_state_dict(hf, 302)
+    ae = AENet("dinov2_vits14", Dinov2ViT.from_hf(hf), dim, 64)
+    ist = build_ist(303)
+    metric = LocalSimilarity(k=E2E["k"], sim_threshold=0.5, patch_threshold=3)
+    model = GigaPose("large", ae, ist, None, metric, None, 1000, tempfile.mkdtemp(), max_num_dets_per_forward=4)
+    return model.eval().to(DEV), hf
+
+
+def make_batch(q):
+    from gigapose_amd.tensor_collection import PandasTensorCollection
+
+    B = len(q["labels"])
+    infos = pd.DataFrame(dict(label=[str(l) for l in q["labels"]], scene_id=[1] * B, view_id=[7] * B))
+    batch = PandasTensorCollection(infos=infos, **{k: torch.from_numpy(q[k]).to(DEV) for k in ["tar_img", "tar_mask", "tar_K", "tar_M"]})
+    objs = sorted(set(int(l) for l in q["labels"]))
+    batch.test_list = PandasTensorCollection(infos=pd.DataFrame(dict(
+        im_id=[7] * len(objs), scene_id=[1] * len(objs), obj_id=objs,
+        inst_count=[int((q["labels"] == o).sum()) for o in objs], detection_time=[0.1] * len(objs))))
+    return batch
+
+
+def pose_rel_err(a, b):
+    t = np.linalg.norm(a[..., :3, 3] - b[..., :3, 3], axis=-1) / np.linalg.norm(b[..., :3, 3], axis=-1)
+    r = np.abs(a[..., :3, :3] - b[..., :3, :3]).max(axis=(-1, -2))
+    return t, r
+
+
+def test_eval_retrieval_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "e2e.npz"))
+    model, _ = build_model()
+    items, q = e2e_inputs(E2E["seed"], E2E["O"], E2E["N"], E2E["B"])
+    model.template_datasets = {"syn": FakeTemplates(items)}
+    model.test_dataset_name = "syn"
+    batch = make_batch(q)
+    assert model.test_step(batch, 0) == 0
+    p = model.last_predictions
+    # onboarding produced the same features as the reference's (ViT-S on CPU)
+    np.testing.assert_allclose(model.template_datas["syn"].ae_features[0, 0].cpu().numpy(), g["tmpl_ae_feat_sample"],
+                               rtol=0, atol=3e-5)
+    # bit-exact template ids / correspondences, floats within tolerance
+    np.testing.assert_array_equal(p.id_src.cpu().numpy(), g["id_src"])
+    np.testing.assert_array_equal(p.src_pts.cpu().numpy(), g["src_pts"].astype(np.int64))
+    np.testing.assert_array_equal(p.tar_pts.cpu().numpy(), g["tar_pts"].astype(np.int64))
+    np.testing.assert_allclose(p.score_src.cpu().numpy(), g["score_src"], rtol=0, atol=2e-5)
+    np.testing.assert_array_equal(p.scores.cpu().numpy(), g["all_scores"])
+    valid = g["relScale"] > -999
+    np.testing.assert_allclose(p.relScale.cpu().numpy()[valid], g["relScale"][valid], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(p.M.cpu().numpy(), g["M"], rtol=2e-4, atol=5e-2)
+    terr, rerr = pose_rel_err(p.pred_poses.cpu().numpy(), g["all_poses"])
+    assert terr.max() < 1e-4 and rerr.max() < 1e-4, (terr.max(), rerr.max())
+    # what filter_and_save wrote (the reference's on-disk contract, gigaPose.py:439-448)
+    out = np.load(os.path.join(model.log_dir, "predictions", "0.npz"))
+    np.testing.assert_array_equal(out["object_id"], g["object_id"])
+    np.testing.assert_array_equal(out["scores"], g["scores"])
+    terr, rerr = pose_rel_err(out["poses"], g["poses"])
+    assert terr.max() < 1e-4 and rerr.max() < 1e-4
+    assert out["poses"].dtype == np.float32 and out["scene_id"].dtype == np.int32

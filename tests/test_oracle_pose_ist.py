@@ -1,0 +1,84 @@
+"""CPU: oracle restatements of the IST regressor, RANSAC and pose recovery pinned against goldens
+produced by the unmodified reference (oracle/make_goldens.py: gen_ist, gen_pose); plus state-dict
+name parity of the gigapose_amd mirrors with the reference modules."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gigapose_amd import synthetic as syn
+from oracle import cpu as oracle
+
+IST_CFG = dict(n_heads=0, input_dim=3, input_size=256, initial_dim=128, block_dims=[128, 192, 256, 512],
+               descriptor_size=256)
+
+
+def build_ist(seed):
+    from gigapose_amd.ist_net import ISTNet, Regressor, ResNet
+
+    net = ISTNet("resnet", ResNet(dict(IST_CFG)), Regressor(256, 256, True, True), 64).eval()
+    return syn.fill_state_dict(net, seed)
+
+
+def mlp_weights(net):
+    out = {}
+    for name, seq in (("scale", net.regressor.scale_predictor), ("inplane", net.regressor.inplane_predictor)):
+        out[name] = [t.detach().numpy() for l in (seq[0], seq[2], seq[4]) for t in (l.weight, l.bias)]
+    return out
+
+
+def test_state_dict_names_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ist.npz"))
+    net = build_ist(101)
+    assert "|".join(sorted(net.state_dict())) == str(g["state_names"])
+
+
+def test_resnet_and_mlp_oracle_vs_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ist.npz"))
+    net = build_ist(101)
+    tmpl, _ = syn.template_images(102, 2)
+    with torch.no_grad():
+        feat = net.forward_by_chunk(torch.from_numpy(tmpl)).numpy()
+    np.testing.assert_allclose(feat, g["resnet_feat"], rtol=1e-4, atol=1e-3)  # |feat| ~ 20
+    rs = np.random.RandomState(103)
+    src_feat = rs.standard_normal((3, 256, 16, 16)).astype(np.float32)
+    tar_feat = rs.standard_normal((3, 256, 16, 16)).astype(np.float32)
+    corr = syn.correspondences_case(104, 3, 1)
+    sc, cs = oracle.ist_inference(tar_feat.reshape(3, 256, 256), src_feat.reshape(3, 1, 256, 256),
+                                  corr["tar_pts"], corr["src_pts"], mlp_weights(net))
+    assert ((sc[:, 0] == -1000) == (g["scales"] == -1000)).all()
+    np.testing.assert_allclose(sc[:, 0], g["scales"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(cs[:, 0], g["cos_sin"], rtol=2e-5, atol=2e-6)
+
+
+def pose_case():
+    B, k, O, N = 4, 5, 2, 6
+    corr = syn.correspondences_case(201, B, k)
+    tK, tM, tP = syn.template_geometry(202, O, N)
+    qK, qM = syn.crop_geometry(203, B)
+    return corr, (tK, tM, tP), (qK, qM)
+
+
+def test_ransac_oracle_vs_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pose.npz"))
+    corr, _, _ = pose_case()
+    M, failed, isrc, itar, isc = oracle.ransac(corr["src_pts"], corr["tar_pts"], corr["rel_scale"], corr["rel_inplane"])
+    np.testing.assert_array_equal(failed, g["idx_failed"])
+    np.testing.assert_array_equal(isc, g["ransac_scores"].astype(np.int64))
+    np.testing.assert_array_equal(isrc, g["ransac_src_pts"].astype(np.int64))
+    np.testing.assert_array_equal(itar, g["ransac_tar_pts"].astype(np.int64))
+    np.testing.assert_allclose(M, g["M"], rtol=1e-5, atol=2e-4)  # translations are O(100) px
+    # edge cases: N=0 -> identity, not failed; N=1 -> that candidate, failed
+    assert (M[0, 0] == np.eye(3)).all() and not failed[0, 0] and failed[0, 1] and isc[0, 1].sum() == 0
+
+
+def test_recovery_oracle_vs_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pose.npz"))
+    _, (tK, tM, tP), (qK, qM) = pose_case()
+    poses = oracle.recover(g["labels"] - 1, qK, qM, g["id_src"], g["M"], tK, tM, tP)
+    ref = g["poses"]
+    np.testing.assert_allclose(poses[..., :3, :3], ref[..., :3, :3], rtol=0, atol=2e-6)
+    rel = np.linalg.norm(poses[..., :3, 3] - ref[..., :3, 3], axis=-1) / np.linalg.norm(ref[..., :3, 3], axis=-1)
+    assert rel.max() < 1e-5, rel.max()
+    np.testing.assert_array_equal(poses[..., 3, :], ref[..., 3, :])

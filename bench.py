@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Headline benchmark: query-crops/sec through the whole coarse-pose hot path
+(ViT feat + template NN + 4DoF regress; BASELINE.json metric) on MI355X.
+
+A "step" = one pass of gigapose_amd.GigaPose.predict over one batch of B synthetic 224x224 crops
+already resident in HBM, against an onboarded bank of O objects x 162 templates:
+DINOv2 ViT-L/14 features -> fused template matching -> IST backbone + regressor -> RANSAC -> pose.
+N=1 workload = BASELINE.json configs[1]: ViT-L/14 random-init, 1 object x 162 templates, B=64.
+N>1 (one rank per GPU, torch.distributed / RCCL): weak scaling, B crops per rank, template bank
+sharded by template index with the two all-gathers of gigapose_amd/sharding.py (configs[3] shape).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` (dominant kernel
+family timed by HIP events on the launch stream inside the timed region) and `cpu_baseline` (the
+CPU oracle port timed on the host cores on a bounded sample; N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense f32-input MFMA peak (MI355X_MICROARCH.md)
+FLOP_PER_CROP = {"dinov2_vitl14": 162.0e9, "dinov2_vits14": 12.25e9, "dinov2_vitb14": 0.0}
+
+
+def cpu_baseline(variant, n_templates, k, sample_crops=2):
+    """The CPU oracle (oracle/: numpy ViT + C matcher/MLP/RANSAC/recovery; torch-CPU convs for the
+    IST backbone) on `sample_crops` crops of the same workload, onboarding excluded."""
+    from gigapose_amd import factory, synthetic as syn
+    from gigapose_amd.vit import VARIANTS
+    from oracle import cpu as oracle
+    from oracle import vit_numpy
+
+    dim, depth, heads = VARIANTS[variant]
+    model = factory.build_model(variant, k=k, device="cpu", seed=0)
+    tset = factory.TemplateSet(1, n_templates, seed=100)
+    sd = {kk: v.numpy() for kk, v in model.ae_net.dinov2_model.state_dict().items()}
+    rs = np.random.RandomState(0)
+    # bank features: values do not affect the oracle's timing -> random unit vectors, not a ViT pass
+    bank = syn._unit(rs.standard_normal((1, n_templates, dim, 256)).astype(np.float32), 2)
+    ist_bank = rs.standard_normal((1, n_templates, 256, 256)).astype(np.float32)
+    q = tset.crops(7, sample_crops, "cpu")
+    tK, tM, tP = syn.template_geometry(101, 1, n_templates)
+    weights = {}
+    for name, seq in (("scale", model.ist_net.regressor.scale_predictor), ("inplane", model.ist_net.regressor.inplane_predictor)):
+        weights[name] = [t.detach().numpy() for l in (seq[0], seq[2], seq[4]) for t in (l.weight, l.bias)]
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    t0 = time.time()
+    feat = vit_numpy.patch_features(sd, q["tar_img"].numpy(), depth, heads)
+    out = oracle.local_similarity_test(bank.reshape(1, n_templates, dim, 16, 16), feat, np.ones((1, n_templates, 224, 224), np.float32),
+                                       q["tar_mask"].numpy(), np.zeros(sample_crops, np.int32), k)
+    with torch.no_grad():
+        tar_ist = model.ist_net.forward_by_chunk(q["tar_img"]).numpy().reshape(sample_crops, 256, 256)
+    sel = ist_bank[0][out["id_src"]]
+    sc, cs = oracle.ist_inference(tar_ist, sel, out["tar_pts"], out["src_pts"], weights)
+    M, failed, isrc, itar, isc = oracle.ransac(out["src_pts"], out["tar_pts"], sc, cs)
+    oracle.recover(np.zeros(sample_crops, np.int32), q["tar_K"].numpy(), q["tar_M"].numpy(), out["id_src"], M, tK, tM, tP)
+    dt = time.time() - t0
+    return {"value": round(sample_crops / dt, 4), "unit": "query-crops/sec", "cores": threads, "kind": "port",
+            "sample": f"{sample_crops} crops x {n_templates} templates, {variant}, oracle/ (numpy ViT + C matcher/MLP/RANSAC, "
+                      f"torch-CPU IST convs), f32, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step")
+    ap.add_argument("--objects", type=int, default=1)
+    ap.add_argument("--templates", type=int, default=162)
+    ap.add_argument("--variant", default="dinov2_vitl14")
+    ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--mode", default="auto", choices=["auto", "sharded", "replicas"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gigapose_amd import _lib, factory
+
+    mode = args.mode if args.mode != "auto" else ("sharded" if world > 1 else "single")
+    model = factory.build_model(args.variant, k=args.k, device=dev, seed=0)
+    if mode == "sharded" and world > 1:
+        model.enable_template_sharding()
+    tset = factory.TemplateSet(args.objects, args.templates, seed=100)
+    model.template_datasets = {"syn": tset}
+    model.set_template_data("syn")  # onboarding: excluded from the timed region (reference gigaPose.py:396-398)
+    q = tset.crops(1000 + rank, args.batch, dev)
+    model.pose_recovery["syn"].check_asserts = False  # no host sync inside the timed loop
+
+    def step():
+        return model.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
+
+    for _ in range(args.warmup):
+        step()
+    lib = _lib.lib()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lib.gp_prof_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pred = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kinds = 8
+    ms = (ctypes.c_double * kinds)()
+    work = (ctypes.c_double * kinds)()
+    cnt = (ctypes.c_longlong * kinds)()
+    nk = lib.gp_prof_end(kinds, ms, work, cnt)
+    lib.gp_prof_kind_name.restype = ctypes.c_char_p
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    crops = world * args.batch * args.steps
+    kern = {}
+    for i in range(nk):
+        if cnt[i]:
+            name = lib.gp_prof_kind_name(i).decode()
+            kern[name] = {"ms_per_step": round(ms[i] / args.steps, 3), "launches_per_step": cnt[i] // args.steps,
+                          "avg_launch_us": round(1e3 * ms[i] / cnt[i], 2),
+                          ("GB/s" if name == "layernorm" else "TFLOP/s"): round(work[i] / ms[i] / (1e6 if name == "layernorm" else 1e9), 2)}
+    g = kern.get("gemm_kmajor", {})
+    achieved = g.get("TFLOP/s", 0.0)
+    roofline = {"kernel": "gemm_kmajor_kernel (ViT linear layers + IST MLP; f32-input MFMA 32x32x2)", "bound": "mfma",
+                "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "share_of_step": round(g.get("ms_per_step", 0.0) / (1e3 * dt / args.steps), 3), "kernels": kern}
+    out = {
+        "metric": "query-crops/sec (ViT feat + template NN + 4DoF regress), 162 templates, 1/2/4/8 GPU",
+        "value": round(crops / dt, 2), "unit": "query-crops/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: {args.variant} random-init, {args.objects} object(s) x {args.templates} templates, "
+                               f"batch={args.batch} crops per GPU, k={args.k}, full path ViT->match->IST->RANSAC->pose",
+                   "global_batch": world * args.batch, "parallelism": "single" if world == 1 else f"{mode}{world}",
+                   "ist_backbone": "MIOpen via PyTorch-ROCm (round 1)"},
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args.variant, args.templates, args.k)
+        except Exception as e:  # the baseline is a reported extra; never lose the GPU number
+            out["cpu_baseline"] = {"error": repr(e)}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

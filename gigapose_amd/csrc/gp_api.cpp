@@ -1,6 +1,7 @@
 // Error reporting + version for the C-ABI (include/gigapose_hip.h).
 #include <cstdarg>
 #include <cstdio>
+#include <vector>
 
 #include "gp_common.h"
 
@@ -14,7 +15,58 @@ void gp_set_error(const char* fmt, ...)
     va_end(ap);
 }
 
+// ---- optional per-kernel-family timing with HIP events on the launch stream (bench.py roofline leg)
+namespace {
+struct Rec { hipEvent_t a, b; int kind; double work; };
+bool g_prof = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t get_event()
+{
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+const char* kKindNames[GP_PROF_KINDS] = {"gemm_kmajor", "match_tiles", "attention", "layernorm", "conv", "other"};
+}  // namespace
+
+GpProfScope::GpProfScope(int kind, double work, hipStream_t st) : idx_(-1), st_(st)
+{
+    if (!g_prof) return;
+    Rec r{get_event(), get_event(), kind, work};
+    (void)hipEventRecord(r.a, st);
+    g_recs.push_back(r);
+    idx_ = (int)g_recs.size() - 1;
+}
+GpProfScope::~GpProfScope()
+{
+    if (idx_ >= 0) (void)hipEventRecord(g_recs[idx_].b, st_);
+}
+
 extern "C" {
+void gp_prof_begin(void)
+{
+    for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+    g_recs.clear();
+    g_prof = true;
+}
+int gp_prof_end(int max_kinds, double* ms, double* work, long long* launches)
+{
+    g_prof = false;
+    for (int k = 0; k < max_kinds; ++k) { ms[k] = 0; work[k] = 0; launches[k] = 0; }
+    for (auto& r : g_recs) {
+        (void)hipEventSynchronize(r.b);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.a, r.b);
+        if (r.kind < max_kinds) { ms[r.kind] += t; work[r.kind] += r.work; launches[r.kind] += 1; }
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+    return GP_PROF_KINDS;
+}
+const char* gp_prof_kind_name(int kind) { return (kind >= 0 && kind < GP_PROF_KINDS) ? kKindNames[kind] : ""; }
 const char* gp_last_error(void) { return g_err; }
 int gp_abi_version(void) { return 1; }
 }

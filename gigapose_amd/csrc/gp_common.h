@@ -38,6 +38,15 @@ void gp_set_error(const char* fmt, ...);
         }                                                                       \
     } while (0)
 
+// bench-only timing scope: records HIP events around a launch when gp_prof_begin() is active
+enum { GP_PROF_GEMM = 0, GP_PROF_MATCH = 1, GP_PROF_ATTN = 2, GP_PROF_LN = 3, GP_PROF_CONV = 4, GP_PROF_OTHER = 5, GP_PROF_KINDS = 6 };
+struct GpProfScope {
+    GpProfScope(int kind, double work, hipStream_t st);
+    ~GpProfScope();
+    int idx_;
+    hipStream_t st_;
+};
+
 // MFMA 32x32x2 f32 C/D fragment map (guide section 3): lane l, register r in [0,16):
 //   col = l & 31,  row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
 __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

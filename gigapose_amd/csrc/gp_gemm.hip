@@ -92,6 +92,7 @@ int gp_gemm_launch(const float* A, int lda, const float* B, int ldb, float* D, i
                "gp_gemm_kmajor: bad leading dimensions lda=%d ldb=%d ldd=%d", lda, ldb, ldd);
     GP_REQUIRE(A && B && D, "gp_gemm_kmajor: null pointer");
     GP_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "gp_gemm_kmajor: operands must be 16-byte aligned");
+    GpProfScope prof(GP_PROF_GEMM, 2.0 * I * J * K, st);
     switch (epilogue) {
         case EPI_NONE: launch<EPI_NONE>(A, lda, B, ldb, D, ldd, I, J, K, bias, scale, res, ldr, st); break;
         case EPI_BIAS_I:

@@ -288,6 +288,7 @@ int gp_match_tiles(const float* query, const float* bank, const float* qmask, co
     if (B == 0) return GP_OK;
     GP_REQUIRE(query && bank && qmask && bmask && labels && idx_t2s && score_t2s && mask_all && sim_avg,
                "gp_match_tiles: null pointer");
+    GpProfScope prof(GP_PROF_MATCH, 2.0 * B * N * 256.0 * 256.0 * C, (hipStream_t)stream);
     hipLaunchKernelGGL(match_tiles_kernel, dim3(xcd_chunked_grid(B * N)), dim3(512), 0,
                        (hipStream_t)stream, query, bank, qmask, bmask, labels, B, N, C, sim_threshold,
                        patch_threshold, idx_t2s, score_t2s, mask_all, sim_avg);

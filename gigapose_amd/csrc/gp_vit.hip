@@ -247,8 +247,11 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
     const int nl = (stop_after_layers >= 0 && stop_after_layers < depth) ? stop_after_layers : depth;
     for (int l = 0; l < nl; ++l) {
         const float* const* w = weights + W_HEADER + l * L_PER_LAYER;
-        hipLaunchKernelGGL(layernorm_kernel, dim3(Mpad / 128), dim3(128), 0, st, X, Hn, w[L_LN1_G], w[L_LN1_B], C,
-                           Mpad, ln_eps);
+        {
+            GpProfScope prof(GP_PROF_LN, 8.0 * C * Mpad, st);
+            hipLaunchKernelGGL(layernorm_kernel, dim3(Mpad / 128), dim3(128), 0, st, X, Hn, w[L_LN1_G], w[L_LN1_B],
+                               C, Mpad, ln_eps);
+        }
         // Q,K channel-major [2C][Mpad]
         if ((rc = gp_gemm_launch(w[L_QK_WT], 2 * C, Hn, Mpad, QK, Mpad, 2 * C, Mpad, C, 1, w[L_QK_B], nullptr,
                                  nullptr, 0, st)))
@@ -257,15 +260,21 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
         if ((rc = gp_gemm_launch(Hn, Mpad, w[L_V_WT], C, Vt, C, Mpad, C, C, 4 /*BIAS_J*/, w[L_V_B], nullptr,
                                  nullptr, 0, st)))
             return rc;
-        hipLaunchKernelGGL(attention_kernel, dim3(xcd_chunked_grid(B * heads * NKT)), dim3(64), 0, st, QK, Vt, Hn,
-                           B, heads, C, Mpad, 0.125f);
+        {
+            GpProfScope prof(GP_PROF_ATTN, 4.0 * B * heads * 257.0 * 257.0 * 64.0, st);
+            hipLaunchKernelGGL(attention_kernel, dim3(xcd_chunked_grid(B * heads * NKT)), dim3(64), 0, st, QK, Vt,
+                               Hn, B, heads, C, Mpad, 0.125f);
+        }
         GP_CHECK_LAUNCH("gp_vit_forward/attention");
         // x = x + ls1 * proj(attn)
         if ((rc = gp_gemm_launch(w[L_PROJ_WT], C, Hn, Mpad, X, Mpad, C, Mpad, C, 3, w[L_PROJ_B], w[L_LS1], X, Mpad,
                                  st)))
             return rc;
-        hipLaunchKernelGGL(layernorm_kernel, dim3(Mpad / 128), dim3(128), 0, st, X, Hn, w[L_LN2_G], w[L_LN2_B], C,
-                           Mpad, ln_eps);
+        {
+            GpProfScope prof(GP_PROF_LN, 8.0 * C * Mpad, st);
+            hipLaunchKernelGGL(layernorm_kernel, dim3(Mpad / 128), dim3(128), 0, st, X, Hn, w[L_LN2_G], w[L_LN2_B],
+                               C, Mpad, ln_eps);
+        }
         if ((rc = gp_gemm_launch(w[L_FC1_WT], mlp_dim, Hn, Mpad, F, Mpad, mlp_dim, Mpad, C, 2 /*GELU*/, w[L_FC1_B],
                                  nullptr, nullptr, 0, st)))
             return rc;

@@ -68,6 +68,14 @@ class GigaPose(_Base):
         self.template_datasets = None
         self.test_dataset_name = None
         self.last_predictions = None  # full (unfiltered) predictions of the last eval_retrieval call
+        self.template_shard = None    # (rank, world, group) when the template bank is sharded
+
+    def enable_template_sharding(self, group=None):
+        """Shard the template bank over the ranks of `group` (gigapose_amd/sharding.py).  Call
+        before set_template_data; every rank must then call predict() with the same batch size."""
+        import torch.distributed as dist
+
+        self.template_shard = (dist.get_rank(group), dist.get_world_size(group), group)
 
     # ------------------------------------------------------------------ onboarding
     @torch.no_grad()
@@ -77,16 +85,27 @@ class GigaPose(_Base):
         template_dataset = self.template_datasets[dataset_name]
         dev = self.device
         cols = {n: [] for n in ["mask", "K", "M", "poses", "ae_features", "ist_features"]}
+        lo, hi = 0, None
+        if self.template_shard is not None:
+            from .sharding import ShardedMatcher, shard_bounds
+
+            rank, world, group = self.template_shard
         for idx in range(len(template_dataset)):
             item = template_dataset[idx]
             templates = item.rgb.to(dev)
-            cols["ae_features"].append(self.ae_net(templates))
+            if self.template_shard is not None:  # AE features only for this rank's template slice
+                lo, hi = shard_bounds(templates.shape[0], world, rank)
+            cols["ae_features"].append(self.ae_net(templates[lo:hi]))
             cols["ist_features"].append(self.ist_net.forward_by_chunk(templates))
             for n in ["mask", "K", "M", "poses"]:
                 cols[n].append(getattr(item, n).to(dev))
         data = {n: torch.stack(v, dim=0) for n, v in cols.items()}
         self.template_datas[dataset_name] = PandasTensorCollection(infos=pd.DataFrame(), **data)
-        self.match_banks[dataset_name] = MatchBank(data["ae_features"], data["mask"])
+        if self.template_shard is None:
+            self.match_banks[dataset_name] = MatchBank(data["ae_features"], data["mask"])
+        else:  # the matcher bank holds only this rank's slice of every object's templates
+            shard = MatchBank(data["ae_features"], data["mask"][:, lo:hi].contiguous())
+            self.match_banks[dataset_name] = ShardedMatcher(self.testing_metric, shard, lo, group)
         self.pose_recovery[dataset_name] = ObjectPoseRecovery(template_K=data["K"], template_Ms=data["M"],
                                                               template_poses=data["poses"])
         torch.cuda.synchronize()
@@ -103,7 +122,10 @@ class GigaPose(_Base):
         template_data = self.template_datas[dataset_name]
         labels0 = (labels.to(tar_img.device) - 1).to(torch.int32).contiguous()
         tar_ae = self.ae_net(tar_img)                                            # stage 1: ViT features
-        pred = self.testing_metric.test_bank(bank, tar_ae, tar_mask, labels0)    # stage 3: matching
+        if self.template_shard is None:
+            pred = self.testing_metric.test_bank(bank, tar_ae, tar_mask, labels0)  # stage 3: matching
+        else:
+            pred = bank.test_bank(tar_ae, tar_mask, labels0)                      # sharded bank + all-gathers
         tar_ist = self.ist_net.forward_by_chunk(tar_img)                         # stage 4a: IST backbone (once)
         rel_scale, rel_inplane = self.ist_net.regress_bank(template_data.ist_features, labels0, pred.id_src,
                                                            tar_ist, pred.src_pts, pred.tar_pts)

@@ -1,0 +1,118 @@
+"""Template-bank sharding across the GPUs of one node (BASELINE.json north_star).
+
+Not present in the reference (its inference is single-GPU): rank r keeps templates
+[lo_r, hi_r) of EVERY object.  Per step each rank
+  1. runs the ViT on its own B crops, all-gathers the matcher-normalised query features, patch
+     masks and labels                                             (exchange #1, RCCL all-gather)
+  2. matches all W*B crops against its shard (gp_match_tiles) and takes a local top-k
+  3. all-gathers the k per-shard candidates per crop -- global template id, score and the 256-patch
+     record (idx u8, score f32, mask f32), packed into one byte row          (exchange #2)
+  4. merges the W*k candidates of its own crops: "higher score, then lower global id" -- exactly
+     gp_topk's order over all N templates, so results equal the unsharded path bit-for-bit
+  5. continues locally (IST regressor, RANSAC, recovery) with the small replicated banks.
+Collectives go through torch.distributed ("nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+P = 256
+REC_BYTES = 8 + 4 + P + 4 * P + 4 * P  # id i64, score f32, idx u8[256], score f32[256], mask f32[256]
+
+
+def shard_bounds(n_templates, world, rank):
+    """Contiguous, near-equal split of template indices: rank r owns [lo, hi)."""
+    lo = (n_templates * rank + world - 1) // world
+    hi = (n_templates * (rank + 1) + world - 1) // world
+    return lo, hi
+
+
+def all_gather_cat(t, group=None):
+    """all-gather equal-shaped tensors and concatenate along dim 0 (rank order)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return t
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t.contiguous(), group=group)
+    return torch.cat(outs, dim=0)
+
+
+def pack_candidates(ids_global, scores, rec_idx, rec_score, rec_mask):
+    """(B,k) i64, (B,k) f32, (B,k,256) u8/f32/f32 -> (B,k,REC_BYTES) u8 rows."""
+    B, k = ids_global.shape
+    parts = [ids_global.contiguous().view(torch.uint8).reshape(B, k, 8),
+             scores.contiguous().view(torch.uint8).reshape(B, k, 4),
+             rec_idx.reshape(B, k, P),
+             rec_score.contiguous().view(torch.uint8).reshape(B, k, 4 * P),
+             rec_mask.contiguous().view(torch.uint8).reshape(B, k, 4 * P)]
+    return torch.cat(parts, dim=2).contiguous()
+
+
+def unpack_candidates(rows):
+    """Inverse of pack_candidates for (..., REC_BYTES) u8 rows."""
+    lead = rows.shape[:-1]
+    rows = rows.contiguous()
+    o = 0
+    ids = rows[..., o:o + 8].contiguous().view(torch.int64).reshape(lead); o += 8
+    sc = rows[..., o:o + 4].contiguous().view(torch.float32).reshape(lead); o += 4
+    ridx = rows[..., o:o + P].contiguous(); o += P
+    rsc = rows[..., o:o + 4 * P].contiguous().view(torch.float32).reshape(*lead, P); o += 4 * P
+    rma = rows[..., o:o + 4 * P].contiguous().view(torch.float32).reshape(*lead, P)
+    return ids, sc, ridx, rsc, rma
+
+
+def merge_topk(ids, scores, k):
+    """ids, scores (B, W*k): select k per row by (score desc, id asc).  Returns positions (B,k)."""
+    by_id = torch.sort(ids, dim=1, stable=True).indices
+    sc_by_id = torch.gather(scores, 1, by_id)
+    by_score = torch.sort(sc_by_id, dim=1, descending=True, stable=True).indices
+    return torch.gather(by_id, 1, by_score)[:, :k]
+
+
+def exchange_and_merge(local_rows, n_own, k, rank, group=None):
+    """local_rows (W*B, k, REC_BYTES) u8: this rank's candidates for ALL crops (crop order = rank-major).
+    Returns merged ids (B,k) i64, scores (B,k), rec_idx/rec_score/rec_mask (B,k,256) for OWN crops."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world > 1:
+        outs = [torch.empty_like(local_rows) for _ in range(world)]
+        dist.all_gather(outs, local_rows, group=group)
+        mine = torch.cat([o[rank * n_own:(rank + 1) * n_own] for o in outs], dim=1)  # (B, W*k, REC)
+    else:
+        mine = local_rows
+    ids, sc, ridx, rsc, rma = unpack_candidates(mine)
+    pos = merge_topk(ids, sc, k)
+    pos3 = pos[:, :, None].expand(-1, -1, P)
+    return (torch.gather(ids, 1, pos), torch.gather(sc, 1, pos), torch.gather(ridx, 1, pos3),
+            torch.gather(rsc, 1, pos3), torch.gather(rma, 1, pos3))
+
+
+class ShardedMatcher:
+    """Wraps a LocalSimilarity (gigapose_amd.matching) and a MatchBank holding only this rank's
+    template shard; produces the same PandasTensorCollection as LocalSimilarity.test_bank."""
+
+    def __init__(self, metric, bank_shard, template_lo, group=None):
+        self.metric, self.bank, self.lo, self.group = metric, bank_shard, template_lo, group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if bank_shard.N < metric.k:
+            raise ValueError(f"shard of {bank_shard.N} templates is smaller than k={metric.k}")
+
+    @torch.no_grad()
+    def test_bank(self, tar_feat, tar_mask, labels0):
+        import pandas as pd
+
+        from .matching import patch_grid_mask
+        from .tensor_collection import PandasTensorCollection
+
+        m = self.metric
+        n_own = tar_feat.shape[0]
+        q = all_gather_cat(m.normalize(tar_feat), self.group)                       # exchange #1
+        qmask = all_gather_cat(patch_grid_mask(tar_mask), self.group)
+        labels_all = all_gather_cat(labels0.to(torch.int32).contiguous(), self.group)
+        idx, sc, ma, avg = m.match_tiles(q, qmask, self.bank, labels_all)
+        ids, score = m.topk(avg)
+        rec_idx, rec_score, rec_mask = m.gather_records(ids, idx, sc, ma)
+        rows = pack_candidates(ids.long() + self.lo, score, rec_idx, rec_score, rec_mask)
+        gid, gsc, ridx, rsc, rma = exchange_and_merge(rows, n_own, m.k, self.rank, self.group)  # exchange #2
+        tar_pts, src_pts = m.format_points(ridx.contiguous(), rma.contiguous())
+        return PandasTensorCollection(infos=pd.DataFrame(), id_src=gid, score_src=gsc, score_pts=rsc.contiguous(),
+                                      tar_pts=tar_pts, src_pts=src_pts)

@@ -23,6 +23,14 @@ extern "C" {
 int gp_abi_version(void);
 const char* gp_last_error(void);
 
+/* Optional timing of kernel families with HIP events on the launch stream (used by bench.py for the
+ * roofline figure; not part of the reference interface).  gp_prof_begin() starts recording;
+ * gp_prof_end() stops, synchronises and returns per-kind totals: ms[k], work[k] (flops, or bytes for
+ * layernorm), launches[k]; its return value is the number of kinds; names via gp_prof_kind_name(). */
+void gp_prof_begin(void);
+int gp_prof_end(int max_kinds, double* ms, double* work, long long* launches);
+const char* gp_prof_kind_name(int kind);
+
 /* ---- template matching: LocalSimilarity.test (src/models/matching.py:188-316) ------------- */
 
 /* F.normalize(x, dim=C) for x (rows, C, 256).  Replaces matching.py:224,229 and ae_net.py:69. */

@@ -58,7 +58,7 @@ def cpu_baseline(variant, n_templates, k, sample_crops=2):
     out = oracle.local_similarity_test(bank.reshape(1, n_templates, dim, 16, 16), feat, np.ones((1, n_templates, 224, 224), np.float32),
                                        q["tar_mask"].numpy(), np.zeros(sample_crops, np.int32), k)
     with torch.no_grad():
-        tar_ist = model.ist_net.forward_by_chunk(q["tar_img"]).numpy().reshape(sample_crops, 256, 256)
+        tar_ist = model.ist_net.backbone.reference_forward(q["tar_img"]).numpy().reshape(sample_crops, 256, 256)
     sel = ist_bank[0][out["id_src"]]
     sc, cs = oracle.ist_inference(tar_ist, sel, out["tar_pts"], out["src_pts"], weights)
     M, failed, isrc, itar, isc = oracle.ransac(out["src_pts"], out["tar_pts"], sc, cs)

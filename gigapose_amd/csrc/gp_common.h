@@ -75,6 +75,7 @@ static inline int xcd_chunked_grid(int total) { return 8 * ((total + 7) / 8); }
 // ---------------------------------------------------------------------------------------------
 template <int WM, int WN, int MI, int NI, int KS>
 struct KMajor {
+    static constexpr int WM_ = WM, WN_ = WN;
     static constexpr int BM = WM * MI * 32;
     static constexpr int BN = WN * NI * 32;
     static constexpr int NT = WM * WN * 64;

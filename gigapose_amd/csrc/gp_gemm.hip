@@ -121,6 +121,63 @@ int gp_gemm_launch(const float* A, int lda, const float* B, int ldb, float* D, i
     return GP_OK;
 }
 
+// ---- tile-shape experiments (tools/probe_gemm.py); not part of the product path -------------------
+namespace {
+template <class CFG, int MINW>
+__global__ __launch_bounds__(CFG::NT, MINW) void gemm_probe_kernel(const float* __restrict__ A, int lda,
+                                                                   const float* __restrict__ B, int ldb, float* D,
+                                                                   int ldd, int tiles_i, int tiles_j, int K)
+{
+    __shared__ float smem[CFG::LDS_FLOATS];
+    const int q = xcd_chunked_tile(blockIdx.x, tiles_i * tiles_j);
+    if (q < 0) return;
+    const int ti = q % tiles_i, tj = q / tiles_i;
+    const int i0 = ti * CFG::BM, j0 = tj * CFG::BN;
+    constexpr int MI = CFG::BM / 32 / CFG::WM_, NI = CFG::BN / 32 / CFG::WN_;
+    f32x16 acc[MI][NI];
+    CFG::run(A + i0, lda, B + j0, ldb, K, smem, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / CFG::WN_, wn = wave % CFG::WN_;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int j = j0 + wn * NI * 32 + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + wm * MI * 32 + mi * 32 + frag_row(r, lane);
+                D[(size_t)i * ldd + j] = acc[mi][ni][r];
+            }
+        }
+}
+template <class CFG, int MINW>
+int probe_launch(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J, int K, hipStream_t st)
+{
+    if (I % CFG::BM || J % CFG::BN || K % 32) return GP_EINVAL;
+    const int ti = I / CFG::BM, tj = J / CFG::BN;
+    hipLaunchKernelGGL((gemm_probe_kernel<CFG, MINW>), dim3(xcd_chunked_grid(ti * tj)), dim3(CFG::NT), 0, st, A, lda, B,
+                       ldb, D, ldd, ti, tj, K);
+    return hipGetLastError() == hipSuccess ? GP_OK : GP_ELAUNCH;
+}
+}  // namespace
+
+extern "C" int gp_gemm_probe(int variant, const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I,
+                             int J, int K, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    switch (variant) {
+        case 0: return probe_launch<KMajor<2, 2, 2, 2, 16>, 2>(A, lda, B, ldb, D, ldd, I, J, K, st);  // 128x128 (product)
+        case 1: return probe_launch<KMajor<2, 2, 2, 2, 32>, 2>(A, lda, B, ldb, D, ldd, I, J, K, st);  // KS=32
+        case 2: return probe_launch<KMajor<2, 4, 2, 2, 16>, 2>(A, lda, B, ldb, D, ldd, I, J, K, st);  // 128x256, 8 waves
+        case 3: return probe_launch<KMajor<4, 2, 2, 2, 16>, 2>(A, lda, B, ldb, D, ldd, I, J, K, st);  // 256x128, 8 waves
+        case 4: return probe_launch<KMajor<4, 2, 2, 4, 16>, 2>(A, lda, B, ldb, D, ldd, I, J, K, st);  // 256x256 (matcher)
+        case 5: return probe_launch<KMajor<2, 2, 4, 2, 16>, 1>(A, lda, B, ldb, D, ldd, I, J, K, st);  // 256x128, 4 waves
+        case 6: return probe_launch<KMajor<2, 2, 2, 4, 16>, 1>(A, lda, B, ldb, D, ldd, I, J, K, st);  // 128x256, 4 waves
+        case 7: return probe_launch<KMajor<2, 2, 2, 2, 8>, 2>(A, lda, B, ldb, D, ldd, I, J, K, st);   // KS=8
+        default: return GP_EINVAL;
+    }
+}
+
 extern "C" int gp_gemm_kmajor(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I,
                               int J, int K, int epilogue, const float* bias, const float* scale,
                               const float* residual, int ldr, void* stream)

@@ -72,6 +72,56 @@ __global__ __launch_bounds__(128) void layernorm_kernel(const float* __restrict_
         Y[(size_t)c * Mpad + m] = (x[(size_t)c * Mpad] - mean) * rstd * gamma[c] + beta[c];
 }
 
+// ---- LayerNorm, wide: block = 64 token columns x 16 channel slices (16 waves, 4128 waves in flight at
+// B=64 instead of 258), three short passes; the block's 64 x C tile is re-read from L2.
+__global__ __launch_bounds__(1024) void layernorm_wide_kernel(const float* __restrict__ X, float* __restrict__ Y,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int C, int Mpad,
+                                                               float eps)
+{
+    __shared__ float red[16][64];
+    const int tok = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int per = C >> 4, c0 = sl * per;
+    const float* x = X + (size_t)c0 * Mpad + (size_t)blockIdx.x * 64 + tok;
+    float* y = Y + (size_t)c0 * Mpad + (size_t)blockIdx.x * 64 + tok;
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < per; ++i) s += x[(size_t)i * Mpad];
+    red[sl][tok] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tot += red[j][tok];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < per; ++i) {
+        const float d = x[(size_t)i * Mpad] - mean;
+        q = __builtin_fmaf(d, d, q);
+    }
+    red[sl][tok] = q;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tot += red[j][tok];
+    const float rstd = 1.0f / __builtin_sqrtf(tot / (float)C + eps);
+#pragma unroll 8
+    for (int i = 0; i < per; ++i)
+        y[(size_t)i * Mpad] = (x[(size_t)i * Mpad] - mean) * rstd * gamma[c0 + i] + beta[c0 + i];
+}
+
+int launch_layernorm(const float* X, float* Y, const float* g, const float* b, int C, int Mpad, float eps,
+                     hipStream_t st)
+{
+    GpProfScope prof(GP_PROF_LN, 8.0 * C * Mpad, st);
+    if (C % 16 == 0)
+        hipLaunchKernelGGL(layernorm_wide_kernel, dim3(Mpad / 64), dim3(1024), 0, st, X, Y, g, b, C, Mpad, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel, dim3(Mpad / 128), dim3(128), 0, st, X, Y, g, b, C, Mpad, eps);
+    return 0;
+}
+
 // ---- attention, one wave per (image, head, 32-query block); everything in registers.
 // S^T tile trick: compute D[i=key][j=query] = sum_d K[d][key] * Q[d][query] so that a lane owns ONE
 // query column and 16 key rows per tile: softmax over keys is in-register (+1 cross-half shuffle),
@@ -81,7 +131,7 @@ __global__ __launch_bounds__(128) void layernorm_kernel(const float* __restrict_
 // dot product equals scaling q first).
 constexpr int NKT = 9;  // ceil(257 / 32) key tiles
 
-__global__ __launch_bounds__(64, 1) void attention_kernel(const float* __restrict__ QK /*[2C][Mpad]*/,
+__global__ __launch_bounds__(64, 4) void attention_kernel(const float* __restrict__ QK /*[2C][Mpad]*/,
                                                            const float* __restrict__ Vt /*[Mpad][C]*/,
                                                            float* __restrict__ O /*[C][Mpad]*/, int B, int H,
                                                            int C, int Mpad, float scale)
@@ -96,74 +146,80 @@ __global__ __launch_bounds__(64, 1) void attention_kernel(const float* __restric
     const int tq = qb * 32 + l31;
     const int tq_c = tq < T_TOK ? tq : T_TOK - 1;
 
-    f32x16 s[NKT];
+    // Online softmax over 3 chunks of 3 key tiles (96 keys): 48 score registers instead of 144, so
+    // four waves fit per SIMD and hide the L2 latency of the operand loads.
+    f32x16 o0, o1;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_part = 0.f;  // l_part: this lane-half's share of the softmax denominator
 
-    int tk_c[NKT];
+#pragma unroll 1
+    for (int ch = 0; ch < 3; ++ch) {
+        f32x16 s[3];
+        int tk_c[3];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        const int tk = kt * 32 + l31;
-        tk_c[kt] = tk < T_TOK ? tk : T_TOK - 1;
-    }
-#pragma unroll 4
-    for (int kk = 0; kk < 32; ++kk) {
-        const size_t drow = (size_t)(2 * kk + half) * Mpad;
-        const float qv = Qp[drow + tq_c];
+        for (int t = 0; t < 3; ++t) {
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            const float kv = Kp[drow + tk_c[kt]];
-            s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv, s[kt], 0, 0, 0);
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+            const int tk = (ch * 3 + t) * 32 + l31;
+            tk_c[t] = tk < T_TOK ? tk : T_TOK - 1;
         }
-    }
-    // scale, mask padded keys, row max (a "row" of the attention matrix = this lane's column)
-    float mx = -INFINITY;
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            const size_t drow = (size_t)(2 * kk + half) * Mpad;
+            const float qv = Qp[drow + tq_c];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tk = kt * 32 + frag_row(r, lane);
-            const float v = (tk < T_TOK) ? s[kt][r] * scale : -INFINITY;
-            s[kt][r] = v;
-            mx = fmaxf(mx, v);
+            for (int t = 0; t < 3; ++t) {
+                const float kv = Kp[drow + tk_c[t]];
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv, s[t], 0, 0, 0);
+            }
         }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
+        float cmax = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = expf(s[kt][r] - mx);
-            s[kt][r] = p;
-            sum += p;
-        }
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
-
-    // O[d][tq] = sum_tk V[tk][d] * P[tk][tq]; A operand lane (i = d, k-slot = half) reads
-    // V[tk = kt*32 + frag_row(r, lane)][d] -- the same key this lane's P register r belongs to.
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        f32x16 o;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int tk = kt * 32 + frag_row(r, lane);
+                const int tk = (ch * 3 + t) * 32 + frag_row(r, lane);
+                const float v = (tk < T_TOK) ? s[t][r] * scale : -INFINITY;
+                s[t][r] = v;
+                cmax = fmaxf(cmax, v);
+            }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+        const float m_new = fmaxf(m_run, cmax);
+        const float alpha = expf(m_run - m_new);  // first chunk: exp(-inf) = 0
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = expf(s[t][r] - m_new);
+                s[t][r] = p;
+                psum += p;
+            }
+        l_part = l_part * alpha + psum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        m_run = m_new;
+        // O[d][tq] += sum_tk V[tk][d] * P[tk][tq]; the A-operand lane (i = d, k-slot = half) reads
+        // V[tk = tile*32 + frag_row(r, lane)][d] -- the key this lane's P register r belongs to.
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int tk = (ch * 3 + t) * 32 + frag_row(r, lane);
                 tk = tk < T_TOK ? tk : T_TOK - 1;  // P is 0 there; keep the load in bounds / finite
-                const float vv = Vp[(size_t)tk * C + dt * 32 + l31];
-                o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[kt][r], o, 0, 0, 0);
+                const float* vrow = Vp + (size_t)tk * C + l31;
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], s[t][r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], s[t][r], o1, 0, 0, 0);
             }
-        if (tq < T_TOK) {
+    }
+    const float inv = 1.0f / (l_part + __shfl_xor(l_part, 32));
+    if (tq < T_TOK) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d = dt * 32 + frag_row(r, lane);
-                O[(size_t)(h * 64 + d) * Mpad + (size_t)b * T_TOK + tq] = o[r] * inv;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int d = frag_row(r, lane);
+            O[(size_t)(h * 64 + d) * Mpad + (size_t)b * T_TOK + tq] = o0[r] * inv;
+            O[(size_t)(h * 64 + 32 + d) * Mpad + (size_t)b * T_TOK + tq] = o1[r] * inv;
         }
     }
 }
@@ -247,11 +303,8 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
     const int nl = (stop_after_layers >= 0 && stop_after_layers < depth) ? stop_after_layers : depth;
     for (int l = 0; l < nl; ++l) {
         const float* const* w = weights + W_HEADER + l * L_PER_LAYER;
-        {
-            GpProfScope prof(GP_PROF_LN, 8.0 * C * Mpad, st);
-            hipLaunchKernelGGL(layernorm_kernel, dim3(Mpad / 128), dim3(128), 0, st, X, Hn, w[L_LN1_G], w[L_LN1_B],
-                               C, Mpad, ln_eps);
-        }
+        launch_layernorm(X, Hn, w[L_LN1_G], w[L_LN1_B], C, Mpad, ln_eps, st);
+        GP_CHECK_LAUNCH("gp_vit_forward/layernorm");
         // Q,K channel-major [2C][Mpad]
         if ((rc = gp_gemm_launch(w[L_QK_WT], 2 * C, Hn, Mpad, QK, Mpad, 2 * C, Mpad, C, 1, w[L_QK_B], nullptr,
                                  nullptr, 0, st)))
@@ -270,11 +323,8 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
         if ((rc = gp_gemm_launch(w[L_PROJ_WT], C, Hn, Mpad, X, Mpad, C, Mpad, C, 3, w[L_PROJ_B], w[L_LS1], X, Mpad,
                                  st)))
             return rc;
-        {
-            GpProfScope prof(GP_PROF_LN, 8.0 * C * Mpad, st);
-            hipLaunchKernelGGL(layernorm_kernel, dim3(Mpad / 128), dim3(128), 0, st, X, Hn, w[L_LN2_G], w[L_LN2_B],
-                               C, Mpad, ln_eps);
-        }
+        launch_layernorm(X, Hn, w[L_LN2_G], w[L_LN2_B], C, Mpad, ln_eps, st);
+        GP_CHECK_LAUNCH("gp_vit_forward/layernorm");
         if ((rc = gp_gemm_launch(w[L_FC1_WT], mlp_dim, Hn, Mpad, F, Mpad, mlp_dim, Mpad, C, 2 /*GELU*/, w[L_FC1_B],
                                  nullptr, nullptr, 0, st)))
             return rc;

@@ -1,11 +1,10 @@
 """IST network behind the reference interface (src/models/network/ist_net.py:11-162,
 src/models/network/resnet.py:26-50, 318-381; Hydra targets in configs/model/ist_net/resnet.yaml).
 
-* `ResNet`  -- LoFTR-style stride-16 CNN on the 256x256-resized crop -> (b,256,16,16).  Round-1
-  status: parameters/state-dict names mirror the reference and the forward runs through
-  PyTorch-ROCm (MIOpen convolutions) -- SURVEY 2b allows "MIOpen via PyTorch-ROCm first"; a HIP
-  implicit-GEMM replacement is SURVEY 8(f) row 4.  It is evaluated ONCE per crop (the reference
-  recomputes it k=5 times with identical input, gigaPose.py:553).
+* `ResNet`  -- LoFTR-style stride-16 CNN on the 256x256-resized crop -> (b,256,16,16).  Parameters /
+  state-dict names mirror the reference; the forward is hand-written HIP (gp_resize_bilinear_cm +
+  gp_conv2d_cm: implicit-GEMM f32-MFMA convolutions with folded eval-BN, residual and ReLU fused).
+  It is evaluated ONCE per crop (the reference recomputes it k=5 times, gigaPose.py:553).
 * `Regressor` / `ISTNet.inference*` -- gather + concat + two MLP heads run in libgigapose_hip.so
   (gp_ist_regress) for every (detection, hypothesis, patch) row at once.
 """
@@ -56,12 +55,90 @@ class ResNet(nn.Module):
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self._packed = None
+        self._bufs = None
+        self._resized = None
 
-    def forward(self, x):
+    # ------------------------------------------------------------------ torch fp32 reference
+    def reference_forward(self, x):
+        """Plain PyTorch statement of resnet.py:364-381 -- the fp32 reference the HIP path is tested
+        against (and what bench.py's CPU baseline times).  Not used by the product path."""
         x = F.interpolate(x, (self.input_size, self.input_size), mode="bilinear", align_corners=True)
         x = self.relu(self.bn1(self.conv1(x)))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.layer4_outconv(x)
+
+    # ------------------------------------------------------------------ HIP path
+    @torch.no_grad()
+    def _pack(self, device):
+        """Per conv: W^T (Kpad, Cout) k-major with k = ci*KH*KW + dy*KW + dx, and eval-BatchNorm folded
+        the way ATen folds it: alpha = gamma / sqrt(var + eps), beta = bias - mean * alpha."""
+        def conv(c, bn):
+            co, ci, kh, kw = c.weight.shape
+            k = ci * kh * kw
+            wt = torch.zeros((k + 15) // 16 * 16, co, dtype=torch.float32)
+            wt[:k] = c.weight.detach().float().reshape(co, k).t().cpu()
+            alpha = beta = None
+            if bn is not None:
+                invstd = 1.0 / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+                alpha = (invstd * bn.weight.detach().float()).to(device).contiguous()
+                beta = (bn.bias.detach().float() - bn.running_mean.detach().float() * invstd * bn.weight.detach().float()).to(device).contiguous()
+            return dict(wt=wt.to(device).contiguous(), alpha=alpha, beta=beta, cin=ci, cout=co, k=kh,
+                        stride=c.stride[0], pad=c.padding[0])
+
+        blocks = []
+        for li in range(1, 5):
+            for blk in getattr(self, f"layer{li}"):
+                ds = None if blk.downsample is None else conv(blk.downsample[0], blk.downsample[1])
+                blocks.append((conv(blk.conv1, blk.bn1), conv(blk.conv2, blk.bn2), ds))
+        self._packed = dict(device=device, stem=conv(self.conv1, self.bn1), blocks=blocks,
+                            out=conv(self.layer4_outconv, None))
+
+    def _conv(self, cv, x, y, B, H, W, residual=None, relu=True, nchw_out=False):
+        _lib.call("gp_conv2d_cm", _lib.ptr(x), _lib.ptr(cv["wt"]), _lib.ptr(y), _lib.ptr(cv["alpha"]),
+                  _lib.ptr(cv["beta"]), _lib.ptr(residual), _lib.i(cv["cin"]), _lib.i(B), _lib.i(H), _lib.i(W),
+                  _lib.i(cv["cout"]), _lib.i(cv["k"]), _lib.i(cv["k"]), _lib.i(cv["stride"]), _lib.i(cv["pad"]),
+                  _lib.i(1 if relu else 0), _lib.i(1 if nchw_out else 0), _lib.stream_ptr())
+        oh = (H + 2 * cv["pad"] - cv["k"]) // cv["stride"] + 1
+        return oh, (W + 2 * cv["pad"] - cv["k"]) // cv["stride"] + 1
+
+    @torch.no_grad()
+    def forward(self, x):
+        """(b,3,224,224) crops -> (b,descriptor,16,16).  HIP only: bilinear resize, 21 implicit-GEMM
+        convolutions with fused BN/residual/ReLU (gp_conv2d_cm), activations channel-major."""
+        if not x.is_cuda:
+            raise _lib.GigaPoseHipError("ResNet.forward runs on the GPU only (use reference_forward for a CPU check)")
+        dev = x.device
+        if getattr(self, "_packed", None) is None or self._packed["device"] != dev:
+            self._pack(dev)
+        pk = self._packed
+        B, S = x.shape[0], self.input_size
+        cdesc = pk["out"]["cout"]
+        out = torch.empty(B, cdesc, S // 16, S // 16, dtype=torch.float32, device=dev)
+        if B == 0:
+            return out
+        need = pk["stem"]["cout"] * B * (S // 2) * (S // 2)
+        if getattr(self, "_bufs", None) is None or self._bufs[0].numel() < need or self._bufs[0].device != dev:
+            self._bufs = [torch.empty(need, dtype=torch.float32, device=dev) for _ in range(4)]
+            self._resized = None
+        if self._resized is None or self._resized.numel() < 3 * B * S * S:
+            self._resized = torch.empty(3 * B * S * S, dtype=torch.float32, device=dev)
+        xin = x.contiguous().float()
+        _lib.call("gp_resize_bilinear_cm", _lib.ptr(xin), _lib.ptr(self._resized), _lib.i(B), _lib.i(3),
+                  _lib.i(x.shape[2]), _lib.i(x.shape[3]), _lib.i(S), _lib.stream_ptr())
+        cur, y1, sc, nxt = self._bufs
+        H, W = self._conv(pk["stem"], self._resized, cur, B, S, S)
+        for c1, c2, ds in pk["blocks"]:
+            oh, ow = self._conv(c1, cur, y1, B, H, W)                       # relu(bn1(conv1(x)))
+            short = cur
+            if ds is not None:
+                self._conv(ds, cur, sc, B, H, W, relu=False)                # bn(conv1x1(x))
+                short = sc
+            self._conv(c2, y1, nxt, B, oh, ow, residual=short)              # relu(shortcut + bn2(conv2(.)))
+            cur, nxt = nxt, cur
+            H, W = oh, ow
+        self._conv(pk["out"], cur, out, B, H, W, relu=False, nchw_out=True)
+        return out
 
 
 class Regressor(nn.Module):
@@ -98,6 +175,7 @@ class ISTNet(nn.Module):
 
     def load_state_dict(self, *a, **k):
         self._packed = None
+        self.backbone._packed = None
         return super().load_state_dict(*a, **k)
 
     @torch.no_grad()

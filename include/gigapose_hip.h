@@ -101,6 +101,23 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
                    const float* const* weights, int n_weights, float* workspace, size_t workspace_bytes,
                    float* out_features, int normalize, int stop_after_layers, void* stream);
 
+/* ---- IST backbone: ResNet.forward (src/models/network/resnet.py:364-381, BasicBlock :26-50) -- */
+
+/* F.interpolate(x, (S,S), mode="bilinear", align_corners=True) (resnet.py:366-368):
+ * images (B,C,IH,IW) NCHW -> out channel-major [C][B][S][S]. */
+int gp_resize_bilinear_cm(const float* images, float* out, int B, int C, int IH, int IW, int S, void* stream);
+
+/* Conv2d(bias=False) + eval BatchNorm + optional residual + optional ReLU on channel-major
+ * activations X [Cin][B][H][W] -> Y [Cout][B][OH][OW] (or NCHW (B,Cout,OH,OW) when nchw_out):
+ *   y = relu( residual + (conv(x) * alpha[co] + beta[co]) ),   alpha = gamma/sqrt(var+eps),
+ *   beta = bias - mean*alpha (NULL alpha/beta = no BN; NULL residual = none).
+ * Wt: (Kpad, Cout), row k = ci*KH*KW + dy*KW + dx, Kpad = round_up(Cin*KH*KW, 16), extra rows zero.
+ * Implicit GEMM on the f32 matrix core; accumulation = sequential fmaf over k.
+ * Requires Cout % 64 == 0 and B*OH*OW % 256 == 0. */
+int gp_conv2d_cm(const float* X, const float* Wt, float* Y, const float* alpha, const float* beta,
+                 const float* residual, int Cin, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                 int relu, int nchw_out, void* stream);
+
 /* ---- IST regressor: ISTNet.inference (src/models/network/ist_net.py:97-120) ----------------- */
 
 size_t gp_ist_workspace_bytes(int B, int k, int D, int H);

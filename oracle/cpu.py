@@ -212,3 +212,20 @@ def recover(labels, tar_K, tar_M, id_src, pred_M, tmpl_K, tmpl_M, tmpl_pose):
                          _p(_f32(tmpl_K)), _p(_f32(tmpl_M)), _p(_f32(tmpl_pose)), ctypes.c_int(B),
                          ctypes.c_int(N), ctypes.c_int(k), _p(out))
     return out
+
+
+def conv2d_cm(X, W, alpha=None, beta=None, res=None, stride=1, pad=0, relu=False):
+    """Channel-major conv + folded BN + residual + ReLU (gp_conv.hip order). X (Cin,B,H,W), W torch layout."""
+    X, W = _f32(X), _f32(W)
+    Cin, B, H, Wd = X.shape
+    Cout, _, KH, KW = W.shape
+    OH, OW = (H + 2 * pad - KH) // stride + 1, (Wd + 2 * pad - KW) // stride + 1
+    Y = np.empty((Cout, B, OH, OW), np.float32)
+    a = None if alpha is None else _f32(alpha)
+    bt = None if beta is None else _f32(beta)
+    r = None if res is None else _f32(res)
+    lib().oracle_conv2d_cm(_p(X), _p(W), _p(Y), _p(a) if a is not None else None, _p(bt) if bt is not None else None,
+                           _p(r) if r is not None else None, ctypes.c_int(Cin), ctypes.c_int(B), ctypes.c_int(H),
+                           ctypes.c_int(Wd), ctypes.c_int(Cout), ctypes.c_int(KH), ctypes.c_int(KW), ctypes.c_int(stride),
+                           ctypes.c_int(pad), ctypes.c_int(1 if relu else 0))
+    return Y

@@ -385,3 +385,39 @@ void oracle_recover(const int32_t* labels, const float* tar_K, const float* tar_
         o[12] = tP[12]; o[13] = tP[13]; o[14] = tP[14]; o[15] = tP[15];
     }
 }
+
+/* ------------------------------------------------------------------------------------
+ * Conv2d(bias=False) + folded eval-BatchNorm + residual + ReLU on channel-major activations,
+ * restating BasicBlock / ResNet stages (reference resnet.py:26-50, 364-381) with the fixed
+ * accumulation order of gp_conv.hip: fmaf chain over k = (ci, dy, dx) ascending, zero padding
+ * contributes fmaf(w, 0, acc).  X [Cin][B][H][W], W torch layout (Cout,Cin,KH,KW),
+ * Y [Cout][B][OH][OW].
+ * ---------------------------------------------------------------------------------- */
+void oracle_conv2d_cm(const float* X, const float* Wt, float* Y, const float* alpha, const float* beta,
+                      const float* res, int Cin, int B, int H, int W, int Cout, int KH, int KW, int stride,
+                      int pad, int relu)
+{
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    const size_t npix = (size_t)B * OH * OW;
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int co = 0; co < Cout; ++co)
+        for (int b = 0; b < B; ++b)
+            for (int oy = 0; oy < OH; ++oy)
+                for (int ox = 0; ox < OW; ++ox) {
+                    float acc = 0.f;
+                    for (int ci = 0; ci < Cin; ++ci)
+                        for (int dy = 0; dy < KH; ++dy)
+                            for (int dx = 0; dx < KW; ++dx) {
+                                int iy = oy * stride - pad + dy, ix = ox * stride - pad + dx;
+                                float x = (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                                              ? X[(((size_t)ci * B + b) * H + iy) * W + ix] : 0.f;
+                                acc = fmaf(Wt[(((size_t)co * Cin + ci) * KH + dy) * KW + dx], x, acc);
+                            }
+                    size_t o = (size_t)co * npix + ((size_t)b * OH + oy) * OW + ox;
+                    float v = acc;
+                    if (alpha) v = v * alpha[co] + beta[co];
+                    if (res) v = res[o] + v;
+                    if (relu) v = fmaxf(v, 0.f);
+                    Y[o] = v;
+                }
+}

@@ -13,7 +13,10 @@ import math
 
 import numpy as np
 
-_erf = np.vectorize(math.erf, otypes=[np.float64])
+try:
+    from scipy.special import erf as _erf
+except Exception:  # pragma: no cover
+    _erf = np.vectorize(math.erf, otypes=[np.float64])
 
 
 def _ln(x, g, b, eps=1e-6):

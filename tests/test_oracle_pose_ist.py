@@ -39,7 +39,7 @@ def test_resnet_and_mlp_oracle_vs_reference_golden(golden_dir):
     net = build_ist(101)
     tmpl, _ = syn.template_images(102, 2)
     with torch.no_grad():
-        feat = net.forward_by_chunk(torch.from_numpy(tmpl)).numpy()
+        feat = net.backbone.reference_forward(torch.from_numpy(tmpl)).numpy()  # torch fp32 statement of the HIP path
     np.testing.assert_allclose(feat, g["resnet_feat"], rtol=1e-4, atol=1e-3)  # |feat| ~ 20
     rs = np.random.RandomState(103)
     src_feat = rs.standard_normal((3, 256, 16, 16)).astype(np.float32)

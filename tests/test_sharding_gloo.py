@@ -1,0 +1,100 @@
+"""CPU, world_size 2 (gloo): the template-sharding exchange + merge of gigapose_amd/sharding.py
+reproduces the unsharded top-k exactly.  Per-shard match results come from the CPU oracle (test
+infrastructure); what is under test is the product's pack / all-gather / merge host logic."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gigapose_amd import sharding
+from gigapose_amd import synthetic as syn
+from oracle import cpu as oracle
+
+
+def test_shard_bounds_cover_and_balance():
+    for n, w in [(162, 8), (162, 2), (7, 3), (5, 5), (6480, 8)]:
+        b = [sharding.shard_bounds(n, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1
+    assert [hi - lo for lo, hi in [sharding.shard_bounds(162, 8, r) for r in range(8)]].count(20) == 6
+
+
+def test_pack_unpack_roundtrip_and_merge_order():
+    rs = np.random.RandomState(0)
+    B, k = 3, 5
+    ids = torch.from_numpy(rs.randint(0, 1000, (B, k)).astype(np.int64))
+    sc = torch.from_numpy(rs.rand(B, k).astype(np.float32))
+    ridx = torch.from_numpy(rs.randint(0, 256, (B, k, 256)).astype(np.uint8))
+    rsc = torch.from_numpy(rs.rand(B, k, 256).astype(np.float32))
+    rma = torch.from_numpy((rs.rand(B, k, 256) > 0.5).astype(np.float32))
+    rows = sharding.pack_candidates(ids, sc, ridx, rsc, rma)
+    assert rows.shape == (B, k, sharding.REC_BYTES) and rows.dtype == torch.uint8
+    for a, b in zip(sharding.unpack_candidates(rows), (ids, sc, ridx, rsc, rma)):
+        assert torch.equal(a, b)
+    # ties: equal scores -> lower global id first (gp_topk's rule)
+    ids = torch.tensor([[40, 3, 17, 8, 25, 1]])
+    sc = torch.tensor([[0.5, 0.0, 0.5, 0.0, 0.7, 0.0]])
+    pos = sharding.merge_topk(ids, sc, 5)
+    assert torch.gather(ids, 1, pos).tolist() == [[25, 17, 40, 1, 3]]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, k, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        O, N, C = case["src_feats"].shape[:3]
+        B_all = case["tar_feat"].shape[0]
+        n_own = B_all // world
+        lo, hi = sharding.shard_bounds(N, world, rank)
+        # exchange #1: every rank contributes its own crops' normalised features / masks / labels
+        own = slice(rank * n_own, (rank + 1) * n_own)
+        q_own = torch.from_numpy(oracle.l2norm_cp(case["tar_feat"][own].reshape(n_own, C, 256)))
+        q = sharding.all_gather_cat(q_own).numpy()
+        qm = sharding.all_gather_cat(torch.from_numpy(oracle.patch_mask(case["tar_mask"][own]))).numpy()
+        labels = sharding.all_gather_cat(torch.from_numpy(case["labels"][own].astype(np.int32))).numpy()
+        bank = oracle.l2norm_cp(case["src_feats"][:, lo:hi].reshape(O, hi - lo, C, 256))
+        idx, sc, ma, avg = oracle.match(q, bank, qm, oracle.patch_mask(case["src_masks"][:, lo:hi]), labels)
+        ids, score = oracle.topk(avg, k)
+        bsel = np.arange(B_all)[:, None]
+        rows = sharding.pack_candidates(torch.from_numpy(ids.astype(np.int64) + lo), torch.from_numpy(score),
+                                        torch.from_numpy(idx[bsel, ids]), torch.from_numpy(sc[bsel, ids]),
+                                        torch.from_numpy(ma[bsel, ids]))
+        gid, gsc, ridx, rsc, rma = sharding.exchange_and_merge(rows, n_own, k, rank)  # exchange #2
+        ret[rank] = dict(id=gid.numpy(), sc=gsc.numpy(), ridx=ridx.numpy(), rsc=rsc.numpy(), rma=rma.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_exchange_equals_unsharded_world2():
+    world, k = 2, 5
+    case = syn.matcher_case(seed=77, B=4, O=2, N=11, C=32)  # 11 templates -> shards of 6 and 5
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), case, k, ret), nprocs=world, join=True)
+    full = oracle.local_similarity_test(case["src_feats"], case["tar_feat"], case["src_masks"], case["tar_mask"],
+                                        case["labels"], k)
+    for rank in range(world):
+        own = slice(rank * 2, rank * 2 + 2)
+        r = ret[rank]
+        np.testing.assert_array_equal(r["id"], full["id_src"][own])
+        np.testing.assert_array_equal(r["sc"].view(np.uint32), full["score_src"][own].view(np.uint32))
+        np.testing.assert_array_equal(r["rsc"].view(np.uint32), full["score_pts"][own].view(np.uint32))
+        bsel = np.arange(4)[own][:, None]
+        np.testing.assert_array_equal(r["ridx"], full["idx_t2s"][bsel, full["id_src"][own]])
+        np.testing.assert_array_equal(r["rma"], full["mask_all"][bsel, full["id_src"][own]])

@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--mode", default="auto", choices=["auto", "sharded", "replicas"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run the IST backbone on the main stream")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -109,6 +110,7 @@ def main():
     model.set_template_data("syn")  # onboarding: excluded from the timed region (reference gigaPose.py:396-398)
     q = tset.crops(1000 + rank, args.batch, dev)
     model.pose_recovery["syn"].check_asserts = False  # no host sync inside the timed loop
+    model.overlap_ist = not args.no_overlap
 
     def step():
         return model.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
@@ -164,7 +166,7 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: {args.variant} random-init, {args.objects} object(s) x {args.templates} templates, "
                                f"batch={args.batch} crops per GPU, k={args.k}, full path ViT->match->IST->RANSAC->pose",
                    "global_batch": world * args.batch, "parallelism": "single" if world == 1 else f"{mode}{world}",
-                   "ist_backbone": "MIOpen via PyTorch-ROCm (round 1)"},
+                   "streams": "ViT+match on stream 0, IST backbone on stream 1" if model.overlap_ist else "single stream"},
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:

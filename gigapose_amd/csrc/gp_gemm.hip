@@ -31,7 +31,7 @@ __device__ __forceinline__ float gelu_erf(float x)
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kmajor_kernel(
+__global__ __launch_bounds__(256, 4) void gemm_kmajor_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* D,
     int ldd, int tiles_i, int tiles_j, int K, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* res /* may alias D (in-place residual) */, int ldr)

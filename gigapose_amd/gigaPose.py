@@ -69,6 +69,8 @@ class GigaPose(_Base):
         self.test_dataset_name = None
         self.last_predictions = None  # full (unfiltered) predictions of the last eval_retrieval call
         self.template_shard = None    # (rank, world, group) when the template bank is sharded
+        self.overlap_ist = True       # run the IST backbone on a side stream, concurrently with ViT + matching
+        self._side_stream = None
 
     def enable_template_sharding(self, group=None):
         """Shard the template bank over the ranks of `group` (gigapose_amd/sharding.py).  Call
@@ -121,12 +123,27 @@ class GigaPose(_Base):
         bank = self.match_banks[dataset_name]
         template_data = self.template_datas[dataset_name]
         labels0 = (labels.to(tar_img.device) - 1).to(torch.int32).contiguous()
+        side = None
+        if self.overlap_ist and tar_img.is_cuda:
+            # IST backbone on a second HIP stream: both chains are matrix-core bound, the overlap fills
+            # the partial last wave of workgroups ("tail") of each other's launches
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=tar_img.device)
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                tar_ist = self.ist_net.forward_by_chunk(tar_img)                 # stage 4a: IST backbone (once)
         tar_ae = self.ae_net(tar_img)                                            # stage 1: ViT features
         if self.template_shard is None:
             pred = self.testing_metric.test_bank(bank, tar_ae, tar_mask, labels0)  # stage 3: matching
         else:
             pred = bank.test_bank(tar_ae, tar_mask, labels0)                      # sharded bank + all-gathers
-        tar_ist = self.ist_net.forward_by_chunk(tar_img)                         # stage 4a: IST backbone (once)
+        if side is None:
+            tar_ist = self.ist_net.forward_by_chunk(tar_img)                     # stage 4a: IST backbone (once)
+        else:
+            torch.cuda.current_stream().wait_stream(side)
+            tar_ist.record_stream(torch.cuda.current_stream())
         rel_scale, rel_inplane = self.ist_net.regress_bank(template_data.ist_features, labels0, pred.id_src,
                                                            tar_ist, pred.src_pts, pred.tar_pts)
         pred.register_tensor("relScale", rel_scale)

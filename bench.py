@@ -118,23 +118,48 @@ def main():
     for _ in range(args.warmup):
         step()
     lib = _lib.lib()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    lib.gp_prof_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pred = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    kinds = 8
-    ms = (ctypes.c_double * kinds)()
-    work = (ctypes.c_double * kinds)()
-    cnt = (ctypes.c_longlong * kinds)()
-    nk = lib.gp_prof_end(kinds, ms, work, cnt)
     lib.gp_prof_kind_name.restype = ctypes.c_char_p
+    kinds = 8
+
+    def timed(steps, profile):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if profile:
+            lib.gp_prof_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        kern = {}
+        if profile:
+            ms = (ctypes.c_double * kinds)()
+            work = (ctypes.c_double * kinds)()
+            cnt = (ctypes.c_longlong * kinds)()
+            nk = lib.gp_prof_end(kinds, ms, work, cnt)
+            for i in range(nk):
+                if cnt[i]:
+                    name = lib.gp_prof_kind_name(i).decode()
+                    unit = "GB/s" if name == "layernorm" else "TFLOP/s"
+                    kern[name] = {"ms_per_step": round(ms[i] / steps, 3), "launches_per_step": cnt[i] // steps,
+                                  "avg_launch_us": round(1e3 * ms[i] / cnt[i], 2),
+                                  unit: round(work[i] / ms[i] / (1e6 if name == "layernorm" else 1e9), 2)}
+        return dt, kern
+
+    # (1) THE timed region: K steps, barrier + synchronize on both sides; the library records HIP events
+    #     around every kernel launch on its launch stream (the IST chain runs on a second stream).
+    dt, kern_timed = timed(args.steps, profile=True)
+    # (2) serialized replay of the same K steps (single stream) with the same event instrumentation:
+    #     per-kernel durations free of cross-stream sharing -> the roofline figure of each kernel family
+    if model.overlap_ist:
+        model.overlap_ist = False
+        dt_serial, kern = timed(args.steps, profile=True)
+        model.overlap_ist = True
+    else:
+        dt_serial, kern = dt, kern_timed
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -145,19 +170,16 @@ def main():
         return
 
     crops = world * args.batch * args.steps
-    kern = {}
-    for i in range(nk):
-        if cnt[i]:
-            name = lib.gp_prof_kind_name(i).decode()
-            kern[name] = {"ms_per_step": round(ms[i] / args.steps, 3), "launches_per_step": cnt[i] // args.steps,
-                          "avg_launch_us": round(1e3 * ms[i] / cnt[i], 2),
-                          ("GB/s" if name == "layernorm" else "TFLOP/s"): round(work[i] / ms[i] / (1e6 if name == "layernorm" else 1e9), 2)}
     g = kern.get("gemm_kmajor", {})
     achieved = g.get("TFLOP/s", 0.0)
     roofline = {"kernel": "gemm_kmajor_kernel (ViT linear layers + IST MLP; f32-input MFMA 32x32x2)", "bound": "mfma",
                 "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "share_of_step": round(g.get("ms_per_step", 0.0) / (1e3 * dt / args.steps), 3), "kernels": kern}
+                "share_of_step": round(g.get("ms_per_step", 0.0) / (1e3 * dt_serial / args.steps), 3),
+                "measured": "HIP events on the launch stream around every launch, over a single-stream replay of the "
+                            "timed steps (kernels_timed_region: same events inside the timed, two-stream region)",
+                "serial_ms_per_step": round(1e3 * dt_serial / args.steps, 3), "kernels": kern,
+                "kernels_timed_region": {k: v["ms_per_step"] for k, v in kern_timed.items()}}
     out = {
         "metric": "query-crops/sec (ViT feat + template NN + 4DoF regress), 162 templates, 1/2/4/8 GPU",
         "value": round(crops / dt, 2), "unit": "query-crops/sec", "n_gpus": world, "steps": args.steps,

@@ -62,9 +62,13 @@ __global__ __launch_bounds__(256, 4) void gemm_kmajor_kernel(
                 if (EPI == EPI_BIAS_J) v = v + bias[j];
                 if (EPI == EPI_BIAS_I_GELU) v = gelu_erf(v);
                 if (EPI == EPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
-                if (EPI == EPI_BIAS_I_SCALE_RES) v = res[(size_t)i * ldr + j] + scale[i] * v;
-                D[(size_t)i * ldd + j] = v;
+                // 32-bit element offsets (I * ld < 2^31 is checked by the launcher): half the address VGPRs
+                if (EPI == EPI_BIAS_I_SCALE_RES) v = res[(unsigned)i * (unsigned)ldr + (unsigned)j] + scale[i] * v;
+                D[(unsigned)i * (unsigned)ldd + (unsigned)j] = v;
             }
+            // keep the next tile's residual loads below this tile's stores: without the fence hipcc
+            // hoists all 64 loads first (+64 VGPRs -> half the occupancy for the residual epilogue)
+            if (EPI == EPI_BIAS_I_SCALE_RES) __builtin_amdgcn_sched_barrier(0);
         }
 }
 
@@ -90,6 +94,8 @@ int gp_gemm_launch(const float* A, int lda, const float* B, int ldb, float* D, i
                "gp_gemm_kmajor: I=%d, J=%d must be multiples of 128 and K=%d of 16 (pad the operands)", I, J, K);
     GP_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= I && ldb >= J && ldd >= J,
                "gp_gemm_kmajor: bad leading dimensions lda=%d ldb=%d ldd=%d", lda, ldb, ldd);
+    GP_REQUIRE((long long)I * ldd < (1ll << 31) && (long long)I * (ldr > 0 ? ldr : 1) < (1ll << 31),
+               "gp_gemm_kmajor: output larger than 2^31 elements");
     GP_REQUIRE(A && B && D, "gp_gemm_kmajor: null pointer");
     GP_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "gp_gemm_kmajor: operands must be 16-byte aligned");
     GpProfScope prof(GP_PROF_GEMM, 2.0 * I * J * K, st);

@@ -52,11 +52,17 @@ __device__ __forceinline__ void candidate(const RansacSmem& s, int i, float& m00
     t1 = s.ty[i] - a1;
 }
 
+// apply_affine on the validation points (lib3d/torch.py:82-88) is an einsum -> torch.bmm over
+// (3x3)x(3x(n-1)).  Two query patches matched to the SAME template patch give an error of EXACTLY
+// 14 px in exact arithmetic, so `error <= 14` is decided by the rounding of this product and the
+// reference's result depends on which bmm path torch takes: its native kernel (plain mul/add) when
+// 3*(n-1)*3 < 400, i.e. n <= 45, and MKL sgemm (fused multiply-add over c) for n >= 46.  Both are
+// reproduced here bit-for-bit (verified against torch 2.10 CPU, tests/golden/pose.npz, e2e.npz).
 __device__ __forceinline__ bool is_inlier(const RansacSmem& s, int j, float m00, float m01, float m10, float m11,
-                                          float t0, float t1, float thr)
+                                          float t0, float t1, float thr, bool fused)
 {
-    const float v0 = (m00 * s.sx[j] + m01 * s.sy[j]) + t0;  // apply_affine (lib3d/torch.py:82-88)
-    const float v1 = (m10 * s.sx[j] + m11 * s.sy[j]) + t1;
+    const float v0 = fused ? __builtin_fmaf(m01, s.sy[j], m00 * s.sx[j]) + t0 : (m00 * s.sx[j] + m01 * s.sy[j]) + t0;
+    const float v1 = fused ? __builtin_fmaf(m11, s.sy[j], m10 * s.sx[j]) + t1 : (m10 * s.sx[j] + m11 * s.sy[j]) + t1;
     const float d0 = s.tx[j] - v0, d1 = s.ty[j] - v1;
     return __builtin_sqrtf(d0 * d0 + d1 * d1) <= thr;       // torch.norm(dim=2) <= pixel_threshold
 }
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256) void ransac_kernel(
         float m00, m01, m10, m11, t0, t1;
         candidate(s, p, m00, m01, m10, m11, t0, t1);
         for (int j = 0; j < n; ++j)
-            if (j != p && is_inlier(s, j, m00, m01, m10, m11, t0, t1, thr)) ++cnt;
+            if (j != p && is_inlier(s, j, m00, m01, m10, m11, t0, t1, thr, n >= 46)) ++cnt;
         s.count[p] = cnt;
     }
     __syncthreads();
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256) void ransac_kernel(
         failed[r] = (s.best_count == 0) ? 1 : 0;  // failed = score == 0 (ransac.py:100)
     }
     // inliers of the winner, in ascending order, packed at the front (ransac.py:103-104, 160-163)
-    const bool inl = (p < n) && (p != best) && is_inlier(s, p, m00, m01, m10, m11, t0, t1, thr);
+    const bool inl = (p < n) && (p != best) && is_inlier(s, p, m00, m01, m10, m11, t0, t1, thr, n >= 46);
     int tot;
     const int q = block_compact(inl, s.wave_n, &tot);
     if (inl) {

@@ -207,6 +207,33 @@ def fill_state_dict(module, seed):
     return module
 
 
+def many_to_one_case(seed, R):
+    """RANSAC stress case: neighbouring query patches matched to the SAME template patch, so many
+    errors are exactly 14 px in exact arithmetic and the `<= 14` test is decided by rounding (see
+    gp_pose.hip).  Problem r has n_r valid correspondences, n_r straddling torch's bmm switch at 46."""
+    rs = np.random.RandomState(seed)
+    sizes = [2, 9, 44, 45, 46, 47, 90, 200, 256][:R] + [int(rs.randint(2, 257)) for _ in range(max(0, R - 9))]
+    src_pts = -np.ones((R, P, 2), np.int64)
+    tar_pts = -np.ones((R, P, 2), np.int64)
+    rel_scale = np.full((R, P), -1000, np.float32)
+    rel_inplane = np.full((R, P, 2), -1000, np.float32)
+    for r, n in enumerate(sizes):
+        pos = np.sort(rs.choice(P, n, replace=False))
+        prev = None
+        sat = r % 2 == 0  # saturated tanh outputs (+-1), as random-init nets produce
+        for i, p in enumerate(pos):
+            tar_pts[r, p] = (p % G, p // G)
+            if prev is not None and i % 2 == 1:
+                src_pts[r, p] = prev
+            else:
+                src_pts[r, p] = rs.randint(0, G, 2)
+            prev = src_pts[r, p].copy()
+            rel_scale[r, p] = rs.uniform(0.3, 2.0)
+            ang = rs.uniform(-3, 3)
+            rel_inplane[r, p] = (1.0, -1.0) if sat else (np.cos(ang), np.sin(ang))
+    return dict(src_pts=src_pts, tar_pts=tar_pts, rel_scale=rel_scale, rel_inplane=rel_inplane)
+
+
 def correspondences_case(seed, B, k):
     """Synthetic post-matcher state for the IST / RANSAC / recovery stages: (x,y) correspondences
     with -1 padding that mostly follow one similarity per (b,k) plus outliers; IST features random.

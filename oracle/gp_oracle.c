@@ -272,10 +272,13 @@ static cand_t make_cand(const float* sx, const float* sy, const float* tx, const
     c.t1 = ty[i] - a1;
     return c;
 }
-static int cand_inlier(const cand_t* c, float sx, float sy, float tx, float ty, float thr)
+/* `fused`: the reference's einsum->bmm takes torch's native kernel (plain mul/add) for n <= 45
+ * correspondences and MKL sgemm (fma over the 3-term contraction) for n >= 46; errors of exactly
+ * 14 px (two query patches on one template patch) make the inlier test depend on it. */
+static int cand_inlier(const cand_t* c, float sx, float sy, float tx, float ty, float thr, int fused)
 {
-    float v0 = (c->m00 * sx + c->m01 * sy) + c->t0;
-    float v1 = (c->m10 * sx + c->m11 * sy) + c->t1;
+    float v0 = fused ? fmaf(c->m01, sy, c->m00 * sx) + c->t0 : (c->m00 * sx + c->m01 * sy) + c->t0;
+    float v1 = fused ? fmaf(c->m11, sy, c->m10 * sx) + c->t1 : (c->m10 * sx + c->m11 * sy) + c->t1;
     float d0 = tx - v0, d1 = ty - v1;
     return sqrtf(d0 * d0 + d1 * d1) <= thr;
 }
@@ -310,7 +313,7 @@ void oracle_ransac(const int64_t* src_pts, const int64_t* tar_pts, const float* 
         for (int i = 0; i < n; ++i) {
             cand_t c = make_cand(sx, sy, tx, ty, sc, cs, sn, i);
             int cnt = 0;
-            for (int j = 0; j < n; ++j) if (j != i && cand_inlier(&c, sx[j], sy[j], tx[j], ty[j], thr)) ++cnt;
+            for (int j = 0; j < n; ++j) if (j != i && cand_inlier(&c, sx[j], sy[j], tx[j], ty[j], thr, n >= 46)) ++cnt;
             if (cnt > bc) { bc = cnt; best = i; }                   /* first max (:99) */
         }
         cand_t c = make_cand(sx, sy, tx, ty, sc, cs, sn, best);
@@ -319,7 +322,7 @@ void oracle_ransac(const int64_t* src_pts, const int64_t* tar_pts, const float* 
         failed[r] = (bc == 0);                                      /* :100 */
         int q = 0;
         for (int j = 0; j < n; ++j) {
-            if (j == best || !cand_inlier(&c, sx[j], sy[j], tx[j], ty[j], thr)) continue;
+            if (j == best || !cand_inlier(&c, sx[j], sy[j], tx[j], ty[j], thr, n >= 46)) continue;
             size_t o = (size_t)r * P + q, s = (size_t)r * P + orig[j];
             inl_src[2 * o] = src_pts[2 * s]; inl_src[2 * o + 1] = src_pts[2 * s + 1];
             inl_tar[2 * o] = tar_pts[2 * s]; inl_tar[2 * o + 1] = tar_pts[2 * s + 1];

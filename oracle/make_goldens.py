@@ -111,6 +111,18 @@ def gen_pose():
                         ransac_src_pts=pred.ransac_src_pts.numpy().astype(np.int16),
                         ransac_tar_pts=pred.ransac_tar_pts.numpy().astype(np.int16), poses=poses.numpy())
     print("pose: inlier counts", pred.ransac_scores.sum(-1).tolist(), "failed", pred.idx_failed.tolist())
+    # boundary case: errors of exactly 14 px, problem sizes on both sides of torch's bmm switch (n = 46)
+    from src.models.ransac import RANSAC
+
+    case = syn.many_to_one_case(211, 14)
+    batch = PandasTensorCollection(infos=pd.DataFrame(), src_pts=torch.from_numpy(case["src_pts"]),
+                                   tar_pts=torch.from_numpy(case["tar_pts"]), relScale=torch.from_numpy(case["rel_scale"]),
+                                   relInplane=torch.from_numpy(case["rel_inplane"]))
+    Ms, failed, out = RANSAC(pixel_threshold=14)(batch)
+    np.savez_compressed(os.path.join(GOLD, "pose_boundary.npz"), M=Ms.numpy(), idx_failed=failed.numpy(),
+                        scores=out.scores.numpy().astype(np.int8), src_pts=out.src_pts.numpy().astype(np.int16),
+                        tar_pts=out.tar_pts.numpy().astype(np.int16))
+    print("pose_boundary: sizes", (case["src_pts"][..., 0] >= 0).sum(-1).tolist(), "inliers", out.scores.sum(-1).tolist())
 
 
 class _FakeTemplates:

@@ -154,7 +154,7 @@ def test_voting_and_recovery_reproduce_reference_exactly_given_its_regressions(g
     M, failed, isrc, itar, isc = rec.ransac.run(t(g["src_pts"].astype(np.int64)), t(g["tar_pts"].astype(np.int64)),
                                                 t(g["relScale"]), t(g["relInplane"]))
     np.testing.assert_array_equal((isc.sum(-1) / 256).cpu().numpy(), g["all_scores"])
-    np.testing.assert_allclose(M.cpu().numpy(), g["M"], rtol=1e-5, atol=2e-4)
+    np.testing.assert_array_equal(M.cpu().numpy().view(np.uint32), g["M"].view(np.uint32))  # bit-exact M
     poses = rec.forward_recovery(torch.from_numpy(q["labels"]), t(q["tar_K"]), t(q["tar_M"]), t(g["id_src"]), M).cpu().numpy()
     terr, rerr = pose_rel_err(poses, g["all_poses"])
     assert terr.max() < 1e-4 and rerr.max() < 1e-4, (terr.max(), rerr.max())  # north-star tolerance
@@ -177,7 +177,7 @@ def test_ist_outputs_as_close_to_f64_truth_as_the_reference(golden_dir):
         tar64 = ist64.backbone.reference_forward(torch.from_numpy(q["tar_img"]).double()).reshape(E2E["B"], 256, 256)
         tmpl64 = [ist64.backbone.reference_forward(it.rgb.double()).reshape(-1, 256, 256) for it in items]
     # evaluate the scale head in f64 for the golden's hypothesis order
-    errs_mine, errs_ref = [], []
+    errs_mine, errs_ref, mags = [], [], []
     mine_ids = p.id_src.cpu().numpy()
     for b in range(E2E["B"]):
         for j in range(E2E["k"]):
@@ -191,9 +191,12 @@ def test_ist_outputs_as_close_to_f64_truth_as_the_reference(golden_dir):
             feats = torch.cat([tar64[b][:, ti].t(), tmpl64[int(q["labels"][b]) - 1][tid][:, si].t()], dim=1)
             with torch.no_grad():
                 truth = ist64.regressor.scale_predictor(feats)[:, 0].numpy()
-            errs_ref.append(np.abs(g["relScale"][b, j][ok] - truth) / np.abs(truth).clip(1e-3))
-            errs_mine.append(np.abs(p.relScale[b, jm].cpu().numpy()[ok] - truth) / np.abs(truth).clip(1e-3))
-    em, er = np.concatenate(errs_mine), np.concatenate(errs_ref)
-    print("relScale relative error vs f64 truth: HIP median %.2e max %.2e | reference(f32 CPU) median %.2e max %.2e"
-          % (np.median(em), em.max(), np.median(er), er.max()))
-    assert np.median(em) <= 3 * np.median(er) + 1e-6 and em.max() <= 5 * er.max() + 1e-5
+            errs_ref.append(np.abs(g["relScale"][b, j][ok] - truth))
+            errs_mine.append(np.abs(p.relScale[b, jm].cpu().numpy()[ok] - truth))
+            mags.append(np.abs(truth))
+    mag = np.median(np.concatenate(mags))
+    em, er = np.concatenate(errs_mine) / mag, np.concatenate(errs_ref) / mag
+    print("relScale error vs f64 truth (relative to median |scale| = %.3f): HIP median %.2e p99 %.2e | "
+          "reference (f32 CPU) median %.2e p99 %.2e" % (mag, np.median(em), np.percentile(em, 99), np.median(er),
+                                                        np.percentile(er, 99)))
+    assert np.median(em) <= 3 * np.median(er) + 1e-6 and np.percentile(em, 99) <= 5 * np.percentile(er, 99) + 1e-5

@@ -36,6 +36,20 @@ def test_ransac_bit_exact_vs_oracle_and_golden(golden_dir):
     np.testing.assert_allclose(M.cpu().numpy(), g["M"], rtol=1e-5, atol=2e-4)
 
 
+def test_ransac_boundary_case_bit_exact_vs_reference_golden(golden_dir):
+    """Exactly-14-px errors, n on both sides of torch's bmm switch: HIP == reference, M included."""
+    from gigapose_amd.poses import RANSAC
+
+    g = np.load(os.path.join(golden_dir, "pose_boundary.npz"))
+    case = syn.many_to_one_case(211, 14)
+    M, failed, isrc, itar, isc = RANSAC(pixel_threshold=14).run(t(case["src_pts"]), t(case["tar_pts"]),
+                                                                 t(case["rel_scale"]), t(case["rel_inplane"]))
+    np.testing.assert_array_equal(isc.cpu().numpy(), g["scores"].astype(np.int64))
+    np.testing.assert_array_equal(isrc.cpu().numpy(), g["src_pts"].astype(np.int64))
+    np.testing.assert_array_equal(failed.cpu().numpy(), g["idx_failed"])
+    np.testing.assert_array_equal(M.cpu().numpy().view(np.uint32), g["M"].view(np.uint32))
+
+
 def test_ransac_full_width_and_reference_signature():
     """256 valid correspondences per problem (maximum size), and RANSAC.forward(batch) signature."""
     import pandas as pd

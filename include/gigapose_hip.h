@@ -114,6 +114,7 @@ int gp_resize_bilinear_cm(const float* images, float* out, int B, int C, int IH,
  * Wt: (Kpad, Cout), row k = ci*KH*KW + dy*KW + dx, Kpad = round_up(Cin*KH*KW, 16), extra rows zero.
  * Implicit GEMM on the f32 matrix core; accumulation = sequential fmaf over k.
  * Requires Cout % 64 == 0 and B*OH*OW % 256 == 0. */
+void gp_conv_set_direct(int on); /* test hook: 0 = always use the generic gather kernel (results identical) */
 int gp_conv2d_cm(const float* X, const float* Wt, float* Y, const float* alpha, const float* beta,
                  const float* residual, int Cin, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
                  int relu, int nchw_out, void* stream);

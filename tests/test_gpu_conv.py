@@ -32,7 +32,9 @@ def hip_conv(X, W, alpha, beta, res, stride, pad, relu, nchw=False):
 
 @pytest.mark.parametrize("cin,cout,k,stride,pad,hw,B,bn,res,relu", [
     (3, 128, 7, 2, 3, 64, 1, True, False, True),     # stem shape (K=147 -> padded 160)
-    (8, 64, 3, 1, 1, 16, 2, True, True, True),       # BasicBlock conv2 + residual
+    (8, 64, 3, 1, 1, 16, 2, True, True, True),       # BasicBlock conv2 + residual (direct kernel, 16x16 window)
+    (24, 128, 3, 1, 1, 32, 2, True, True, True),     # direct kernel, 32x8 window, 3 channel chunks, 2 co tiles
+    (16, 64, 3, 1, 1, 64, 1, True, False, True),     # direct kernel, several windows per image (halo borders)
     (16, 192, 3, 2, 1, 32, 1, True, False, True),    # strided block entry, Cout = 3*64
     (24, 64, 1, 2, 0, 32, 1, True, False, False),    # downsample 1x1 stride 2
     (32, 64, 1, 1, 0, 16, 1, False, False, False),   # layer4_outconv (no BN)
@@ -61,6 +63,15 @@ def test_conv_bit_exact_vs_oracle(cin, cout, k, stride, pad, hw, B, bn, res, rel
     if not res:
         nchw = hip_conv(X, W, alpha, beta, None, stride, pad, relu, nchw=True)
         np.testing.assert_array_equal(nchw, got.transpose(1, 0, 2, 3))
+    if k == 3 and stride == 1:  # the generic im2col-gather kernel must agree with the direct one bit-for-bit
+        from gigapose_amd import _lib
+
+        _lib.lib().gp_conv_set_direct(0)
+        try:
+            generic = hip_conv(X, W, alpha, beta, R, stride, pad, relu)
+        finally:
+            _lib.lib().gp_conv_set_direct(1)
+        np.testing.assert_array_equal(generic.view(np.uint32), got.view(np.uint32))
 
 
 def test_resize_matches_torch():

@@ -23,38 +23,43 @@ enum {
     EPI_BIAS_I_RELU = 5,       // relu(acc + bias[i])                          (IST MLP)
 };
 
-using GM = KMajor<2, 2, 2, 2, 16>;  // 128 x 128 block tile, 4 waves, 64 accumulators/lane
+using GM = KMajor<2, 2, 2, 2, 16>;  // main tile: 128 x 128, 4 waves, 64 accumulators/lane
+using GT = KMajor<1, 2, 1, 1, 16>;  // tail tile:  32 x 64, 2 waves (1/8 of a main tile's work)
 
 __device__ __forceinline__ float gelu_erf(float x)
 {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 4) void gemm_kmajor_kernel(
+// One kernel body for both tile shapes.  Columns [j_begin, j_begin + tiles_j * CFG::BN) are covered;
+// the per-output accumulation chain does not depend on the tiling, so main and tail tiles (and any
+// other split) give bit-identical results.
+template <int EPI, class CFG, int MINW>
+__global__ __launch_bounds__(CFG::NT, MINW) void gemm_kmajor_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* D,
-    int ldd, int tiles_i, int tiles_j, int K, const float* __restrict__ bias,
+    int ldd, int tiles_i, int tiles_j, int j_begin, int K, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* res /* may alias D (in-place residual) */, int ldr)
 {
-    __shared__ float smem[GM::LDS_FLOATS];
+    __shared__ float smem[CFG::LDS_FLOATS];
     const int q = xcd_chunked_tile(blockIdx.x, tiles_i * tiles_j);
     if (q < 0) return;
     // i fastest: the blocks of one XCD chunk share the B (activation) panel in that XCD's L2
     const int ti = q % tiles_i, tj = q / tiles_i;
-    const int i0 = ti * GM::BM, j0 = tj * GM::BN;
-    f32x16 acc[2][2];
-    GM::run(A + i0, lda, B + j0, ldb, K, smem, acc);
+    const int i0 = ti * CFG::BM, j0 = j_begin + tj * CFG::BN;
+    constexpr int MI = CFG::BM / 32 / CFG::WM_, NI = CFG::BN / 32 / CFG::WN_;
+    f32x16 acc[MI][NI];
+    CFG::run(A + i0, lda, B + j0, ldb, K, smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / CFG::WN_, wn = wave % CFG::WN_;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int j = j0 + wn * 64 + ni * 32 + (lane & 31);
+        for (int ni = 0; ni < NI; ++ni) {
+            const int j = j0 + wn * NI * 32 + ni * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = i0 + wm * 64 + mi * 32 + frag_row(r, lane);
+                const int i = i0 + wm * MI * 32 + mi * 32 + frag_row(r, lane);
                 float v = acc[mi][ni][r];
                 if (EPI == EPI_BIAS_I || EPI == EPI_BIAS_I_GELU || EPI == EPI_BIAS_I_SCALE_RES ||
                     EPI == EPI_BIAS_I_RELU)
@@ -66,19 +71,36 @@ __global__ __launch_bounds__(256, 4) void gemm_kmajor_kernel(
                 if (EPI == EPI_BIAS_I_SCALE_RES) v = res[(unsigned)i * (unsigned)ldr + (unsigned)j] + scale[i] * v;
                 D[(unsigned)i * (unsigned)ldd + (unsigned)j] = v;
             }
-            // keep the next tile's residual loads below this tile's stores: without the fence hipcc
-            // hoists all 64 loads first (+64 VGPRs -> half the occupancy for the residual epilogue)
+            // keep the next tile's residual loads below this tile's stores (register pressure)
             if (EPI == EPI_BIAS_I_SCALE_RES) __builtin_amdgcn_sched_barrier(0);
         }
 }
+
+// Residency of the main kernel: 4 workgroups per CU (<= 128 VGPR, 32 KiB LDS) x 256 CUs.  When the
+// tile count is just over a multiple of that (ViT-L at B=64: 8 x 129 = 1032 tiles on 1024 slots), the
+// last few main tiles would run alone after everything else has finished; instead the trailing j-tiles
+// are "peeled" into 32x64 tail tiles (8x more, 1/8 of the work each) that spread over the whole chip.
+constexpr int kResidentSlots = 1024;
+static bool g_tail_peel = true;
 
 template <int EPI>
 int launch(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J, int K,
            const float* bias, const float* scale, const float* res, int ldr, hipStream_t st)
 {
-    const int ti = I / GM::BM, tj = J / GM::BN;
-    hipLaunchKernelGGL(gemm_kmajor_kernel<EPI>, dim3(xcd_chunked_grid(ti * tj)), dim3(GM::NT), 0, st, A,
-                       lda, B, ldb, D, ldd, ti, tj, K, bias, scale, res, ldr);
+    const int ti = I / GM::BM;
+    int tj = J / GM::BN;
+    const int rem = (ti * tj) % kResidentSlots;
+    int peel = 0;  // number of trailing j-tiles handed to the tail kernel
+    if (g_tail_peel && ti * tj > kResidentSlots && rem > 0 && rem <= kResidentSlots / 4 && rem % ti == 0 && rem / ti < tj)
+        peel = rem / ti;
+    tj -= peel;
+    hipLaunchKernelGGL((gemm_kmajor_kernel<EPI, GM, 4>), dim3(xcd_chunked_grid(ti * tj)), dim3(GM::NT), 0, st, A, lda,
+                       B, ldb, D, ldd, ti, tj, 0, K, bias, scale, res, ldr);
+    if (peel) {
+        const int tti = I / GT::BM, ttj = peel * GM::BN / GT::BN;
+        hipLaunchKernelGGL((gemm_kmajor_kernel<EPI, GT, 2>), dim3(xcd_chunked_grid(tti * ttj)), dim3(GT::NT), 0, st, A,
+                           lda, B, ldb, D, ldd, tti, ttj, tj * GM::BN, K, bias, scale, res, ldr);
+    }
     return 0;
 }
 
@@ -166,6 +188,8 @@ int probe_launch(const float* A, int lda, const float* B, int ldb, float* D, int
     return hipGetLastError() == hipSuccess ? GP_OK : GP_ELAUNCH;
 }
 }  // namespace
+
+extern "C" void gp_gemm_set_tail_peel(int on) { g_tail_peel = on != 0; }
 
 extern "C" int gp_gemm_probe(int variant, const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I,
                              int J, int K, void* stream)

@@ -75,6 +75,7 @@ int gp_format_points(const uint8_t* rec_idx, const float* rec_mask, int rows, lo
  * epilogue: 0 none | 1 +bias[i] | 2 gelu_erf(+bias[i]) | 3 residual[i][j] + scale[i]*(acc+bias[i])
  *           (D may alias residual) | 4 +bias[j] | 5 relu(+bias[i]).
  * Requires I % 128 == 0, J % 128 == 0, K % 16 == 0, lda/ldb % 4 == 0, 16-byte aligned A/B. */
+void gp_gemm_set_tail_peel(int on); /* test hook: 0 disables the tail-tile split (results identical) */
 int gp_gemm_kmajor(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J,
                    int K, int epilogue, const float* bias, const float* scale, const float* residual,
                    int ldr, void* stream);

@@ -46,6 +46,30 @@ def test_gemm_bit_exact_vs_fmaf_chain(epi):
     np.testing.assert_allclose(got if epi == 0 else got, ref, rtol=1e-6)
 
 
+def test_gemm_tail_peel_is_bit_identical():
+    """ViT-L proj shape at B=64 (8 x 129 tiles on 1024 resident slots): the trailing j-tile is computed by
+    32x64 tail tiles; the result must not depend on the split."""
+    from gigapose_amd import _lib
+
+    rs = np.random.RandomState(7)
+    I, J, K = 1024, 129 * 128, 48
+    A = rs.standard_normal((K, I)).astype(np.float32)
+    B = rs.standard_normal((K, J)).astype(np.float32)
+    bias = rs.standard_normal(I).astype(np.float32)
+    scale = rs.standard_normal(I).astype(np.float32)
+    res = rs.standard_normal((I, J)).astype(np.float32)
+    peeled = hip_gemm(A, B, 3, bias, scale, res)
+    _lib.lib().gp_gemm_set_tail_peel(0)
+    try:
+        plain = hip_gemm(A, B, 3, bias, scale, res)
+    finally:
+        _lib.lib().gp_gemm_set_tail_peel(1)
+    np.testing.assert_array_equal(peeled.view(np.uint32), plain.view(np.uint32))
+    cols = np.r_[0:64, J - 200:J]  # oracle on the first columns and the peeled region
+    ref = oracle.gemm_kmajor(A, B[:, cols], 3, bias, scale, res[:, cols])
+    np.testing.assert_array_equal(peeled[:, cols].view(np.uint32), ref.view(np.uint32))
+
+
 def test_gemm_gelu_and_errors():
     from gigapose_amd import _lib
 

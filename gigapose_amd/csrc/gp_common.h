@@ -73,7 +73,7 @@ static inline int xcd_chunked_grid(int total) { return 8 * ((total + 7) / 8); }
 // Requirements: K % KS == 0, lda/ldb % 4 == 0, A/B 16-byte aligned, tile fully in bounds.
 // LDS needed: 2 * KS * (BM + BN) floats.
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int MI, int NI, int KS>
+template <int WM, int WN, int MI, int NI, int KS, bool PIPE = false>
 struct KMajor {
     static constexpr int WM_ = WM, WN_ = WN;
     static constexpr int BM = WM * MI * 32;
@@ -145,19 +145,42 @@ struct KMajor {
             if (s + 1 < nslab) gload(A, lda, B, ldb, (s + 1) * KS, tid, ra, rb);
             const float* cA = sA + buf * KS * BM;
             const float* cB = sB + buf * KS * BN;
+            if (!PIPE) {
 #pragma unroll
-            for (int kk = 0; kk < KS / 2; ++kk) {
-                const int k = 2 * kk + khalf;
-                float a[MI], b[NI];
+                for (int kk = 0; kk < KS / 2; ++kk) {
+                    const int k = 2 * kk + khalf;
+                    float a[MI], b[NI];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) a[mi] = cA[k * BM + arow + mi * 32];
+                    for (int mi = 0; mi < MI; ++mi) a[mi] = cA[k * BM + arow + mi * 32];
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) b[ni] = cB[k * BN + bcol + ni * 32];
+                    for (int ni = 0; ni < NI; ++ni) b[ni] = cB[k * BN + bcol + ni * 32];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+                    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                }
+            } else {  // operands of k-pair kk+1 are read from LDS before the MFMAs of k-pair kk issue
+                float a[2][MI], b[2][NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) a[0][mi] = cA[khalf * BM + arow + mi * 32];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) b[0][ni] = cB[khalf * BN + bcol + ni * 32];
+#pragma unroll
+                for (int kk = 0; kk < KS / 2; ++kk) {
+                    if (kk + 1 < KS / 2) {
+                        const int k = 2 * (kk + 1) + khalf;
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) a[(kk + 1) & 1][mi] = cA[k * BM + arow + mi * 32];
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) b[(kk + 1) & 1][ni] = cB[k * BN + bcol + ni * 32];
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][mi], b[kk & 1][ni], acc[mi][ni], 0, 0, 0);
+                }
             }
             if (s + 1 < nslab) swrite(sA, sB, buf ^ 1, tid, ra, rb);
             __syncthreads();

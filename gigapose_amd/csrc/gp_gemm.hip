@@ -23,7 +23,7 @@ enum {
     EPI_BIAS_I_RELU = 5,       // relu(acc + bias[i])                          (IST MLP)
 };
 
-using GM = KMajor<2, 2, 2, 2, 16>;  // main tile: 128 x 128, 4 waves, 64 accumulators/lane
+using GM = KMajor<2, 4, 2, 1, 16>;  // main tile: 128 x 128, 8 waves (2 x 4), 32 accumulators/lane
 using GT = KMajor<1, 2, 1, 1, 16>;  // tail tile:  32 x 64, 2 waves (1/8 of a main tile's work)
 
 __device__ __forceinline__ float gelu_erf(float x)
@@ -94,7 +94,7 @@ int launch(const float* A, int lda, const float* B, int ldb, float* D, int ldd, 
     if (g_tail_peel && ti * tj > kResidentSlots && rem > 0 && rem <= kResidentSlots / 4 && rem % ti == 0 && rem / ti < tj)
         peel = rem / ti;
     tj -= peel;
-    hipLaunchKernelGGL((gemm_kmajor_kernel<EPI, GM, 4>), dim3(xcd_chunked_grid(ti * tj)), dim3(GM::NT), 0, st, A, lda,
+    hipLaunchKernelGGL((gemm_kmajor_kernel<EPI, GM, 2>), dim3(xcd_chunked_grid(ti * tj)), dim3(GM::NT), 0, st, A, lda,
                        B, ldb, D, ldd, ti, tj, 0, K, bias, scale, res, ldr);
     if (peel) {
         const int tti = I / GT::BM, ttj = peel * GM::BN / GT::BN;
@@ -204,6 +204,10 @@ extern "C" int gp_gemm_probe(int variant, const float* A, int lda, const float* 
         case 5: return probe_launch<KMajor<2, 2, 4, 2, 16>, 1>(A, lda, B, ldb, D, ldd, I, J, K, st);  // 256x128, 4 waves
         case 6: return probe_launch<KMajor<2, 2, 2, 4, 16>, 1>(A, lda, B, ldb, D, ldd, I, J, K, st);  // 128x256, 4 waves
         case 7: return probe_launch<KMajor<2, 2, 2, 2, 8>, 2>(A, lda, B, ldb, D, ldd, I, J, K, st);   // KS=8
+        case 8: return probe_launch<KMajor<2, 2, 2, 2, 16, true>, 2>(A, lda, B, ldb, D, ldd, I, J, K, st);  // + LDS operand prefetch
+        case 9: return probe_launch<KMajor<2, 4, 2, 1, 16>, 2>(A, lda, B, ldb, D, ldd, I, J, K, st);   // 128x128, 8 waves
+        case 10: return probe_launch<KMajor<2, 2, 2, 2, 8, true>, 2>(A, lda, B, ldb, D, ldd, I, J, K, st);  // KS=8 + prefetch
+        case 11: return probe_launch<KMajor<4, 2, 2, 4, 16, true>, 2>(A, lda, B, ldb, D, ldd, I, J, K, st); // 256x256 + prefetch
         default: return GP_EINVAL;
     }
 }

@@ -15,12 +15,12 @@ def timeit(fn, iters=5, warm=2):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 names = {0: "128x128 KS16 4w", 1: "128x128 KS32 4w", 2: "128x256 KS16 8w", 3: "256x128 KS16 8w", 4: "256x256 KS16 8w",
-         5: "256x128 KS16 4w", 6: "128x256 KS16 4w", 7: "128x128 KS8 4w"}
-J = 16640
+         5: "256x128 KS16 4w", 6: "128x256 KS16 4w", 7: "128x128 KS8 4w", 8: "128x128 KS16 4w prefetch", 9: "128x128 KS16 8w", 10: "128x128 KS8 4w prefetch", 11: "256x256 8w prefetch"}
+J = 16640 - 256  # 128 * 128: no ragged tail, isolates the main loop
 for (I, K) in [(1024, 1024), (2048, 1024), (4096, 1024), (1024, 4096)]:
     A = torch.randn(K, I, device=dev); Bm = torch.randn(K, J, device=dev); D = torch.empty(I, J, device=dev)
     ref = None
-    for v in range(8):
+    for v in [0, 7, 8, 9, 10, 4, 11]:
         rc = lib.gp_gemm_probe(v, _lib.ptr(A), I, _lib.ptr(Bm), J, _lib.ptr(D), J, I, J, K, _lib.stream_ptr())
         if rc != 0:
             print(f"I={I} K={K} variant {v} ({names[v]}): n/a"); continue

@@ -75,14 +75,15 @@ static inline int xcd_chunked_grid(int total) { return 8 * ((total + 7) / 8); }
 // ---------------------------------------------------------------------------------------------
 template <int WM, int WN, int MI, int NI, int KS, bool PIPE = false>
 struct KMajor {
-    static constexpr int WM_ = WM, WN_ = WN;
+    static constexpr int WM_ = WM, WN_ = WN, KS_ = KS;
     static constexpr int BM = WM * MI * 32;
     static constexpr int BN = WN * NI * 32;
     static constexpr int NT = WM * WN * 64;
-    static constexpr int A4 = KS * BM / 4 / NT;  // float4 loads per thread per slab (A)
-    static constexpr int B4 = KS * BN / 4 / NT;
+    static constexpr int AF4 = KS * BM / 4, BF4 = KS * BN / 4;  // float4s per slab
+    static constexpr int A4 = (AF4 + NT - 1) / NT;  // float4 loads per thread per slab (A)
+    static constexpr int B4 = (BF4 + NT - 1) / NT;
+    static constexpr bool AG = (AF4 % NT) != 0, BG = (BF4 % NT) != 0;  // guarded (not every thread loads)
     static constexpr int LDS_FLOATS = 2 * KS * (BM + BN);
-    static_assert((KS * BM / 4) % NT == 0 && (KS * BN / 4) % NT == 0, "slab not divisible");
     static_assert(KS % 2 == 0, "KS must be even");
 
 
@@ -94,13 +95,13 @@ struct KMajor {
         for (int u = 0; u < A4; ++u) {
             const int f = tid + u * NT;
             const int r = f / (BM / 4), c4 = f % (BM / 4);
-            ra[u] = *reinterpret_cast<const f32x4*>(A + (size_t)(k0 + r) * lda + c4 * 4);
+            if (!AG || f < AF4) ra[u] = *reinterpret_cast<const f32x4*>(A + (size_t)(k0 + r) * lda + c4 * 4);
         }
 #pragma unroll
         for (int u = 0; u < B4; ++u) {
             const int f = tid + u * NT;
             const int r = f / (BN / 4), c4 = f % (BN / 4);
-            rb[u] = *reinterpret_cast<const f32x4*>(B + (size_t)(k0 + r) * ldb + c4 * 4);
+            if (!BG || f < BF4) rb[u] = *reinterpret_cast<const f32x4*>(B + (size_t)(k0 + r) * ldb + c4 * 4);
         }
     }
     __device__ static __forceinline__ void swrite(float* __restrict__ sA, float* __restrict__ sB, int buf,
@@ -108,15 +109,29 @@ struct KMajor {
     {
 #pragma unroll
         for (int u = 0; u < A4; ++u)
-            *reinterpret_cast<f32x4*>(sA + buf * KS * BM + (tid + u * NT) * 4) = ra[u];
+            if (!AG || tid + u * NT < AF4) *reinterpret_cast<f32x4*>(sA + buf * KS * BM + (tid + u * NT) * 4) = ra[u];
 #pragma unroll
         for (int u = 0; u < B4; ++u)
-            *reinterpret_cast<f32x4*>(sB + buf * KS * BN + (tid + u * NT) * 4) = rb[u];
+            if (!BG || tid + u * NT < BF4) *reinterpret_cast<f32x4*>(sB + buf * KS * BN + (tid + u * NT) * 4) = rb[u];
     }
 
     __device__ static __forceinline__ void run(const float* __restrict__ A, int lda,
                                                 const float* __restrict__ B, int ldb, int K,
                                                 float* __restrict__ smem, f32x16 (&acc)[MI][NI])
+    {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        run_acc(A, lda, B, ldb, K, smem, acc);
+    }
+
+    // continues the chain: acc holds the partial sums of the k rows BEFORE A/B (or zeros)
+    __device__ static __forceinline__ void run_acc(const float* __restrict__ A, int lda,
+                                                    const float* __restrict__ B, int ldb, int K,
+                                                    float* __restrict__ smem, f32x16 (&acc)[MI][NI])
     {
         const int tid = threadIdx.x;
         const int lane = tid & 63;
@@ -124,13 +139,6 @@ struct KMajor {
         const int wm = wave / WN, wn = wave % WN;
         float* sA = smem;                // [2][KS][BM]
         float* sB = smem + 2 * KS * BM;  // [2][KS][BN]
-
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
         f32x4 ra[A4], rb[B4];
         const int nslab = K / KS;

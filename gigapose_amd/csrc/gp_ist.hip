@@ -11,7 +11,7 @@
 
 int gp_gemm_launch(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J,
                    int K, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
-                   hipStream_t st);
+                   float* sk_ws, hipStream_t st);
 
 namespace {
 
@@ -105,10 +105,10 @@ int gp_ist_regress(const float* tar_feat, const float* src_bank, const int* labe
     for (int head = 0; head < 2; ++head) {  // 0: scale_predictor, 1: inplane_predictor (ist_net.py:140-155)
         const float* const* w = weights + head * 6;  // W1^T [2D][2H], b1, W2^T [2H][H], b2, W3 [nout][H], b3
         if ((rc = gp_gemm_launch(w[0], 2 * H, X, (int)R, H1, (int)R, 2 * H, (int)R, 2 * D, 5, w[1], nullptr, nullptr,
-                                 0, st)))
+                                 0, nullptr, st)))
             return rc;
         if ((rc = gp_gemm_launch(w[2], H, H1, (int)R, H2, (int)R, H, (int)R, 2 * H, 5, w[3], nullptr, nullptr, 0,
-                                 st)))
+                                 nullptr, st)))
             return rc;
         if (head == 0)
             hipLaunchKernelGGL(ist_head_kernel<1>, dim3((unsigned)(R / 256)), dim3(256), 0, st, H2, w[4], w[5],

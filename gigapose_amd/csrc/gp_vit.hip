@@ -13,7 +13,9 @@
 
 int gp_gemm_launch(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J,
                    int K, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
-                   hipStream_t st);
+                   float* sk_ws, hipStream_t st);
+size_t gp_gemm_streamk_bytes();
+int gp_gemm_streamk_reset_launch(float* sk_ws, hipStream_t st);
 
 namespace {
 
@@ -262,7 +264,8 @@ size_t gp_vit_workspace_bytes(int B, int dim, int mlp_dim)
     size_t f = (size_t)mlp_dim * Mpad;
     const size_t pe_need = (size_t)KPE_PAD * B * GP_P + (size_t)dim * B * GP_P;
     if (pe_need > f) f = pe_need;
-    return sizeof(float) * ((size_t)5 * dim * Mpad + f);
+    // + the stream-K scratch of the GEMMs (gp_gemm.hip), behind the activations
+    return sizeof(float) * ((size_t)5 * dim * Mpad + f) + gp_gemm_streamk_bytes();
 }
 
 int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
@@ -286,15 +289,19 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
     float* QK = Hn + (size_t)C * Mpad;
     float* Vt = QK + (size_t)2 * C * Mpad;
     float* F = Vt + (size_t)C * Mpad;
+    size_t f_floats = (size_t)mlp_dim * Mpad;
+    if ((size_t)KPE_PAD * B * GP_P + (size_t)dim * B * GP_P > f_floats) f_floats = (size_t)KPE_PAD * B * GP_P + (size_t)dim * B * GP_P;
+    float* SK = F + f_floats;                  // stream-K scratch (flags zeroed once per forward)
     float* col = F;                            // [592][B*256]
     float* pe = F + (size_t)KPE_PAD * BP;      // [C][B*256]
     int rc;
 
+    if ((rc = gp_gemm_streamk_reset_launch(SK, st))) return rc;
     hipLaunchKernelGGL(im2col_kernel, dim3(KPE_PAD, B), dim3(256), 0, st, images, col, B);
     GP_CHECK_LAUNCH("gp_vit_forward/im2col");
     // BP = B*256 is a multiple of 128 only for even B... (256 is) -> always a multiple of 128
     if ((rc = gp_gemm_launch(weights[W_PATCH_WT], C, col, BP, pe, BP, C, BP, KPE_PAD, 1 /*BIAS_I*/,
-                             weights[W_PATCH_B], nullptr, nullptr, 0, st)))
+                             weights[W_PATCH_B], nullptr, nullptr, 0, SK, st)))
         return rc;
     hipLaunchKernelGGL(embed_kernel, dim3(C, B + 1), dim3(320), 0, st, pe, weights[W_CLS_POS], weights[W_POS_T],
                        X, B, Mpad);
@@ -307,11 +314,11 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
         GP_CHECK_LAUNCH("gp_vit_forward/layernorm");
         // Q,K channel-major [2C][Mpad]
         if ((rc = gp_gemm_launch(w[L_QK_WT], 2 * C, Hn, Mpad, QK, Mpad, 2 * C, Mpad, C, 1, w[L_QK_B], nullptr,
-                                 nullptr, 0, st)))
+                                 nullptr, 0, SK, st)))
             return rc;
         // V token-major [Mpad][C]: swap operand roles (A = activations, B = weights), bias along j
         if ((rc = gp_gemm_launch(Hn, Mpad, w[L_V_WT], C, Vt, C, Mpad, C, C, 4 /*BIAS_J*/, w[L_V_B], nullptr,
-                                 nullptr, 0, st)))
+                                 nullptr, 0, SK, st)))
             return rc;
         {
             GpProfScope prof(GP_PROF_ATTN, 4.0 * B * heads * 257.0 * 257.0 * 64.0, st);
@@ -321,16 +328,16 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
         GP_CHECK_LAUNCH("gp_vit_forward/attention");
         // x = x + ls1 * proj(attn)
         if ((rc = gp_gemm_launch(w[L_PROJ_WT], C, Hn, Mpad, X, Mpad, C, Mpad, C, 3, w[L_PROJ_B], w[L_LS1], X, Mpad,
-                                 st)))
+                                 SK, st)))
             return rc;
         launch_layernorm(X, Hn, w[L_LN2_G], w[L_LN2_B], C, Mpad, ln_eps, st);
         GP_CHECK_LAUNCH("gp_vit_forward/layernorm");
         if ((rc = gp_gemm_launch(w[L_FC1_WT], mlp_dim, Hn, Mpad, F, Mpad, mlp_dim, Mpad, C, 2 /*GELU*/, w[L_FC1_B],
-                                 nullptr, nullptr, 0, st)))
+                                 nullptr, nullptr, 0, SK, st)))
             return rc;
         // x = x + ls2 * fc2(gelu(fc1))
         if ((rc = gp_gemm_launch(w[L_FC2_WT], C, F, Mpad, X, Mpad, C, Mpad, mlp_dim, 3, w[L_FC2_B], w[L_LS2], X,
-                                 Mpad, st)))
+                                 Mpad, SK, st)))
             return rc;
     }
     hipLaunchKernelGGL(features_kernel, dim3(B), dim3(256), 0, st, X, out_features, C, Mpad, normalize);

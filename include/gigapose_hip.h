@@ -75,10 +75,26 @@ int gp_format_points(const uint8_t* rec_idx, const float* rec_mask, int rows, lo
  * epilogue: 0 none | 1 +bias[i] | 2 gelu_erf(+bias[i]) | 3 residual[i][j] + scale[i]*(acc+bias[i])
  *           (D may alias residual) | 4 +bias[j] | 5 relu(+bias[i]).
  * Requires I % 128 == 0, J % 128 == 0, K % 16 == 0, lda/ldb % 4 == 0, 16-byte aligned A/B. */
-void gp_gemm_set_tail_peel(int on); /* test hook: 0 disables the tail-tile split (results identical) */
+void gp_gemm_set_streamk(int mode); /* test hook: 0 = one workgroup per tile even with a scratch, 1 = by the built-in rule
+                                      (default), 2 = split whenever the tile count allows (results identical) */
+void gp_gemm_set_group(int g);    /* tuning hook: tiles are ordered in bands of g i-tiles (default 8; results identical) */
 int gp_gemm_kmajor(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J,
                    int K, int epilogue, const float* bias, const float* scale, const float* residual,
                    int ldr, void* stream);
+
+/* Same contraction with a device scratch that lets the library balance tile counts that are not a multiple
+ * of the resident workgroups ("chain-preserving stream-K", gp_gemm.hip): a tile split between two workgroups
+ * is handed over as an accumulator fragment, so the per-output fmaf chain -- and every output bit -- is the
+ * same as gp_gemm_kmajor's.  scratch: gp_gemm_streamk_workspace_bytes() bytes, 16-byte aligned, one per
+ * stream; call gp_gemm_streamk_reset() on it once before first use (zeroes the hand-off flags).
+ * gp_gemm_streamk_error() synchronises the stream and returns the scratch's error word (0 = every hand-off
+ * arrived; test hook). */
+size_t gp_gemm_streamk_workspace_bytes(void);
+int gp_gemm_streamk_reset(float* scratch, void* stream);
+int gp_gemm_streamk_error(const float* scratch, void* stream);
+int gp_gemm_kmajor_sk(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J,
+                      int K, int epilogue, const float* bias, const float* scale, const float* residual,
+                      int ldr, float* scratch, size_t scratch_bytes, void* stream);
 
 /* ---- DINOv2 ViT patch features: AENet.forward (src/models/network/ae_net.py:44-73) ---------- */
 

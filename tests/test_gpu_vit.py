@@ -46,28 +46,62 @@ def test_gemm_bit_exact_vs_fmaf_chain(epi):
     np.testing.assert_allclose(got if epi == 0 else got, ref, rtol=1e-6)
 
 
-def test_gemm_tail_peel_is_bit_identical():
-    """ViT-L proj shape at B=64 (8 x 129 tiles on 1024 resident slots): the trailing j-tile is computed by
-    32x64 tail tiles; the result must not depend on the split."""
+def hip_gemm_sk(A, B, epi, bias, scale, res):
+    """gp_gemm_kmajor_sk: same contraction with the stream-K scratch (tile count not a multiple of the slots)."""
+    import ctypes
+    from gigapose_amd import _lib
+
+    lib = _lib.lib()
+    lib.gp_gemm_streamk_workspace_bytes.restype = ctypes.c_size_t
+    nbytes = lib.gp_gemm_streamk_workspace_bytes()
+    K, I = A.shape
+    J = B.shape[1]
+    tA, tB = torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV)
+    D = torch.from_numpy(res).to(DEV).clone() if epi == 3 else torch.empty(I, J, device=DEV)
+    tb, ts = torch.from_numpy(bias).to(DEV), torch.from_numpy(scale).to(DEV)
+    tr = D if epi == 3 else None                     # in-place residual, as the ViT uses it
+    ws = torch.full((nbytes // 4,), float("nan"), device=DEV)
+    _lib.call("gp_gemm_streamk_reset", _lib.ptr(ws), _lib.stream_ptr())
+    for _ in range(2):                               # second launch: flags of the first must not satisfy it
+        if epi == 3:
+            D.copy_(torch.from_numpy(res))
+        _lib.call("gp_gemm_kmajor_sk", _lib.ptr(tA), _lib.i(I), _lib.ptr(tB), _lib.i(J), _lib.ptr(D), _lib.i(J),
+                  _lib.i(I), _lib.i(J), _lib.i(K), _lib.i(epi), _lib.ptr(tb), _lib.ptr(ts), _lib.ptr(tr), _lib.i(J),
+                  _lib.ptr(ws), ctypes.c_size_t(nbytes), _lib.stream_ptr())
+    assert lib.gp_gemm_streamk_error(_lib.ptr(ws), _lib.stream_ptr()) == 0, "a stream-K hand-off timed out"
+    return D.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", ["proj", "v", "qk", "ragged", "fc1"])
+def test_gemm_streamk_is_bit_identical(shape):
+    """ViT-L shapes at B=64 (8 x 129, 129 x 8, 16 x 129 tiles on 1024 resident slots) + a tile count with
+    T % 8 != 0: tiles split between two workgroups are handed over as accumulator fragments; the result must
+    depend neither on the split nor on the tile order, and equal the oracle's fmaf chain bit for bit."""
     from gigapose_amd import _lib
 
     rs = np.random.RandomState(7)
-    I, J, K = 1024, 129 * 128, 48
+    I, J, K, epi = {"proj": (1024, 129 * 128, 80, 3), "v": (129 * 128, 1024, 48, 4), "qk": (2048, 129 * 128, 32, 1),
+                    "ragged": (9 * 128, 115 * 128, 64, 0), "fc1": (4096, 129 * 128, 32, 1)}[shape]
     A = rs.standard_normal((K, I)).astype(np.float32)
     B = rs.standard_normal((K, J)).astype(np.float32)
-    bias = rs.standard_normal(I).astype(np.float32)
+    bias = rs.standard_normal(J if epi == 4 else I).astype(np.float32)
     scale = rs.standard_normal(I).astype(np.float32)
     res = rs.standard_normal((I, J)).astype(np.float32)
-    peeled = hip_gemm(A, B, 3, bias, scale, res)
-    _lib.lib().gp_gemm_set_tail_peel(0)
+    lib = _lib.lib()
+    lib.gp_gemm_set_streamk(2)   # also where the built-in rule would not split (fc1: several whole tiles per slot)
     try:
-        plain = hip_gemm(A, B, 3, bias, scale, res)
+        split = hip_gemm_sk(A, B, epi, bias, scale, res)
     finally:
-        _lib.lib().gp_gemm_set_tail_peel(1)
-    np.testing.assert_array_equal(peeled.view(np.uint32), plain.view(np.uint32))
-    cols = np.r_[0:64, J - 200:J]  # oracle on the first columns and the peeled region
-    ref = oracle.gemm_kmajor(A, B[:, cols], 3, bias, scale, res[:, cols])
-    np.testing.assert_array_equal(peeled[:, cols].view(np.uint32), ref.view(np.uint32))
+        lib.gp_gemm_set_streamk(1)
+    lib.gp_gemm_set_group(3)
+    try:
+        plain = hip_gemm(A, B, epi, bias, scale, res)   # one workgroup per tile, other tile order
+    finally:
+        lib.gp_gemm_set_group(8)
+    np.testing.assert_array_equal(split.view(np.uint32), plain.view(np.uint32))
+    rows = np.r_[0:40, I // 2:I // 2 + 24, I - 40:I]     # oracle on a band of rows
+    ref = oracle.gemm_kmajor(np.ascontiguousarray(A[:, rows]), B, epi, bias if epi == 4 else bias[rows], scale[rows], res[rows])
+    np.testing.assert_array_equal(split[rows].view(np.uint32), ref.view(np.uint32))
 
 
 def test_gemm_gelu_and_errors():

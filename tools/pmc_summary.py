@@ -1,0 +1,42 @@
+"""Summarise rocprofv3 --pmc passes (csv): per kernel, per counter: dispatches, mean value per dispatch.
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for
+wide coalesced reads, so the corrected byte figure is 2 x (MI355X_MICROARCH.md, "HBM").
+usage: python tools/pmc_summary.py <dir with <pass>/**/p_counter_collection.csv>"""
+import collections
+import csv
+import glob
+import os
+import sys
+
+
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n[:64]
+
+
+def main(root):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+        per_dispatch = collections.defaultdict(float)
+        names = {}
+        for r in csv.DictReader(open(path)):
+            key = (r["Dispatch_Id"], r["Counter_Name"])
+            per_dispatch[key] += float(r["Counter_Value"])
+            names[r["Dispatch_Id"]] = (short(r["Kernel_Name"]), r.get("Grid_Size", r.get("Grid_Size_X", "")))
+        for (d, c), v in per_dispatch.items():
+            acc[names[d]][c].append(v)
+    for k in sorted(acc):
+        if "gemm" not in k[0] and "match" not in k[0] and "conv" not in k[0] and "attention" not in k[0] and "layernorm" not in k[0]:
+            continue
+        print(f"{k[0]}  grid={k[1]}")
+        for c, v in sorted(acc[k].items()):
+            extra = ""
+            if c == "FETCH_SIZE":
+                extra = f"  -> {sum(v)/len(v)*1024*2/1e6:.1f} MB/launch after the gfx950 x2 correction"
+            if c == "WRITE_SIZE":
+                extra = f"  -> {sum(v)/len(v)*1024/1e6:.1f} MB/launch (uncalibrated)"
+            print(f"    {c:34s} n={len(v):3d} mean={sum(v)/len(v):.4g}{extra}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -15,11 +15,27 @@ def timeit(fn, iters=5, warm=2):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 
-for (I, J, K) in [(1024, 16512, 1024), (4096, 16512, 1024), (1024, 16512, 4096), (2048, 16512, 1024)]:
-    A = torch.randn(K, I, device=dev); Bm = torch.randn(K, J, device=dev); D = torch.empty(I, J, device=dev)
-    ms = timeit(lambda: _lib.call("gp_gemm_kmajor", _lib.ptr(A), _lib.i(I), _lib.ptr(Bm), _lib.i(J), _lib.ptr(D), _lib.i(J),
-                                  _lib.i(I), _lib.i(J), _lib.i(K), _lib.i(0), None, None, None, _lib.i(J), _lib.stream_ptr()))
-    print(f"gemm I={I} J={J} K={K}: {ms:.3f} ms {2.0*I*J*K/ms/1e9:.1f} TF")
+import ctypes
+lib = _lib.lib()
+lib.gp_gemm_streamk_workspace_bytes.restype = ctypes.c_size_t
+nbytes = lib.gp_gemm_streamk_workspace_bytes()
+ws = torch.zeros(nbytes // 4, device=dev)
+for mode in ["plain", "streamk", "plain", "streamk"]:
+    tot = 0.0
+    for (I, J, K, epi) in [(1024, 16512, 1024, 3), (4096, 16512, 1024, 2), (1024, 16512, 4096, 3), (2048, 16512, 1024, 1), (16512, 1024, 1024, 4)]:
+        A = torch.randn(K, I, device=dev); Bm = torch.randn(K, J, device=dev); D = torch.randn(I, J, device=dev)
+        bias = torch.randn(max(I, J), device=dev); sc = torch.randn(I, device=dev)
+        if mode == "plain":
+            fn = lambda: _lib.call("gp_gemm_kmajor", _lib.ptr(A), _lib.i(I), _lib.ptr(Bm), _lib.i(J), _lib.ptr(D), _lib.i(J),
+                                   _lib.i(I), _lib.i(J), _lib.i(K), _lib.i(epi), _lib.ptr(bias), _lib.ptr(sc), _lib.ptr(D), _lib.i(J), _lib.stream_ptr())
+        else:
+            fn = lambda: _lib.call("gp_gemm_kmajor_sk", _lib.ptr(A), _lib.i(I), _lib.ptr(Bm), _lib.i(J), _lib.ptr(D), _lib.i(J),
+                                   _lib.i(I), _lib.i(J), _lib.i(K), _lib.i(epi), _lib.ptr(bias), _lib.ptr(sc), _lib.ptr(D), _lib.i(J),
+                                   _lib.ptr(ws), ctypes.c_size_t(nbytes), _lib.stream_ptr())
+        ms = timeit(fn)
+        tot += ms
+        print(f"{mode} gemm I={I} J={J} K={K} epi={epi}: {ms:.3f} ms {2.0*I*J*K/ms/1e9:.1f} TF")
+    print(f"{mode} layer total {tot:.3f} ms -> {415.5/tot:.1f} TF  err={lib.gp_gemm_streamk_error(_lib.ptr(ws), _lib.stream_ptr())}")
 
 name = sys.argv[1] if len(sys.argv) > 1 else "dinov2_vitl14"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64

@@ -95,7 +95,8 @@ def main():
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or (under_launcher and args.mode == "sharded"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -103,8 +104,8 @@ def main():
 
     mode = args.mode if args.mode != "auto" else ("sharded" if world > 1 else "single")
     model = factory.build_model(args.variant, k=args.k, device=dev, seed=0)
-    if mode == "sharded" and world > 1:
-        model.enable_template_sharding()
+    if mode == "sharded" and dist.is_initialized():
+        model.enable_template_sharding()  # world 1: only meaningful with GIGAPOSE_FORCE_COLLECTIVES=1 (path check)
     tset = factory.TemplateSet(args.objects, args.templates, seed=100)
     model.template_datasets = {"syn": tset}
     model.set_template_data("syn")  # onboarding: excluded from the timed region (reference gigaPose.py:396-398)
@@ -165,8 +166,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     crops = world * args.batch * args.steps
@@ -197,7 +197,7 @@ def main():
         except Exception as e:  # the baseline is a reported extra; never lose the GPU number
             out["cpu_baseline"] = {"error": repr(e)}
     print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -294,6 +294,7 @@ int gp_gemm_streamk_reset_launch(float* sk_ws, hipStream_t st)
 
 // ---- tile-shape experiments (tools/probe_gemm.py); not part of the product path -------------------
 namespace {
+__device__ unsigned long long g_clk[4];  // shader-clock / 100 MHz wall-clock stamps of block 0 (tools/probe_clock.py)
 template <class CFG, int MINW>
 __global__ __launch_bounds__(CFG::NT, MINW) void gemm_probe_kernel(const float* __restrict__ A, int lda,
                                                                    const float* __restrict__ B, int ldb, float* D,
@@ -306,7 +307,12 @@ __global__ __launch_bounds__(CFG::NT, MINW) void gemm_probe_kernel(const float* 
     const int i0 = ti * CFG::BM, j0 = tj * CFG::BN;
     constexpr int MI = CFG::BM / 32 / CFG::WM_, NI = CFG::BN / 32 / CFG::WN_;
     f32x16 acc[MI][NI];
+    unsigned long long c0 = 0, w0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c0 = __builtin_readcyclecounter(); w0 = wall_clock64(); }
     CFG::run(A + i0, lda, B + j0, ldb, K, smem, acc);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_clk[0] = c0; g_clk[1] = __builtin_readcyclecounter(); g_clk[2] = w0; g_clk[3] = wall_clock64();
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / CFG::WN_, wn = wave % CFG::WN_;
 #pragma unroll
@@ -321,9 +327,11 @@ __global__ __launch_bounds__(CFG::NT, MINW) void gemm_probe_kernel(const float* 
             }
         }
 }
+static int g_probe_occ = 0;  // blocks/CU the runtime reports for the last probe kernel
 template <class CFG, int MINW>
 int probe_launch(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J, int K, hipStream_t st)
 {
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&g_probe_occ, gemm_probe_kernel<CFG, MINW>, CFG::NT, 0);
     if (I % CFG::BM || J % CFG::BN || K % 32) return GP_EINVAL;
     const int ti = I / CFG::BM, tj = J / CFG::BN;
     hipLaunchKernelGGL((gemm_probe_kernel<CFG, MINW>), dim3(xcd_chunked_grid(ti * tj)), dim3(CFG::NT), 0, st, A, lda, B,
@@ -333,6 +341,18 @@ int probe_launch(const float* A, int lda, const float* B, int ldb, float* D, int
 }  // namespace
 
 extern "C" void gp_gemm_set_streamk(int mode) { g_streamk = mode; }
+extern "C" int gp_gemm_probe_occupancy(void) { return g_probe_occ; }
+extern "C" int gp_gemm_product_occupancy(int streamk)
+{
+    int n = 0;
+    if (streamk) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_streamk_kernel<EPI_BIAS_I_SCALE_RES>, GM::NT, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_kmajor_kernel<EPI_BIAS_I_SCALE_RES>, GM::NT, 0);
+    return n;
+}
+extern "C" int gp_gemm_probe_clock(unsigned long long* host4)
+{
+    return hipMemcpyFromSymbol(host4, HIP_SYMBOL(g_clk), 4 * sizeof(unsigned long long)) == hipSuccess ? GP_OK : GP_ELAUNCH;
+}
 extern "C" void gp_gemm_set_group(int g) { g_group = g > 0 ? g : 1; }
 
 extern "C" int gp_gemm_probe(int variant, const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I,

@@ -15,7 +15,17 @@ Collectives go through torch.distributed ("nccl" = RCCL on ROCm; "gloo" in the C
 import torch
 import torch.distributed as dist
 
+import os
+
 P = 256
+
+
+def _always_collective():
+    """GIGAPOSE_FORCE_COLLECTIVES=1: issue the all-gathers even with one rank (the single-GPU box exercises the
+    RCCL calls, streams and layouts of the N>1 path this way; tests/test_gpu_e2e.py)."""
+    return os.environ.get("GIGAPOSE_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized()
+
+
 REC_BYTES = 8 + 4 + P + 4 * P + 4 * P  # id i64, score f32, idx u8[256], score f32[256], mask f32[256]
 
 
@@ -29,7 +39,7 @@ def shard_bounds(n_templates, world, rank):
 def all_gather_cat(t, group=None):
     """all-gather equal-shaped tensors and concatenate along dim 0 (rank order)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not _always_collective():
         return t
     outs = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(outs, t.contiguous(), group=group)
@@ -72,7 +82,7 @@ def exchange_and_merge(local_rows, n_own, k, rank, group=None):
     """local_rows (W*B, k, REC_BYTES) u8: this rank's candidates for ALL crops (crop order = rank-major).
     Returns merged ids (B,k) i64, scores (B,k), rec_idx/rec_score/rec_mask (B,k,256) for OWN crops."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world > 1:
+    if world > 1 or _always_collective():
         outs = [torch.empty_like(local_rows) for _ in range(world)]
         dist.all_gather(outs, local_rows, group=group)
         mine = torch.cat([o[rank * n_own:(rank + 1) * n_own] for o in outs], dim=1)  # (B, W*k, REC)

@@ -200,3 +200,46 @@ def test_ist_outputs_as_close_to_f64_truth_as_the_reference(golden_dir):
           "reference (f32 CPU) median %.2e p99 %.2e" % (mag, np.median(em), np.percentile(em, 99), np.median(er),
                                                         np.percentile(er, 99)))
     assert np.median(em) <= 3 * np.median(er) + 1e-6 and np.percentile(em, 99) <= 5 * np.percentile(er, 99) + 1e-5
+
+
+def test_template_sharded_path_over_rccl_equals_unsharded(monkeypatch):
+    """The N>1 path on the 1-GPU box: torch.distributed 'nccl' (= RCCL) process group of ONE rank with the
+    all-gathers forced (GIGAPOSE_FORCE_COLLECTIVES): exchange #1/#2, packing, merge and the hand-over to IST /
+    RANSAC / recovery run on device buffers through RCCL and must reproduce the unsharded predict() exactly.
+    (world_size 2 equality of the exchange + merge logic: tests/test_sharding_gloo.py on CPU.)"""
+    import socket
+
+    import torch.distributed as dist
+
+    from gigapose_amd import factory
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(port))
+    monkeypatch.setenv("GIGAPOSE_FORCE_COLLECTIVES", "1")
+    dev = torch.device("cuda", 0)
+    tset = factory.TemplateSet(2, 9, seed=60)
+    q = tset.crops(61, 5, dev)
+
+    def run(sharded):
+        model = factory.build_model("dinov2_vits14", k=4, device=dev, seed=5)
+        if sharded:
+            model.enable_template_sharding()
+        model.template_datasets = {"syn": tset}
+        model.set_template_data("syn")
+        p = model.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
+        torch.cuda.synchronize()
+        return {n: v.cpu() for n, v in p.tensors.items()}
+
+    plain = run(False)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        shard = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert set(plain) == set(shard)
+    for n in plain:
+        assert torch.equal(plain[n], shard[n]), f"{n} differs between the sharded and the unsharded path"

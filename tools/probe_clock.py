@@ -1,0 +1,31 @@
+"""GPU probe: is the f32 MFMA GEMM main loop power/clock limited?  Same kernel (gp_gemm_probe variants) on
+random vs zero-filled operands (MI355X guide, "DVFS give-back": zeros run at a higher clock)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gigapose_amd import _lib
+dev = "cuda"
+lib = _lib.lib()
+def timeit(fn, iters=8, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+import ctypes
+def clk():
+    c = (ctypes.c_ulonglong * 4)()
+    lib.gp_gemm_probe_clock(c)
+    return (c[1] - c[0]) / ((c[3] - c[2]) * 10.0) if c[3] > c[2] else 0.0, c[1] - c[0]
+for (I, J, K) in [(4096, 16384, 1024), (1024, 16384, 4096), (1024, 16384, 1024)]:
+    for data in ["random", "zeros"]:
+        mk = {"random": torch.randn, "zeros": torch.zeros}[data]
+        A = mk(K, I, device=dev); Bm = mk(K, J, device=dev); D = torch.empty(I, J, device=dev)
+        for rep in range(3 if data == "random" else 1):
+            for v in [9, 5, 0, 4, 6, 3]:
+                ms = timeit(lambda: lib.gp_gemm_probe(v, _lib.ptr(A), I, _lib.ptr(Bm), J, _lib.ptr(D), J, I, J, K, _lib.stream_ptr()))
+                ghz, cyc = clk()
+                print(f"I={I} K={K} {data:6s} rep{rep} variant {v}: {ms:.3f} ms {2.0*I*J*K/ms/1e9:6.1f} TF  clock {ghz:.3f} GHz  "
+                      f"block-0 loop {cyc} cyc  occ {lib.gp_gemm_probe_occupancy()}/CU")

@@ -263,3 +263,33 @@ def correspondences_case(seed, B, k):
                 ang = a + rs.normal(0, 0.08)
                 rel_inplane[b, j, p] = (np.cos(ang), np.sin(ang))
     return dict(src_pts=src_pts, tar_pts=tar_pts, rel_scale=rel_scale, rel_inplane=rel_inplane)
+
+
+def detection_case(seed, n_img=2, D=10, H=480, W=640):
+    """Full-frame uint8 images, per-detection binary masks and xyxy boxes for the crop pre-processing stage
+    (reference src/dataloader/train.py:80-123 + src/utils/crop.py:11-61).  Boxes cover: wide, tall, square,
+    exactly target-sized, tiny (up-scaling), odd sizes whose scaled side falls one pixel short of 224, a box
+    that runs past the right/bottom border (the reference's slicing clamps it) and the full frame."""
+    rs = np.random.RandomState(seed)
+    rgb = rs.randint(0, 256, (n_img, 3, H, W)).astype(np.uint8)
+    fixed = [(100, 50, 324, 274), (10, 20, 310, 140), (400, 100, 470, 420), (5, 7, 16, 14), (0, 0, W, H),
+             (W - 120, H - 90, W + 30, H + 25), (33, 41, 33 + 223, 41 + 223), (200, 120, 200 + 225, 120 + 97)]
+    if (H, W) != (480, 640):  # other frame sizes: keep the frame-relative cases only
+        fixed = [(0, 0, W, H), (W - W // 5, H - H // 6, W + 30, H + 25), (W // 4, H // 4, W // 4 + 9, H // 4 + 6)]
+    boxes = []
+    for d in range(D):
+        if d < len(fixed):
+            boxes.append(fixed[d])
+        else:
+            w, h = rs.randint(8, W // 2), rs.randint(8, H // 2)
+            x0, y0 = rs.randint(0, W - w), rs.randint(0, H - h)
+            boxes.append((x0, y0, x0 + w, y0 + h))
+    boxes = np.asarray(boxes, np.int64)
+    masks = np.zeros((D, H, W), np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for d, (x0, y0, x1, y1) in enumerate(boxes):
+        cx, cy = 0.5 * (x0 + min(x1, W)), 0.5 * (y0 + min(y1, H))
+        rx, ry = 0.55 * (min(x1, W) - x0), 0.45 * (min(y1, H) - y0)
+        masks[d] = (((xx - cx) / max(rx, 1)) ** 2 + ((yy - cy) / max(ry, 1)) ** 2 <= 1.0).astype(np.float32)
+    im_id = rs.randint(0, n_img, D).astype(np.int32)
+    return dict(rgb=rgb, masks=masks, boxes=boxes, im_id=im_id)

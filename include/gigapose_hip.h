@@ -31,6 +31,27 @@ void gp_prof_begin(void);
 int gp_prof_end(int max_kinds, double* ms, double* work, long long* launches);
 const char* gp_prof_kind_name(int kind);
 
+/* ---- detection pre-processing (the step before the hot path) ------------- */
+
+/* CropResizePad.__call__(xyxy_boxes, images) (src/utils/crop.py:11-61): per detection d, crop images[d] to its
+ * box (clamped at the frame border like the reference's slicing), nearest resize by 224/max(w,h), zero-pad to
+ * target x target, nearest resize to target; M[d] = M_resize_pad @ M_crop.  One gather per output pixel with
+ * ATen's nearest index arithmetic (bit-exact vs the reference).
+ *   images (D,C,H,W) f32, boxes (D,4) int64 xyxy -> out (D,C,target,target) f32, M (D,3,3) f32.
+ * A box that is empty, starts outside the frame or scales to nothing (the reference raises / produces an empty
+ * tensor there) leaves its outputs untouched and stores d+1 in *err_flag (device int, caller zeroes it). */
+int gp_crop_resize_pad(const float* images, const long long* boxes, int D, int C, int H, int W, int target, float* out,
+                       float* M, int* err_flag, void* stream);
+
+/* process_real + normalize fused (src/dataloader/train.py:80-123, src/dataloader/test.py:295-315,
+ * configs/data/transform.yaml): tar_img = ((rgb/255) * mask cropped as above - mean) / std, tar_mask = cropped mask.
+ *   rgb (n_img,3,H,W) u8 full frames, masks (D,H,W) f32 {0,1}, boxes (D,4) int64 xyxy, im_id (D) int32 frame of
+ *   each detection, mean3/std3: HOST arrays of 3 floats -> tar_img (D,3,target,target), tar_mask (D,target,target),
+ *   M (D,3,3).  err_flag as above. */
+int gp_preprocess_detections(const uint8_t* rgb, const float* masks, const long long* boxes, const int* im_id, int n_img,
+                             int D, int H, int W, int target, const float* mean3_host, const float* std3_host,
+                             float* tar_img, float* tar_mask, float* M, int* err_flag, void* stream);
+
 /* ---- template matching: LocalSimilarity.test (src/models/matching.py:188-316) ------------- */
 
 /* F.normalize(x, dim=C) for x (rows, C, 256).  Replaces matching.py:224,229 and ae_net.py:69. */

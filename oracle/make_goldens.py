@@ -223,7 +223,34 @@ def gen_e2e():
     print("     valid corr", (p.src_pts[..., 0] >= 0).sum(-1).tolist())
 
 
-STAGES = {"matcher": gen_matcher, "ist": gen_ist, "pose": gen_pose, "e2e": gen_e2e}
+CLIP_MEAN = [0.48145466, 0.4578275, 0.40821073]   # reference configs/data/transform.yaml:6-7
+CLIP_STD = [0.26862954, 0.26130258, 0.27577711]
+
+
+def gen_crop():
+    """Detection pre-processing as GigaPoseTestSet.process_real + collate_fn do it (reference
+    src/dataloader/train.py:80-123, src/dataloader/test.py:295-315): rgb/255 * mask, CropResizePad on the RGBA
+    stack, torchvision Normalize (un-vendored; restated here as its documented `(x - mean) / std`)."""
+    ref_shim.install()
+    from src.utils.crop import CropResizePad
+
+    case = syn.detection_case(seed=401)
+    rgb = torch.from_numpy(case["rgb"]) / 255.0
+    masks = torch.from_numpy(case["masks"])
+    boxes = torch.from_numpy(case["boxes"])
+    m_rgb = rgb[torch.from_numpy(case["im_id"]).long()] * masks[:, None]
+    m_rgba = torch.cat([m_rgb, masks[:, None]], dim=1)
+    out = CropResizePad(target_size=224)(boxes, images=m_rgba)
+    mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
+    std = torch.tensor(CLIP_STD).view(3, 1, 1)
+    tar_img = (out["images"][:, :3] - mean) / std
+    np.savez_compressed(os.path.join(GOLD, "crop.npz"), seed=401, tar_img=tar_img.numpy(),
+                        tar_mask=out["images"][:, -1].numpy(), M=out["M"].numpy(),
+                        input_checksum=np.float64(case["rgb"].astype(np.float64).sum() + case["masks"].sum() + case["boxes"].sum()))
+    print("crop: images", tuple(out["images"].shape), "M[0]", out["M"][0].tolist())
+
+
+STAGES = {"matcher": gen_matcher, "ist": gen_ist, "pose": gen_pose, "e2e": gen_e2e, "crop": gen_crop}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

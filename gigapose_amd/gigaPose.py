@@ -213,15 +213,12 @@ class GigaPose(_Base):
         return 0
 
     def on_test_epoch_end(self):
-        """BOP csv aggregation lives in the reference's src/utils/inout.py (not
-        rebuilt): when the reference package is importable it is called exactly as the reference does
-        (gigaPose.py:644-653); otherwise the per-image npz files are left for it."""
+        """Merge the per-batch npz files into the BOP csv files (reference gigaPose.py:644-653 ->
+        src/utils/inout.py:278-367; here gigapose_amd/inout.py, byte-identical output)."""
         if self.global_rank != 0:
             return
-        try:
-            from src.utils.inout import save_predictions_from_batched_predictions
-        except Exception:
-            return
+        from .inout import save_predictions_from_batched_predictions
+
         save_predictions_from_batched_predictions(osp.join(self.log_dir, "predictions"),
                                                   dataset_name=self.test_dataset_name, model_name=self.model_name,
                                                   run_id=self.run_id, is_refined=False)

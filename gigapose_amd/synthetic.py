@@ -293,3 +293,20 @@ def detection_case(seed, n_img=2, D=10, H=480, W=640):
         masks[d] = (((xx - cx) / max(rx, 1)) ** 2 + ((yy - cy) / max(ry, 1)) ** 2 <= 1.0).astype(np.float32)
     im_id = rs.randint(0, n_img, D).astype(np.int32)
     return dict(rgb=rgb, masks=masks, boxes=boxes, im_id=im_id)
+
+
+def prediction_batches(seed, n_batches=3, k=4):
+    """Per-batch npz payloads in the layout GigaPose.filter_and_save writes (reference gigaPose.py:436-447):
+    several images, an image spread over two batches, repeated objects."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for b in range(n_batches):
+        n = int(rs.randint(3, 7))
+        im = np.sort(rs.randint(1 + b, 3 + b, n)).astype(np.int32)        # image ids overlap between batches
+        poses = rs.standard_normal((n, k, 4, 4)).astype(np.float32)
+        poses[..., 3, :] = (0, 0, 0, 1)
+        det_t = {int(i): float(rs.uniform(0.05, 0.3)) for i in np.unique(im)}
+        out.append(dict(scene_id=np.full(n, 2, np.int32), im_id=im, object_id=rs.randint(1, 9, n).astype(np.int32),
+                        time=np.full(n, float(rs.uniform(0.02, 0.08))), detection_time=np.array([det_t[int(i)] for i in im]),
+                        poses=poses, scores=np.sort(rs.rand(n, k).astype(np.float32), axis=1)[:, ::-1].copy()))
+    return out

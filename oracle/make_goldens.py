@@ -250,7 +250,28 @@ def gen_crop():
     print("crop: images", tuple(out["images"].shape), "M[0]", out["M"][0].tolist())
 
 
-STAGES = {"matcher": gen_matcher, "ist": gen_ist, "pose": gen_pose, "e2e": gen_e2e, "crop": gen_crop}
+def gen_bop_csv():
+    """The reference's BOP writer (src/utils/inout.py:278-367) on synthetic per-batch npz files, for an LM-O-named
+    and a plain dataset: the csv texts are the golden."""
+    import tempfile
+
+    ref_shim.install()
+    from src.utils.inout import save_predictions_from_batched_predictions
+
+    gold = {"seed": 501}
+    for ds in ["lmo", "ycbv"]:
+        with tempfile.TemporaryDirectory() as tmp:
+            for i, b in enumerate(syn.prediction_batches(501)):
+                np.savez(os.path.join(tmp, f"{i}.npz"), **b)
+            save_predictions_from_batched_predictions(tmp, dataset_name=ds, model_name="large", run_id="r0", is_refined=False)
+            for f in sorted(os.listdir(tmp)):
+                if f.endswith(".csv"):
+                    gold[f"{ds}:{f}"] = np.frombuffer(open(os.path.join(tmp, f), "rb").read(), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "bop_csv.npz"), **gold)
+    print("bop_csv:", [k for k in gold if k != "seed"])
+
+
+STAGES = {"bop_csv": gen_bop_csv, "matcher": gen_matcher, "ist": gen_ist, "pose": gen_pose, "e2e": gen_e2e, "crop": gen_crop}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

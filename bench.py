@@ -170,11 +170,22 @@ def main():
         return
 
     crops = world * args.batch * args.steps
+    # HBM traffic of the dominant kernel family from the committed PMC passes of this same command (tools/pmc_bench.sh;
+    # counters cannot be collected from inside the timed run): bytes per launch, corrected as the MI355X guide says
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if args.variant == "dinov2_vitl14" and args.batch == 64 and args.templates == 162:
+            traffic = round(pmc["gemm_kmajor"]["hbm_bytes_per_launch"])
+    except Exception:
+        pass
     g = kern.get("gemm_kmajor", {})
     achieved = g.get("TFLOP/s", 0.0)
     roofline = {"kernel": "gemm_kmajor_kernel (ViT linear layers + IST MLP; f32-input MFMA 32x32x2)", "bound": "mfma",
                 "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json); algorithmic "
+                                "operand + result bytes per launch: see DESIGN.md section 4",
                 "share_of_step": round(g.get("ms_per_step", 0.0) / (1e3 * dt_serial / args.steps), 3),
                 "measured": "HIP events on the launch stream around every launch, over a single-stream replay of the "
                             "timed steps (kernels_timed_region: same events inside the timed, two-stream region)",

@@ -67,7 +67,13 @@ __global__ __launch_bounds__(512, 2) void match_tiles_kernel(
     __shared__ MatchSmem sm;
     const int q = xcd_chunked_tile(blockIdx.x, B * N);
     if (q < 0) return;
-    const int n = q / B, b = q % B;  // b fastest: neighbours on one XCD share the template tile
+    // Tile order: bands of 8 detections, b fastest inside a band, then n.  The 32 tiles an XCD runs concurrently
+    // (one 84 KB workgroup per CU) are then 8 queries x 4 templates: each k-slab of a query is fetched into that
+    // XCD's L2 once per 4 tiles and each template slab once per 8, instead of every query being streamed again
+    // for every template (b fastest over all B: 10.4 GB of fabric reads per launch at B=64, N=162).
+    const int band = q / (8 * N), r8 = q - band * (8 * N);
+    const int gsz = min(8, B - band * 8);
+    const int b = band * 8 + r8 % gsz, n = r8 / gsz;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const size_t on = (size_t)labels[b] * N + n;

@@ -82,6 +82,10 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "sharded", "replicas"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the IST backbone on the main stream")
+    ap.add_argument("--numerics", default="split", choices=["split", "chain"],
+                    help="numerics of `value`: split = 3 x f16 MFMA on split f32 operands (f32-equivalent, DESIGN.md 2); "
+                         "chain = f32-input MFMA fmaf chain (bit-exact vs the CPU oracle).  The other mode is timed too "
+                         "and reported under `other_numerics` (N=1 only).")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -108,19 +112,13 @@ def main():
         model.enable_template_sharding()  # world 1: only meaningful with GIGAPOSE_FORCE_COLLECTIVES=1 (path check)
     tset = factory.TemplateSet(args.objects, args.templates, seed=100)
     model.template_datasets = {"syn": tset}
-    model.set_template_data("syn")  # onboarding: excluded from the timed region (reference gigaPose.py:396-398)
     q = tset.crops(1000 + rank, args.batch, dev)
-    model.pose_recovery["syn"].check_asserts = False  # no host sync inside the timed loop
-    model.overlap_ist = not args.no_overlap
-
-    def step():
-        return model.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
-
-    for _ in range(args.warmup):
-        step()
     lib = _lib.lib()
     lib.gp_prof_kind_name.restype = ctypes.c_char_p
     kinds = 8
+
+    def step():
+        return model.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
 
     def timed(steps, profile):
         if world > 1:
@@ -150,21 +148,37 @@ def main():
                                   unit: round(work[i] / ms[i] / (1e6 if name == "layernorm" else 1e9), 2)}
         return dt, kern
 
-    # (1) THE timed region: K steps, barrier + synchronize on both sides; the library records HIP events
-    #     around every kernel launch on its launch stream (the IST chain runs on a second stream).
-    dt, kern_timed = timed(args.steps, profile=True)
-    # (2) serialized replay of the same K steps (single stream) with the same event instrumentation:
-    #     per-kernel durations free of cross-stream sharing -> the roofline figure of each kernel family
-    if model.overlap_ist:
-        model.overlap_ist = False
-        dt_serial, kern = timed(args.steps, profile=True)
-        model.overlap_ist = True
-    else:
-        dt_serial, kern = dt, kern_timed
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def run_mode(numerics):
+        """Onboard the bank in `numerics`, warm up, time K steps (two-stream region = THE timed region), then replay
+        them on one stream for per-kernel durations free of cross-stream sharing."""
+        model.set_numerics(numerics)
+        model.set_template_data("syn")  # onboarding: excluded from the timed region (reference gigaPose.py:396-398)
+        model.pose_recovery["syn"].check_asserts = False  # no host sync inside the timed loop
+        model.overlap_ist = not args.no_overlap
+        for _ in range(args.warmup):
+            step()
+        dt, kern_timed = timed(args.steps, profile=True)
+        if model.overlap_ist:
+            model.overlap_ist = False
+            dt_serial, kern = timed(args.steps, profile=True)
+            model.overlap_ist = True
+        else:
+            dt_serial, kern = dt, kern_timed
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, dt_serial, kern, kern_timed
+
+    dt, dt_serial, kern, kern_timed = run_mode(args.numerics)
+    other = None
+    if world == 1 and not dist.is_initialized():
+        other_mode = "chain" if args.numerics == "split" else "split"
+        odt, odt_serial, okern, _ = run_mode(other_mode)
+        other = {"numerics": other_mode, "value": round(args.batch * args.steps / odt, 2), "unit": "query-crops/sec",
+                 "ms_per_step": round(1e3 * odt / args.steps, 3), "serial_ms_per_step": round(1e3 * odt_serial / args.steps, 3),
+                 "kernels": okern}
+        model.set_numerics(args.numerics)
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -179,29 +193,49 @@ def main():
             traffic = round(pmc["gemm_kmajor"]["hbm_bytes_per_launch"])
     except Exception:
         pass
-    g = kern.get("gemm_kmajor", {})
-    achieved = g.get("TFLOP/s", 0.0)
-    roofline = {"kernel": "gemm_kmajor_kernel (ViT linear layers + IST MLP; f32-input MFMA 32x32x2)", "bound": "mfma",
-                "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json); algorithmic "
-                                "operand + result bytes per launch: see DESIGN.md section 4",
-                "share_of_step": round(g.get("ms_per_step", 0.0) / (1e3 * dt_serial / args.steps), 3),
-                "measured": "HIP events on the launch stream around every launch, over a single-stream replay of the "
-                            "timed steps (kernels_timed_region: same events inside the timed, two-stream region)",
-                "serial_ms_per_step": round(1e3 * dt_serial / args.steps, 3), "kernels": kern,
-                "kernels_timed_region": {k: v["ms_per_step"] for k, v in kern_timed.items()}}
+    F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
+    if args.numerics == "split":
+        g = kern.get("gemm_split", {})
+        alg = g.get("TFLOP/s", 0.0)
+        achieved = round(3.0 * alg, 2)  # executed on the matrix core: 3 f16 MFMAs per f32-equivalent product block
+        roofline = {"kernel": "gemm_split_kernel (ViT linear layers; 3 x v_mfma_f32_32x32x16_f16 per k-block on f16-split f32 "
+                              "operands, f32 accumulate)", "bound": "mfma", "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / F16_MFMA_PEAK_TFLOPS, 4),
+                    "algorithmic_tflops_f32_equivalent": alg,
+                    "note": "achieved = 3 x algorithmic 2IJK flops / launch time (the three f16 products per f32-equivalent "
+                            "product all execute on the matrix core); the f32-input MFMA peak this mode replaces is 157.3",
+                    "traffic": None}
+    else:
+        g = kern.get("gemm_kmajor", {})
+        achieved = g.get("TFLOP/s", 0.0)
+        roofline = {"kernel": "gemm_kmajor_kernel (ViT linear layers + IST MLP; f32-input MFMA 32x32x2)", "bound": "mfma",
+                    "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic}
+    roofline.update({
+        "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json); algorithmic "
+                        "operand + result bytes per launch: see DESIGN.md section 4",
+        "share_of_step": round(g.get("ms_per_step", 0.0) / (1e3 * dt_serial / args.steps), 3),
+        "measured": "HIP events on the launch stream around every launch, over a single-stream replay of the "
+                    "timed steps (kernels_timed_region: same events inside the timed, two-stream region)",
+        "serial_ms_per_step": round(1e3 * dt_serial / args.steps, 3), "kernels": kern,
+        "kernels_timed_region": {k: v["ms_per_step"] for k, v in kern_timed.items()}})
     out = {
         "metric": "query-crops/sec (ViT feat + template NN + 4DoF regress), 162 templates, 1/2/4/8 GPU",
         "value": round(crops / dt, 2), "unit": "query-crops/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": ("f32 (linear layers + matcher: f32 operands split into f16 hi/lo, 3 x f16 MFMA per k-block, f32 accumulate -- "
+                  "error vs f64 below the f32 fmaf chain's, tests/test_gpu_split.py; everything else f32)"
+                  if args.numerics == "split" else "f32"),
+        "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: {args.variant} random-init, {args.objects} object(s) x {args.templates} templates, "
                                f"batch={args.batch} crops per GPU, k={args.k}, full path ViT->match->IST->RANSAC->pose",
-                   "global_batch": world * args.batch, "parallelism": "single" if world == 1 else f"{mode}{world}",
+                   "numerics": args.numerics, "global_batch": world * args.batch, "parallelism": "single" if world == 1 else f"{mode}{world}",
                    "streams": "ViT+match on stream 0, IST backbone on stream 1" if model.overlap_ist else "single stream"},
         "roofline": roofline,
     }
+    if other is not None:
+        out["other_numerics"] = other
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(args.variant, args.templates, args.k)

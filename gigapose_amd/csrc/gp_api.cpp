@@ -28,7 +28,8 @@ hipEvent_t get_event()
     (void)hipEventCreate(&e);
     return e;
 }
-const char* kKindNames[GP_PROF_KINDS] = {"gemm_kmajor", "match_tiles", "attention", "layernorm", "conv", "other"};
+const char* kKindNames[GP_PROF_KINDS] = {"gemm_kmajor", "match_tiles", "attention", "layernorm", "conv", "other", "gemm_split",
+                                        "match_split"};
 }  // namespace
 
 GpProfScope::GpProfScope(int kind, double work, hipStream_t st) : idx_(-1), st_(st)

@@ -39,7 +39,8 @@ void gp_set_error(const char* fmt, ...);
     } while (0)
 
 // bench-only timing scope: records HIP events around a launch when gp_prof_begin() is active
-enum { GP_PROF_GEMM = 0, GP_PROF_MATCH = 1, GP_PROF_ATTN = 2, GP_PROF_LN = 3, GP_PROF_CONV = 4, GP_PROF_OTHER = 5, GP_PROF_KINDS = 6 };
+enum { GP_PROF_GEMM = 0, GP_PROF_MATCH = 1, GP_PROF_ATTN = 2, GP_PROF_LN = 3, GP_PROF_CONV = 4, GP_PROF_OTHER = 5, GP_PROF_GEMM_SPLIT = 6,
+       GP_PROF_MATCH_SPLIT = 7, GP_PROF_KINDS = 8 };
 struct GpProfScope {
     GpProfScope(int kind, double work, hipStream_t st);
     ~GpProfScope();

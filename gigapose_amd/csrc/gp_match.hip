@@ -52,40 +52,16 @@ struct MatchSmem {
     float maskv[GP_P];
 };
 
-__global__ __launch_bounds__(512, 2) void match_tiles_kernel(
-    const float* __restrict__ query,  // (B, C, 256)   matcher-normalised
-    const float* __restrict__ bank,   // (O, N, C, 256) matcher-normalised
-    const float* __restrict__ qmask,  // (B, 256)
-    const float* __restrict__ bmask,  // (O, N, 256)
-    const int* __restrict__ labels,   // (B) 0-based object index
-    int B, int N, int C, float thr, float patch_thr,
-    uint8_t* __restrict__ idx_t2s,    // (B, N, 256)
-    float* __restrict__ score_t2s,    // (B, N, 256)
-    float* __restrict__ mask_all,     // (B, N, 256)
-    float* __restrict__ sim_avg)      // (B, N)
+// Everything after the 256x256 similarity tile sits in the accumulators (8 waves as 4 (t) x 2 (s), wave tile
+// 64 x 128 = acc[2][4]): masks, threshold, bidirectional argmax, cycle check, template score.  Shared by the
+// f32-chain kernel and the split-f16 kernel (gp_match_split below); SM is the kernel's shared-memory struct.
+template <class SM>
+__device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int b, int n, int N, float thr, float patch_thr,
+                                               uint8_t* __restrict__ idx_t2s, float* __restrict__ score_t2s,
+                                               float* __restrict__ mask_all, float* __restrict__ sim_avg)
 {
-    __shared__ MatchSmem sm;
-    const int q = xcd_chunked_tile(blockIdx.x, B * N);
-    if (q < 0) return;
-    // Tile order: bands of 8 detections, b fastest inside a band, then n.  The 32 tiles an XCD runs concurrently
-    // (one 84 KB workgroup per CU) are then 8 queries x 4 templates: each k-slab of a query is fetched into that
-    // XCD's L2 once per 4 tiles and each template slab once per 8, instead of every query being streamed again
-    // for every template (b fastest over all B: 10.4 GB of fabric reads per launch at B=64, N=162).
-    const int band = q / (8 * N), r8 = q - band * (8 * N);
-    const int gsz = min(8, B - band * 8);
-    const int b = band * 8 + r8 % gsz, n = r8 / gsz;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const size_t on = (size_t)labels[b] * N + n;
-    const float* A = query + (size_t)b * C * GP_P;
-    const float* Bm = bank + on * (size_t)C * GP_P;
-
-    if (tid < GP_P) sm.qmask[tid] = qmask[(size_t)b * GP_P + tid];
-    else sm.smask[tid - GP_P] = bmask[on * GP_P + (tid - GP_P)];
-
-    f32x16 acc[2][4];
-    MM::run(A, GP_P, Bm, GP_P, C, sm.stage, acc);  // ends with __syncthreads(): masks visible
-
     // ---- sim *= src_mask; sim *= tar_mask; sim[sim < thr] = 0   (matching.py:234-236)
     const int s_lane = 128 * wc + (lane & 31);
     const int t_lane = 64 * wr + 4 * (lane >> 5);
@@ -206,6 +182,198 @@ __global__ __launch_bounds__(512, 2) void match_tiles_kernel(
     }
 }
 
+__global__ __launch_bounds__(512, 2) void match_tiles_kernel(
+    const float* __restrict__ query,  // (B, C, 256)   matcher-normalised
+    const float* __restrict__ bank,   // (O, N, C, 256) matcher-normalised
+    const float* __restrict__ qmask,  // (B, 256)
+    const float* __restrict__ bmask,  // (O, N, 256)
+    const int* __restrict__ labels,   // (B) 0-based object index
+    int B, int N, int C, float thr, float patch_thr,
+    uint8_t* __restrict__ idx_t2s,    // (B, N, 256)
+    float* __restrict__ score_t2s,    // (B, N, 256)
+    float* __restrict__ mask_all,     // (B, N, 256)
+    float* __restrict__ sim_avg)      // (B, N)
+{
+    __shared__ MatchSmem sm;
+    const int q = xcd_chunked_tile(blockIdx.x, B * N);
+    if (q < 0) return;
+    // Tile order: bands of 8 detections, b fastest inside a band, then n.  The 32 tiles an XCD runs concurrently
+    // (one 84 KB workgroup per CU) are then 8 queries x 4 templates: each k-slab of a query is fetched into that
+    // XCD's L2 once per 4 tiles and each template slab once per 8, instead of every query being streamed again
+    // for every template (b fastest over all B: 10.4 GB of fabric reads per launch at B=64, N=162).
+    const int band = q / (8 * N), r8 = q - band * (8 * N);
+    const int gsz = min(8, B - band * 8);
+    const int b = band * 8 + r8 % gsz, n = r8 / gsz;
+    const int tid = threadIdx.x;
+    const size_t on = (size_t)labels[b] * N + n;
+    const float* A = query + (size_t)b * C * GP_P;
+    const float* Bm = bank + on * (size_t)C * GP_P;
+
+    if (tid < GP_P) sm.qmask[tid] = qmask[(size_t)b * GP_P + tid];
+    else sm.smask[tid - GP_P] = bmask[on * GP_P + (tid - GP_P)];
+
+    f32x16 acc[2][4];
+    MM::run(A, GP_P, Bm, GP_P, C, sm.stage, acc);  // ends with __syncthreads(): masks visible
+
+    match_epilogue(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg);
+}
+
+// ------------------------------------------------------------------ split-f16 matcher (opt-in numerics)
+// Same tile, same epilogue; the 256x256xC similarity product runs on the f16 matrix core as THREE MFMAs per
+// k-block (gp_split.hip explains the split): both operands arrive PRE-SPLIT as f16 planes [patch][C] (channel
+// contiguous), scaled by 32 so that the low halves of unit-vector components stay in f16's normal range; the
+// three products go into ONE f32 accumulator and the tile is rescaled by the exact factor 2^-10 before the
+// epilogue.  LDS: two buffers of 4 planes x 256 rows x 64 B (k-step 32), 16-byte chunks XOR-swizzled by
+// (row >> 2) & 3 so that every ds_read_b128 lane group touches all 64 banks once.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+constexpr float kFeatScale = 32.0f;
+constexpr int MS_BK = 32, MS_PLANE = 256 * MS_BK;  // halfs per plane per buffer
+
+struct MatchSplitSmem {
+    _Float16 stage[2 * 4 * MS_PLANE];  // 128 KiB
+    float qmask[GP_P];
+    float smask[GP_P];
+    float rowv[2][GP_P];
+    int rowi[2][GP_P];
+    float colv[4][GP_P];
+    int coli[4][GP_P];
+    float sc_t2s[GP_P];
+    int id_t2s[GP_P];
+    float sc_s2t[GP_P];
+    int id_s2t[GP_P];
+    float contrib[GP_P];
+    float maskv[GP_P];
+};
+
+__global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
+    const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo,  // (B, 256, C)
+    const _Float16* __restrict__ b_hi, const _Float16* __restrict__ b_lo,  // (O*N, 256, C)
+    const float* __restrict__ qmask, const float* __restrict__ bmask, const int* __restrict__ labels, int B, int N, int C,
+    float thr, float patch_thr, uint8_t* __restrict__ idx_t2s, float* __restrict__ score_t2s, float* __restrict__ mask_all,
+    float* __restrict__ sim_avg)
+{
+    __shared__ MatchSplitSmem sm;
+    const int q = xcd_chunked_tile(blockIdx.x, B * N);
+    if (q < 0) return;
+    const int band = q / (8 * N), r8 = q - band * (8 * N);
+    const int gsz = min(8, B - band * 8);
+    const int b = band * 8 + r8 % gsz, n = r8 / gsz;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const size_t on = (size_t)labels[b] * N + n;
+    if (tid < GP_P) sm.qmask[tid] = qmask[(size_t)b * GP_P + tid];
+    else sm.smask[tid - GP_P] = bmask[on * GP_P + (tid - GP_P)];
+
+    // staging: chunk c = tid + 512 u (u < 8): plane c >> 10 (q_hi, q_lo, b_hi, b_lo), row (c & 1023) >> 2, k-chunk c & 3
+    const _Float16* src[4] = {q_hi + (size_t)b * GP_P * C, q_lo + (size_t)b * GP_P * C, b_hi + on * GP_P * C, b_lo + on * GP_P * C};
+    h16x8 rg[8];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = tid + 512 * u, row = (c & 1023) >> 2, kc = c & 3;
+            rg[u] = *reinterpret_cast<const h16x8*>(src[u >> 1] + (size_t)row * C + k0 + kc * 8);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = tid + 512 * u, row = (c & 1023) >> 2, kc = c & 3;
+            *reinterpret_cast<h16x8*>(sm.stage + (buf * 4 + (u >> 1)) * MS_PLANE + row * MS_BK + ((kc ^ ((row >> 2) & 3)) * 8)) = rg[u];
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int nstep = C / MS_BK;
+    gload(0);
+    stage(0);
+    __syncthreads();
+    const int l31 = lane & 31, kh = lane >> 5;
+    for (int s = 0; s < nstep; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstep) gload((s + 1) * MS_BK);
+        const _Float16* L = sm.stage + buf * 4 * MS_PLANE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kc = 2 * ks + kh;  // this lane's 8-k chunk inside the 32-k slab
+            h16x8 ah[2], al[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row = 64 * wr + 32 * mi + l31;
+                const int off = row * MS_BK + ((kc ^ ((row >> 2) & 3)) * 8);
+                ah[mi] = *reinterpret_cast<const h16x8*>(L + 0 * MS_PLANE + off);
+                al[mi] = *reinterpret_cast<const h16x8*>(L + 1 * MS_PLANE + off);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int row = 128 * wc + 32 * ni + l31;
+                const int off = row * MS_BK + ((kc ^ ((row >> 2) & 3)) * 8);
+                const h16x8 bh = *reinterpret_cast<const h16x8*>(L + 2 * MS_PLANE + off);
+                const h16x8 bl = *reinterpret_cast<const h16x8*>(L + 3 * MS_PLANE + off);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+                }
+            }
+        }
+        if (s + 1 < nstep) stage(buf ^ 1);
+        __syncthreads();
+    }
+    constexpr float inv = 1.0f / (kFeatScale * kFeatScale);  // exact power of two
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= inv;
+    match_epilogue(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg);
+}
+
+// norms of gp_l2norm_cp (same sequential fma over c), then x / d * 32 split into f16 planes [row][patch][C]
+__global__ __launch_bounds__(256) void l2norm_split_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
+                                                            _Float16* __restrict__ lo, int C, int Cp)
+{
+    __shared__ float t[32][GP_P + 1];
+    __shared__ float dn[GP_P];
+    const int row = blockIdx.x, p = threadIdx.x;
+    const float* xr = x + (size_t)row * C * GP_P;
+    float ss = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float v = xr[(size_t)c * GP_P + p];
+        ss = __builtin_fmaf(v, v, ss);
+    }
+    dn[p] = fmaxf(__builtin_sqrtf(ss), 1e-12f);
+    for (int c0 = 0; c0 < Cp; c0 += 32) {  // Cp = round_up(C, 32): the planes are zero-padded along C
+        __syncthreads();
+        for (int r = 0; r < 32; ++r) t[r][p] = (c0 + r < C) ? xr[(size_t)(c0 + r) * GP_P + p] : 0.f;  // coalesced along p
+        __syncthreads();
+        // thread -> (patch pp, 8-channel group g): 256 patches x 4 groups = 1024 items, 4 per thread
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int item = p + 256 * u, pp = item >> 2, g = item & 3;
+            h16x8 h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = (t[g * 8 + e][pp] / dn[pp]) * kFeatScale;
+                const _Float16 hh = (_Float16)v;
+                h[e] = hh;
+                l[e] = (_Float16)(v - (float)hh);
+            }
+            const size_t o = ((size_t)row * GP_P + pp) * Cp + c0 + g * 8;
+            *reinterpret_cast<h16x8*>(hi + o) = h;
+            *reinterpret_cast<h16x8*>(lo + o) = l;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ top-k per detection
 // One wave per detection.  Order: higher score, then lower template index (torch.topk leaves
 // ties unspecified; the oracle uses the same rule).
@@ -299,6 +467,35 @@ int gp_match_tiles(const float* query, const float* bank, const float* qmask, co
                        (hipStream_t)stream, query, bank, qmask, bmask, labels, B, N, C, sim_threshold,
                        patch_threshold, idx_t2s, score_t2s, mask_all, sim_avg);
     GP_CHECK_LAUNCH("gp_match_tiles");
+    return GP_OK;
+}
+
+int gp_l2norm_split(const float* x, void* hi, void* lo, int rows, int C, void* stream)
+{
+    GP_REQUIRE(rows >= 0 && C > 0, "gp_l2norm_split: bad arguments (rows=%d C=%d)", rows, C);
+    if (rows == 0) return GP_OK;
+    GP_REQUIRE(x && hi && lo, "gp_l2norm_split: null pointer");
+    hipLaunchKernelGGL(l2norm_split_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)hi, (_Float16*)lo, C,
+                       (C + 31) / 32 * 32);
+    GP_CHECK_LAUNCH("gp_l2norm_split");
+    return GP_OK;
+}
+
+int gp_match_tiles_split(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
+                         const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
+                         float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
+                         void* stream)
+{
+    GP_REQUIRE(B >= 0 && O > 0 && N > 0, "gp_match_tiles_split: bad sizes B=%d O=%d N=%d", B, O, N);
+    GP_REQUIRE(C > 0 && C % 32 == 0, "gp_match_tiles_split: C=%d must be a positive multiple of 32", C);
+    if (B == 0) return GP_OK;
+    GP_REQUIRE(q_hi && q_lo && b_hi && b_lo && qmask && bmask && labels && idx_t2s && score_t2s && mask_all && sim_avg,
+               "gp_match_tiles_split: null pointer");
+    GpProfScope prof(GP_PROF_MATCH_SPLIT, 2.0 * B * N * 256.0 * 256.0 * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(match_tiles_split_kernel, dim3(xcd_chunked_grid(B * N)), dim3(512), 0, (hipStream_t)stream,
+                       (const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)b_hi, (const _Float16*)b_lo, qmask,
+                       bmask, labels, B, N, C, sim_threshold, patch_threshold, idx_t2s, score_t2s, mask_all, sim_avg);
+    GP_CHECK_LAUNCH("gp_match_tiles_split");
     return GP_OK;
 }
 

@@ -1,0 +1,264 @@
+// "f32-equivalent" dense contraction on the f16 matrix core (gfx950): every f32 operand x is split into two
+// halves  x ~= hi + lo * 2^-11,  hi = f16(x),  lo = f16((x - hi) * 2^11)   (22-23 significant bits), and
+//     sum_k a_k b_k  ~=  sum_k ahi*bhi  +  2^-11 * sum_k (ahi*blo + alo*bhi)
+// runs as THREE v_mfma_f32_32x32x16_f16 per k-block with f32 accumulation (the two sums in separate
+// accumulators).  The f16 products are exact in f32, so the only errors are the 2^-22-relative representation
+// error per term and the dropped lo*lo term (2^-22) -- the same class as the rounding of an f32 fmaf chain.
+// Throughput: 3/16 of the f32-input MFMA's time per flop (f16 MFMA is 16x the f32 MFMA rate).
+//
+// This is the OPT-IN fast mode of the ViT linear layers (GigaPose numerics contract: DESIGN.md section 2): results
+// are NOT bit-identical to the fmaf-chain kernels of gp_gemm.hip (which stay the default and the parity path);
+// tests/test_gpu_split.py bounds the difference against an f64 reference next to the exact kernel's own error.
+//
+// Layouts: same as gp_gemm.hip on the outside -- activations f32 k-major X[K][n] (converted while staging),
+// result f32 D[I][ldd] -- plus PRE-SPLIT weights: gp_split_weights() turns W^T [K][n] f32 into two f16 planes
+// [n][K] (k contiguous: the MFMA operand is 8 consecutive k per lane).
+#include "gp_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
+
+__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)x;
+    lo = (_Float16)((x - (float)hi) * kLoScale);
+}
+
+// W^T [K][n] f32 (k-major) -> hi/lo [n][K] f16.  One 32x32 tile per block through LDS (coalesced both ways).
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ Wt, int K, int n, int ldw,
+                                                             _Float16* __restrict__ hi, _Float16* __restrict__ lo)
+{
+    __shared__ float t[32][33];
+    const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) t[r][tx] = (k0 + r < K && n0 + tx < n) ? Wt[(size_t)(k0 + r) * ldw + n0 + tx] : 0.f;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        if (n0 + r < n && k0 + tx < K) {
+            _Float16 h, l;
+            split1(t[tx][r], h, l);
+            hi[(size_t)(n0 + r) * K + k0 + tx] = h;
+            lo[(size_t)(n0 + r) * K + k0 + tx] = l;
+        }
+    }
+}
+
+enum { SEPI_NONE = 0, SEPI_BIAS_I = 1, SEPI_BIAS_I_GELU = 2, SEPI_BIAS_I_SCALE_RES = 3, SEPI_BIAS_J = 4, SEPI_BIAS_I_RELU = 5 };
+
+constexpr int SBM = 128, SBN = 128, SBK = 32, SNT = 256;
+constexpr int SROW = 40;                       // halfs per LDS row: 32 data + 8 pad (80 B: conflict-free ds_read_b128)
+constexpr int SPLANE = 128 * SROW;             // halfs per (operand, hi|lo) plane
+constexpr int SBUF = 4 * SPLANE;               // A hi, A lo, B hi, B lo
+constexpr int SLDS_BYTES = 2 * SBUF * 2;       // double buffered: 81920 B
+
+struct SplitArgs {
+    const float* act;  int ld_act;             // activations f32 k-major [K][ld_act]
+    const _Float16* whi; const _Float16* wlo;  // pre-split weights [n][K]
+    float* D; int ldd; int K;
+    const float* bias; const float* scale; const float* res; int ldr;
+    int tiles_i, tiles_j, group;
+};
+
+__device__ __forceinline__ float gelu_erf_s(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ACT_IS_B: activations are the j operand (D = W . X: qk / proj / fc1 / fc2); else the i operand (token-major V).
+template <int EPI, bool ACT_IS_B>
+__global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, 64 x 64 each
+    const int q = xcd_chunked_tile(blockIdx.x, a.tiles_i * a.tiles_j);
+    if (q < 0) return;
+    const int per_band = a.group * a.tiles_j;
+    const int band = q / per_band, rr = q - band * per_band;
+    const int first_i = band * a.group;
+    const int gsz = min(a.group, a.tiles_i - first_i);
+    const int i0 = (first_i + rr % gsz) * SBM, j0 = (rr / gsz) * SBN;
+    const int n_act0 = ACT_IS_B ? j0 : i0, n_w0 = ACT_IS_B ? i0 : j0;
+    // plane offsets (halfs) inside one buffer
+    constexpr int P_AHI = 0, P_ALO = SPLANE, P_BHI = 2 * SPLANE, P_BLO = 3 * SPLANE;
+    const int act_hi = ACT_IS_B ? P_BHI : P_AHI, act_lo = ACT_IS_B ? P_BLO : P_ALO;
+    const int w_hi = ACT_IS_B ? P_AHI : P_BHI, w_lo = ACT_IS_B ? P_ALO : P_BLO;
+
+    // staging roles: waves 0-1 convert the activation tile (4 n x 8 k micro-block per thread), waves 2-3 copy the
+    // pre-split weight tile (8 x 16-byte chunks per thread)
+    const bool act_role = tid < 128;
+    const int t7 = tid & 127;
+    f32x4 ract[8];   // activation role: rows k = kg*8 .. +7, columns n = ng*4 .. +3
+    f16x8 rw[8];     // weight role: chunk c = t7 + 128*u: plane (c >> 9), row (c & 511) >> 2, k-chunk c & 3
+    const int ng = t7 & 31, kg = t7 >> 5;
+    auto gload = [&](int k0) {
+        if (act_role) {
+            const float* src = a.act + (size_t)(k0 + kg * 8) * a.ld_act + n_act0 + ng * 4;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) ract[r] = *reinterpret_cast<const f32x4*>(src + (size_t)r * a.ld_act);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = t7 + 128 * u;
+                const int row = (c & 511) >> 2, kc = c & 3;
+                const _Float16* base = (c >> 9) ? a.wlo : a.whi;
+                rw[u] = *reinterpret_cast<const f16x8*>(base + (size_t)(n_w0 + row) * a.K + k0 + kc * 8);
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+        _Float16* L = lds + buf * SBUF;
+        if (act_role) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {  // column n = ng*4 + c: 8 consecutive k
+                f16x8 h, l;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    _Float16 hh, ll;
+                    split1(ract[r][c], hh, ll);
+                    h[r] = hh;
+                    l[r] = ll;
+                }
+                const int off = (ng * 4 + c) * SROW + kg * 8;
+                *reinterpret_cast<f16x8*>(L + act_hi + off) = h;
+                *reinterpret_cast<f16x8*>(L + act_lo + off) = l;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = t7 + 128 * u;
+                const int row = (c & 511) >> 2, kc = c & 3;
+                *reinterpret_cast<f16x8*>(L + ((c >> 9) ? w_lo : w_hi) + row * SROW + kc * 8) = rw[u];
+            }
+        }
+    };
+
+    f32x16 hh[2][2], xx[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { hh[mi][ni][r] = 0.f; xx[mi][ni][r] = 0.f; }
+
+    const int nstep = a.K / SBK;
+    gload(0);
+    stage(0);
+    __syncthreads();
+    const int arow = (wm * 64 + (lane & 31)) * SROW + (lane >> 5) * 8;
+    const int brow = (wn * 64 + (lane & 31)) * SROW + (lane >> 5) * 8;
+    for (int s = 0; s < nstep; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstep) gload((s + 1) * SBK);
+        const _Float16* L = lds + buf * SBUF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {  // two k16 blocks per staged slab
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                ah[mi] = *reinterpret_cast<const f16x8*>(L + P_AHI + arow + mi * 32 * SROW + ks * 16);
+                al[mi] = *reinterpret_cast<const f16x8*>(L + P_ALO + arow + mi * 32 * SROW + ks * 16);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                bh[ni] = *reinterpret_cast<const f16x8*>(L + P_BHI + brow + ni * 32 * SROW + ks * 16);
+                bl[ni] = *reinterpret_cast<const f16x8*>(L + P_BLO + brow + ni * 32 * SROW + ks * 16);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    hh[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], hh[mi][ni], 0, 0, 0);
+                    xx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], xx[mi][ni], 0, 0, 0);
+                    xx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], xx[mi][ni], 0, 0, 0);
+                }
+        }
+        if (s + 1 < nstep) stage(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int j = j0 + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + wm * 64 + mi * 32 + frag_row(r, lane);
+                float v = hh[mi][ni][r] + xx[mi][ni][r] * kLoInv;
+                if (EPI == SEPI_BIAS_I || EPI == SEPI_BIAS_I_GELU || EPI == SEPI_BIAS_I_SCALE_RES || EPI == SEPI_BIAS_I_RELU)
+                    v = v + a.bias[i];
+                if (EPI == SEPI_BIAS_J) v = v + a.bias[j];
+                if (EPI == SEPI_BIAS_I_GELU) v = gelu_erf_s(v);
+                if (EPI == SEPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
+                if (EPI == SEPI_BIAS_I_SCALE_RES) v = a.res[(unsigned)i * (unsigned)a.ldr + (unsigned)j] + a.scale[i] * v;
+                a.D[(unsigned)i * (unsigned)a.ldd + (unsigned)j] = v;
+            }
+        }
+}
+
+template <int EPI>
+void launch_split(const SplitArgs& a, bool act_is_b, hipStream_t st)
+{
+    const int grid = xcd_chunked_grid(a.tiles_i * a.tiles_j);
+    if (act_is_b) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<EPI, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SLDS_BYTES);
+        hipLaunchKernelGGL((gemm_split_kernel<EPI, true>), dim3(grid), dim3(SNT), SLDS_BYTES, st, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<EPI, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SLDS_BYTES);
+        hipLaunchKernelGGL((gemm_split_kernel<EPI, false>), dim3(grid), dim3(SNT), SLDS_BYTES, st, a);
+    }
+}
+
+}  // namespace
+
+// internal entry (gp_vit.hip).  act: f32 k-major activations [K][ld_act]; whi/wlo: pre-split weights [n_w][K].
+// act_is_b: D[i][j] = sum_k W[i][k] X[k][j]  (weights index i); else D[i][j] = sum_k X[k][i] W[j][k].
+int gp_gemm_split_launch(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J,
+                         int K, int act_is_b, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
+                         hipStream_t st)
+{
+    GP_REQUIRE(I > 0 && J > 0 && K > 0 && I % SBM == 0 && J % SBN == 0 && K % SBK == 0,
+               "gp_gemm_split: I=%d, J=%d must be multiples of 128 and K=%d of 32", I, J, K);
+    GP_REQUIRE(act && whi && wlo && D && ld_act % 4 == 0 && ((uintptr_t)act % 16 == 0) && ((uintptr_t)whi % 16 == 0) &&
+                   ((uintptr_t)wlo % 16 == 0),
+               "gp_gemm_split: null / misaligned operand");
+    GP_REQUIRE((long long)I * ldd < (1ll << 31) && (long long)I * (ldr > 0 ? ldr : 1) < (1ll << 31), "gp_gemm_split: output too large");
+    SplitArgs a{act, ld_act, (const _Float16*)whi, (const _Float16*)wlo, D, ldd, K, bias, scale, res, ldr, I / SBM, J / SBN, 8};
+    GpProfScope prof(GP_PROF_GEMM_SPLIT, 2.0 * I * J * K, st);  // algorithmic flops (the kernel executes 3x as f16 MFMAs)
+    switch (epilogue) {
+        case SEPI_NONE: launch_split<SEPI_NONE>(a, act_is_b != 0, st); break;
+        case SEPI_BIAS_I: launch_split<SEPI_BIAS_I>(a, act_is_b != 0, st); break;
+        case SEPI_BIAS_I_GELU: launch_split<SEPI_BIAS_I_GELU>(a, act_is_b != 0, st); break;
+        case SEPI_BIAS_I_SCALE_RES: launch_split<SEPI_BIAS_I_SCALE_RES>(a, act_is_b != 0, st); break;
+        case SEPI_BIAS_J: launch_split<SEPI_BIAS_J>(a, act_is_b != 0, st); break;
+        case SEPI_BIAS_I_RELU: launch_split<SEPI_BIAS_I_RELU>(a, act_is_b != 0, st); break;
+        default: GP_REQUIRE(false, "gp_gemm_split: unknown epilogue %d", epilogue);
+    }
+    GP_CHECK_LAUNCH("gp_gemm_split");
+    return GP_OK;
+}
+
+extern "C" {
+
+int gp_split_weights(const float* Wt, int K, int n, int ldw, void* hi, void* lo, void* stream)
+{
+    GP_REQUIRE(Wt && hi && lo && K > 0 && n > 0 && ldw >= n, "gp_split_weights: bad arguments");
+    hipLaunchKernelGGL(split_weights_kernel, dim3((n + 31) / 32, (K + 31) / 32), dim3(256), 0, (hipStream_t)stream, Wt, K, n,
+                       ldw, (_Float16*)hi, (_Float16*)lo);
+    GP_CHECK_LAUNCH("gp_split_weights");
+    return GP_OK;
+}
+
+int gp_gemm_split(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J, int K,
+                  int act_is_b, int epilogue, const float* bias, const float* scale, const float* residual, int ldr,
+                  void* stream)
+{
+    return gp_gemm_split_launch(act, ld_act, whi, wlo, D, ldd, I, J, K, act_is_b, epilogue, bias, scale, residual, ldr,
+                                (hipStream_t)stream);
+}
+
+}  // extern "C"

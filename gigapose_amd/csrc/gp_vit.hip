@@ -14,6 +14,9 @@
 int gp_gemm_launch(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J,
                    int K, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
                    float* sk_ws, hipStream_t st);
+int gp_gemm_split_launch(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J,
+                         int K, int act_is_b, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
+                         hipStream_t st);
 size_t gp_gemm_streamk_bytes();
 int gp_gemm_streamk_reset_launch(float* sk_ws, hipStream_t st);
 
@@ -268,9 +271,26 @@ size_t gp_vit_workspace_bytes(int B, int dim, int mlp_dim)
     return sizeof(float) * ((size_t)5 * dim * Mpad + f) + gp_gemm_streamk_bytes();
 }
 
+// per-layer table of pre-split weight planes (f16 hi / lo, PyTorch-native [out][in]) for the split-f16 mode
+enum { S_QK_HI = 0, S_QK_LO, S_V_HI, S_V_LO, S_PROJ_HI, S_PROJ_LO, S_FC1_HI, S_FC1_LO, S_FC2_HI, S_FC2_LO, S_PER_LAYER = 10 };
+
+int gp_vit_forward_split(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
+                         const float* const* weights, int n_weights, const void* const* split, int n_split,
+                         float* workspace, size_t workspace_bytes, float* out_features, int normalize,
+                         int stop_after_layers, void* stream);
+
 int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                    const float* const* weights, int n_weights, float* workspace, size_t workspace_bytes,
                    float* out_features, int normalize, int stop_after_layers, void* stream)
+{
+    return gp_vit_forward_split(images, B, dim, depth, heads, mlp_dim, ln_eps, weights, n_weights, nullptr, 0, workspace,
+                                workspace_bytes, out_features, normalize, stop_after_layers, stream);
+}
+
+int gp_vit_forward_split(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
+                         const float* const* weights, int n_weights, const void* const* split, int n_split,
+                         float* workspace, size_t workspace_bytes, float* out_features, int normalize,
+                         int stop_after_layers, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
     GP_REQUIRE(B >= 0 && dim > 0 && depth > 0 && heads > 0, "gp_vit_forward: bad config");
@@ -282,6 +302,12 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
     GP_REQUIRE(images && weights && workspace && out_features, "gp_vit_forward: null pointer");
     GP_REQUIRE(workspace_bytes >= gp_vit_workspace_bytes(B, dim, mlp_dim), "gp_vit_forward: workspace too small");
     for (int i = 0; i < n_weights; ++i) GP_REQUIRE(weights[i], "gp_vit_forward: weight pointer %d is null", i);
+    GP_REQUIRE(split == nullptr || n_split == depth * S_PER_LAYER, "gp_vit_forward_split: expected %d split planes, got %d",
+               depth * S_PER_LAYER, n_split);
+    if (split) {
+        GP_REQUIRE(dim % 32 == 0 && mlp_dim % 32 == 0, "gp_vit_forward_split: dim / mlp_dim must be multiples of 32");
+        for (int i = 0; i < n_split; ++i) GP_REQUIRE(split[i], "gp_vit_forward_split: split plane %d is null", i);
+    }
 
     const int C = dim, Mpad = round_up(B * T_TOK, 128), BP = B * GP_P;
     float* X = workspace;
@@ -312,14 +338,17 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
         const float* const* w = weights + W_HEADER + l * L_PER_LAYER;
         launch_layernorm(X, Hn, w[L_LN1_G], w[L_LN1_B], C, Mpad, ln_eps, st);
         GP_CHECK_LAUNCH("gp_vit_forward/layernorm");
+        const void* const* sp = split ? split + l * S_PER_LAYER : nullptr;
         // Q,K channel-major [2C][Mpad]
-        if ((rc = gp_gemm_launch(w[L_QK_WT], 2 * C, Hn, Mpad, QK, Mpad, 2 * C, Mpad, C, 1, w[L_QK_B], nullptr,
-                                 nullptr, 0, SK, st)))
-            return rc;
+        if (sp) rc = gp_gemm_split_launch(Hn, Mpad, sp[S_QK_HI], sp[S_QK_LO], QK, Mpad, 2 * C, Mpad, C, 1, 1, w[L_QK_B],
+                                          nullptr, nullptr, 0, st);
+        else rc = gp_gemm_launch(w[L_QK_WT], 2 * C, Hn, Mpad, QK, Mpad, 2 * C, Mpad, C, 1, w[L_QK_B], nullptr, nullptr, 0, SK, st);
+        if (rc) return rc;
         // V token-major [Mpad][C]: swap operand roles (A = activations, B = weights), bias along j
-        if ((rc = gp_gemm_launch(Hn, Mpad, w[L_V_WT], C, Vt, C, Mpad, C, C, 4 /*BIAS_J*/, w[L_V_B], nullptr,
-                                 nullptr, 0, SK, st)))
-            return rc;
+        if (sp) rc = gp_gemm_split_launch(Hn, Mpad, sp[S_V_HI], sp[S_V_LO], Vt, C, Mpad, C, C, 0, 4 /*BIAS_J*/, w[L_V_B],
+                                          nullptr, nullptr, 0, st);
+        else rc = gp_gemm_launch(Hn, Mpad, w[L_V_WT], C, Vt, C, Mpad, C, C, 4 /*BIAS_J*/, w[L_V_B], nullptr, nullptr, 0, SK, st);
+        if (rc) return rc;
         {
             GpProfScope prof(GP_PROF_ATTN, 4.0 * B * heads * 257.0 * 257.0 * 64.0, st);
             hipLaunchKernelGGL(attention_kernel, dim3(xcd_chunked_grid(B * heads * NKT)), dim3(64), 0, st, QK, Vt,
@@ -327,18 +356,22 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
         }
         GP_CHECK_LAUNCH("gp_vit_forward/attention");
         // x = x + ls1 * proj(attn)
-        if ((rc = gp_gemm_launch(w[L_PROJ_WT], C, Hn, Mpad, X, Mpad, C, Mpad, C, 3, w[L_PROJ_B], w[L_LS1], X, Mpad,
-                                 SK, st)))
-            return rc;
+        if (sp) rc = gp_gemm_split_launch(Hn, Mpad, sp[S_PROJ_HI], sp[S_PROJ_LO], X, Mpad, C, Mpad, C, 1, 3, w[L_PROJ_B],
+                                          w[L_LS1], X, Mpad, st);
+        else rc = gp_gemm_launch(w[L_PROJ_WT], C, Hn, Mpad, X, Mpad, C, Mpad, C, 3, w[L_PROJ_B], w[L_LS1], X, Mpad, SK, st);
+        if (rc) return rc;
         launch_layernorm(X, Hn, w[L_LN2_G], w[L_LN2_B], C, Mpad, ln_eps, st);
         GP_CHECK_LAUNCH("gp_vit_forward/layernorm");
-        if ((rc = gp_gemm_launch(w[L_FC1_WT], mlp_dim, Hn, Mpad, F, Mpad, mlp_dim, Mpad, C, 2 /*GELU*/, w[L_FC1_B],
-                                 nullptr, nullptr, 0, SK, st)))
-            return rc;
+        if (sp) rc = gp_gemm_split_launch(Hn, Mpad, sp[S_FC1_HI], sp[S_FC1_LO], F, Mpad, mlp_dim, Mpad, C, 1, 2 /*GELU*/,
+                                          w[L_FC1_B], nullptr, nullptr, 0, st);
+        else rc = gp_gemm_launch(w[L_FC1_WT], mlp_dim, Hn, Mpad, F, Mpad, mlp_dim, Mpad, C, 2 /*GELU*/, w[L_FC1_B], nullptr,
+                                 nullptr, 0, SK, st);
+        if (rc) return rc;
         // x = x + ls2 * fc2(gelu(fc1))
-        if ((rc = gp_gemm_launch(w[L_FC2_WT], C, F, Mpad, X, Mpad, C, Mpad, mlp_dim, 3, w[L_FC2_B], w[L_LS2], X,
-                                 Mpad, SK, st)))
-            return rc;
+        if (sp) rc = gp_gemm_split_launch(F, Mpad, sp[S_FC2_HI], sp[S_FC2_LO], X, Mpad, C, Mpad, mlp_dim, 1, 3, w[L_FC2_B],
+                                          w[L_LS2], X, Mpad, st);
+        else rc = gp_gemm_launch(w[L_FC2_WT], C, F, Mpad, X, Mpad, C, Mpad, mlp_dim, 3, w[L_FC2_B], w[L_LS2], X, Mpad, SK, st);
+        if (rc) return rc;
     }
     hipLaunchKernelGGL(features_kernel, dim3(B), dim3(256), 0, st, X, out_features, C, Mpad, normalize);
     GP_CHECK_LAUNCH("gp_vit_forward/features");

@@ -72,6 +72,15 @@ class GigaPose(_Base):
         self.overlap_ist = True       # run the IST backbone on a side stream, concurrently with ViT + matching
         self._side_stream = None
 
+    def set_numerics(self, mode):
+        """"chain": f32 fmaf-chain kernels (bit-exact vs the CPU oracle; default).  "split": the ViT linear layers and
+        the template matcher run as 3 x f16 MFMA on split operands (f32-equivalent accuracy).
+        Call before set_template_data (the bank is stored in the matcher's format)."""
+        self.ae_net.dinov2_model.set_numerics(mode)
+        self.testing_metric.numerics = mode
+        self.template_datas, self.match_banks, self.pose_recovery = {}, {}, {}
+        return self
+
     def enable_template_sharding(self, group=None):
         """Shard the template bank over the ranks of `group` (gigapose_amd/sharding.py).  Call
         before set_template_data; every rank must then call predict() with the same batch size."""
@@ -104,9 +113,9 @@ class GigaPose(_Base):
         data = {n: torch.stack(v, dim=0) for n, v in cols.items()}
         self.template_datas[dataset_name] = PandasTensorCollection(infos=pd.DataFrame(), **data)
         if self.template_shard is None:
-            self.match_banks[dataset_name] = MatchBank(data["ae_features"], data["mask"])
+            self.match_banks[dataset_name] = MatchBank(data["ae_features"], data["mask"], self.testing_metric.numerics)
         else:  # the matcher bank holds only this rank's slice of every object's templates
-            shard = MatchBank(data["ae_features"], data["mask"][:, lo:hi].contiguous())
+            shard = MatchBank(data["ae_features"], data["mask"][:, lo:hi].contiguous(), self.testing_metric.numerics)
             self.match_banks[dataset_name] = ShardedMatcher(self.testing_metric, shard, lo, group)
         self.pose_recovery[dataset_name] = ObjectPoseRecovery(template_K=data["K"], template_Ms=data["M"],
                                                               template_poses=data["poses"])

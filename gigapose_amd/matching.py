@@ -11,6 +11,8 @@ gp_gather_records, gp_format_points); torch only owns the buffers.  The fast pat
 so the reference's 170 MB/detection gather `ae_features[label-1]` (gigaPose.py:520) and its
 per-batch re-normalisation of the bank (matching.py:229) disappear.
 """
+import os
+
 import pandas as pd
 import torch
 
@@ -28,17 +30,40 @@ def patch_grid_mask(mask224):
     return m.reshape(*m.shape[:-2], P).contiguous()
 
 
+def default_numerics():
+    """"chain" (f32 fmaf chain, bit-exact vs the CPU oracle) or "split" (3 x f16 MFMA, f32-equivalent)."""
+    return os.environ.get("GIGAPOSE_NUMERICS", "chain")
+
+
+def normalize_split(feats):
+    """(rows, C, 256) f32 -> matcher-normalised, x32, split into f16 planes (hi, lo), each (rows, 256, Cp) with
+    Cp = round_up(C, 32) (zero padded: the split matcher consumes 32 channels per step)."""
+    rows, C = feats.shape[:2]
+    x = feats.reshape(rows, C, P).contiguous().float()
+    hi = torch.empty(rows, P, (C + 31) // 32 * 32, dtype=torch.float16, device=x.device)
+    lo = torch.empty_like(hi)
+    _lib.call("gp_l2norm_split", _lib.ptr(x), _lib.ptr(hi), _lib.ptr(lo), _lib.i(rows), _lib.i(C), _lib.stream_ptr())
+    return hi, lo
+
+
 class MatchBank:
     """Matcher-ready template bank: twice-normalised features (AENet's F.normalize, then the
-    matcher's own, matching.py:229) as (O,N,C,256) f32 and patch masks (O,N,256)."""
+    matcher's own, matching.py:229) and patch masks (O,N,256).  numerics "chain": features (O,N,C,256) f32;
+    "split": f16 planes hi / lo (O,N,256,C) of the same normalised values x 32 (same bytes per template)."""
 
-    def __init__(self, ae_features, masks224):
+    def __init__(self, ae_features, masks224, numerics=None):
+        self.numerics = numerics or default_numerics()
         O, N, C = ae_features.shape[:3]
         feats = ae_features.reshape(O * N, C, P).contiguous().float()
-        self.features = torch.empty_like(feats)
-        _lib.call("gp_l2norm_cp", _lib.ptr(feats), _lib.ptr(self.features), _lib.i(O * N), _lib.i(C),
-                  _lib.stream_ptr())
-        self.features = self.features.view(O, N, C, P)
+        self.features = self.hi = self.lo = None
+        if self.numerics == "split":
+            hi, lo = normalize_split(feats)
+            self.hi, self.lo = hi.view(O, N, P, -1), lo.view(O, N, P, -1)
+        else:
+            self.features = torch.empty_like(feats)
+            _lib.call("gp_l2norm_cp", _lib.ptr(feats), _lib.ptr(self.features), _lib.i(O * N), _lib.i(C),
+                      _lib.stream_ptr())
+            self.features = self.features.view(O, N, C, P)
         self.masks = patch_grid_mask(masks224)
         self.O, self.N, self.C = O, N, C
 
@@ -55,6 +80,7 @@ class LocalSimilarity(torch.nn.Module):
         self.patch_threshold = patch_threshold
         self.search_direction = search_direction
         self.num_patches = image_size // patch_size
+        self.numerics = default_numerics()
         if patch_threshold <= 0:
             raise NotImplementedError("patch_threshold must be > 0 (reference default 3; <= 0 disables the "
                                       "cycle check in the reference, which is not built)")
@@ -63,7 +89,10 @@ class LocalSimilarity(torch.nn.Module):
 
     # ---- kernel-level stages (also used by the template-sharded multi-GPU path) -----------
     def normalize(self, feats):
-        """(rows, C, 16, 16) or (rows, C, 256) -> matcher-normalised (rows, C, 256)."""
+        """(rows, C, 16, 16) or (rows, C, 256) -> matcher-normalised (rows, C, 256) f32 ("chain") or the
+        (hi, lo) f16 planes (rows, 256, C) of the split numerics."""
+        if self.numerics == "split":
+            return normalize_split(feats.reshape(feats.shape[0], feats.shape[1], P))
         rows, C = feats.shape[:2]
         x = feats.reshape(rows, C, P).contiguous().float()
         out = torch.empty_like(x)
@@ -74,13 +103,22 @@ class LocalSimilarity(torch.nn.Module):
         """All (detection, template) tiles.  query (B,C,256) normalised, qmask (B,256),
         bank: MatchBank, labels0 (B,) int32 0-based.  Returns idx_t2s u8, score_t2s, mask_all
         (B,N,256) and sim_avg (B,N)."""
-        B, C, _ = query.shape
+        split = isinstance(query, (tuple, list))
+        if split != (getattr(bank, "numerics", "chain") == "split"):
+            raise ValueError(f"query numerics and bank numerics ({bank.numerics}) differ")
+        B, C = (query[0].shape[0], query[0].shape[2]) if split else query.shape[:2]
         N = bank.N
-        dev = query.device
+        dev = qmask.device
         idx = torch.empty(B, N, P, dtype=torch.uint8, device=dev)
         sc = torch.empty(B, N, P, dtype=torch.float32, device=dev)
         ma = torch.empty(B, N, P, dtype=torch.float32, device=dev)
         avg = torch.empty(B, N, dtype=torch.float32, device=dev)
+        if split:
+            _lib.call("gp_match_tiles_split", _lib.ptr(query[0]), _lib.ptr(query[1]), _lib.ptr(bank.hi), _lib.ptr(bank.lo),
+                      _lib.ptr(qmask), _lib.ptr(bank.masks), _lib.ptr(labels0), _lib.i(B), _lib.i(bank.O), _lib.i(N),
+                      _lib.i(C), _lib.f(self.sim_threshold), _lib.f(self.patch_threshold), _lib.ptr(idx), _lib.ptr(sc),
+                      _lib.ptr(ma), _lib.ptr(avg), _lib.stream_ptr())
+            return idx, sc, ma, avg
         _lib.call("gp_match_tiles", _lib.ptr(query), _lib.ptr(bank.features), _lib.ptr(qmask),
                   _lib.ptr(bank.masks), _lib.ptr(labels0), _lib.i(B), _lib.i(bank.O), _lib.i(N), _lib.i(C),
                   _lib.f(self.sim_threshold), _lib.f(self.patch_threshold), _lib.ptr(idx), _lib.ptr(sc),
@@ -141,7 +179,7 @@ class LocalSimilarity(torch.nn.Module):
         outs = []
         for s in range(0, B, max_batch_size):
             e = min(B, s + max_batch_size)
-            bank = MatchBank(src_feats[s:e], src_masks[s:e])
+            bank = MatchBank(src_feats[s:e], src_masks[s:e], self.numerics)
             labels0 = torch.arange(e - s, dtype=torch.int32, device=tar_feat.device)
             outs.append(self.test_bank(bank, tar_feat[s:e], tar_mask[s:e], labels0))
         out = outs[0]

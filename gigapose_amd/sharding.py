@@ -37,7 +37,9 @@ def shard_bounds(n_templates, world, rank):
 
 
 def all_gather_cat(t, group=None):
-    """all-gather equal-shaped tensors and concatenate along dim 0 (rank order)."""
+    """all-gather equal-shaped tensors and concatenate along dim 0 (rank order); tuples element-wise."""
+    if isinstance(t, (tuple, list)):
+        return tuple(all_gather_cat(x, group) for x in t)
     world = dist.get_world_size(group)
     if world == 1 and not _always_collective():
         return t
@@ -115,7 +117,7 @@ class ShardedMatcher:
 
         m = self.metric
         n_own = tar_feat.shape[0]
-        q = all_gather_cat(m.normalize(tar_feat), self.group)                       # exchange #1
+        q = all_gather_cat(m.normalize(tar_feat), self.group)                       # exchange #1 (f32, or f16 hi/lo planes)
         qmask = all_gather_cat(patch_grid_mask(tar_mask), self.group)
         labels_all = all_gather_cat(labels0.to(torch.int32).contiguous(), self.group)
         idx, sc, ma, avg = m.match_tiles(q, qmask, self.bank, labels_all)

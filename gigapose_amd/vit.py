@@ -9,6 +9,7 @@ used as CPU oracle.  All arithmetic is in the HIP library; this class owns weigh
 """
 import ctypes
 import math
+import os
 
 import torch
 from torch import nn
@@ -21,6 +22,19 @@ VARIANTS = {  # name: (dim, depth, heads)
     "dinov2_vitl14": (1024, 24, 16),
 }
 T = 257
+# Numerics of the linear layers (DESIGN.md section 2):
+#   "chain": f32-input MFMA, every dot product is the sequential fmaf chain the CPU oracle restates (bit-exact parity)
+#   "split": each f32 operand split into two f16 halves, 3 f16 MFMAs per k-block with f32 accumulation
+#            (gp_split.hip): f32-equivalent accuracy (measured error vs f64 below the chain's), ~2x faster
+NUMERICS = ("chain", "split")
+
+
+def split_planes(w):
+    """[out][in] f32 weight -> (hi, lo) f16 planes: w ~= hi + lo * 2^-11 (same rounding as the device's split1)."""
+    w = w.detach().float().contiguous()
+    hi = w.half()
+    lo = ((w - hi.float()) * 2048.0).half()
+    return hi.contiguous(), lo.contiguous()
 
 
 class _Block(nn.Module):
@@ -57,6 +71,15 @@ class Dinov2ViT(nn.Module):
         self.norm = nn.LayerNorm(dim, eps=1e-6)  # final norm: present in checkpoints, not applied
         self._packed = None
         self._ws = None
+        self.numerics = os.environ.get("GIGAPOSE_NUMERICS", "chain")
+
+    def set_numerics(self, mode):
+        if mode not in NUMERICS:
+            raise ValueError(f"numerics must be one of {NUMERICS}")
+        if mode != self.numerics:
+            self.numerics = mode
+            self._packed = None
+        return self
 
     # ---------------------------------------------------------------- construction helpers
     @classmethod
@@ -140,7 +163,15 @@ class Dinov2ViT(nn.Module):
                         dev(blk.mlp.fc1.weight.t()), dev(blk.mlp.fc1.bias),
                         dev(blk.mlp.fc2.weight.t()), dev(blk.mlp.fc2.bias), dev(blk.ls2.gamma)]
         table = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
-        self._packed = (device, tensors, table)
+        split, split_table = [], None
+        if self.numerics == "split":  # pre-split weight planes, PyTorch-native [out][in] (k contiguous)
+            for blk in self.blocks:
+                qkv_w = blk.attn.qkv.weight.detach().to(device)
+                for w in (qkv_w[:2 * C], qkv_w[2 * C:], blk.attn.proj.weight.to(device), blk.mlp.fc1.weight.to(device),
+                          blk.mlp.fc2.weight.to(device)):
+                    split += list(split_planes(w))
+            split_table = (ctypes.c_void_p * len(split))(*[t.data_ptr() for t in split])
+        self._packed = (device, tensors, table, split, split_table)
 
     def _workspace(self, B, device):
         lib = _lib.lib()
@@ -166,11 +197,11 @@ class Dinov2ViT(nn.Module):
         if B == 0:
             return out
         ws, need = self._workspace(B, device)
-        _, tensors, table = self._packed
-        _lib.call("gp_vit_forward", _lib.ptr(x), _lib.i(B), _lib.i(self.dim), _lib.i(self.depth),
+        _, tensors, table, split, split_table = self._packed
+        _lib.call("gp_vit_forward_split", _lib.ptr(x), _lib.i(B), _lib.i(self.dim), _lib.i(self.depth),
                   _lib.i(self.heads), _lib.i(self.mlp_dim), _lib.f(1e-6), table, _lib.i(len(tensors)),
-                  _lib.ptr(ws), ctypes.c_size_t(need), _lib.ptr(out), _lib.i(1 if normalize else 0),
-                  _lib.i(stop_after_layers), _lib.stream_ptr())
+                  split_table, _lib.i(len(split)), _lib.ptr(ws), ctypes.c_size_t(need), _lib.ptr(out),
+                  _lib.i(1 if normalize else 0), _lib.i(stop_after_layers), _lib.stream_ptr())
         return out
 
     @torch.no_grad()

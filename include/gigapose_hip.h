@@ -71,6 +71,18 @@ int gp_match_tiles(const float* query, const float* bank, const float* qmask, co
                    float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
                    float* sim_avg, void* stream);
 
+/* Split-f16 numerics of the matcher (opt-in; same outputs as gp_match_tiles up to f32 round-off: the similarity
+ * tile is computed as 3 f16 MFMAs per k-block on operands split into f16 halves, f32 accumulation; gp_split.hip).
+ * gp_l2norm_split: x (rows, C, 256) f32 -> F.normalize(x, dim=C) * 32 as two f16 planes hi / lo, each
+ * (rows, 256, Cp), Cp = round_up(C, 32), zero padded (value ~= (hi + lo) / 32).
+ * gp_match_tiles_split: query planes (B,256,Cp), bank planes (O,N,256,Cp); C here = Cp; everything else as
+ * gp_match_tiles. */
+int gp_l2norm_split(const float* x, void* hi, void* lo, int rows, int C, void* stream);
+int gp_match_tiles_split(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
+                         const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
+                         float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
+                         void* stream);
+
 /* torch.topk(sim_avg, k, dim=1) (matching.py:279); ties: lower template index first.
  * Fails (-1) when k > N, like torch.topk raises. ids int32 (B,k), scores (B,k). */
 int gp_topk(const float* sim_avg, int B, int N, int k, int* ids, float* scores, void* stream);
@@ -117,6 +129,19 @@ int gp_gemm_kmajor_sk(const float* A, int lda, const float* B, int ldb, float* D
                       int K, int epilogue, const float* bias, const float* scale, const float* residual,
                       int ldr, float* scratch, size_t scratch_bytes, void* stream);
 
+/* Split-f16 numerics of the dense layers (opt-in): D = epi(W . X) with every f32 operand x ~= hi + lo * 2^-11
+ * (hi, lo f16) and three v_mfma_f32_32x32x16_f16 per k-block, f32 accumulation -- f32-equivalent accuracy
+ * (tests/test_gpu_split.py: error vs f64 not above the fmaf chain's) at ~2x the speed of gp_gemm_kmajor.
+ * Not bit-identical to gp_gemm_kmajor.
+ *   gp_split_weights: W^T (K, n) f32 k-major (row stride ldw) -> planes hi, lo (n, K) f16.
+ *   gp_gemm_split: act (K, ld_act) f32 k-major activations; whi / wlo (n_w, K) pre-split weights;
+ *     act_is_b != 0: D[i][j] = sum_k W[i][k] act[k][j];  act_is_b == 0: D[i][j] = sum_k act[k][i] W[j][k].
+ *     epilogues as gp_gemm_kmajor.  Requires I, J % 128 == 0, K % 32 == 0. */
+int gp_split_weights(const float* Wt, int K, int n, int ldw, void* hi, void* lo, void* stream);
+int gp_gemm_split(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J, int K,
+                  int act_is_b, int epilogue, const float* bias, const float* scale, const float* residual, int ldr,
+                  void* stream);
+
 /* ---- DINOv2 ViT patch features: AENet.forward (src/models/network/ae_net.py:44-73) ---------- */
 
 /* Bytes of device workspace gp_vit_forward needs for B crops. */
@@ -138,6 +163,16 @@ size_t gp_vit_workspace_bytes(int B, int dim, int mlp_dim);
 int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                    const float* const* weights, int n_weights, float* workspace, size_t workspace_bytes,
                    float* out_features, int normalize, int stop_after_layers, void* stream);
+
+/* gp_vit_forward with the linear layers in split-f16 numerics: `split` = HOST array of n_split = 10*depth DEVICE
+ * pointers, per layer: qk_hi, qk_lo (2dim, dim), v_hi, v_lo (dim, dim), proj_hi, proj_lo (dim, dim),
+ * fc1_hi, fc1_lo (mlp, dim), fc2_hi, fc2_lo (dim, mlp) -- f16 planes of the PyTorch-native [out][in] weights,
+ * w ~= hi + lo * 2^-11.  split == NULL: identical to gp_vit_forward.  (Patch embedding, LayerNorm, attention and
+ * the feature epilogue are the same f32 kernels in both modes.) */
+int gp_vit_forward_split(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
+                         const float* const* weights, int n_weights, const void* const* split, int n_split,
+                         float* workspace, size_t workspace_bytes, float* out_features, int normalize,
+                         int stop_after_layers, void* stream);
 
 /* ---- IST backbone: ResNet.forward (src/models/network/resnet.py:364-381, BasicBlock :26-50) -- */
 

@@ -92,9 +92,12 @@ def pose_rel_err(a, b):
     return t, r
 
 
-def test_eval_retrieval_matches_reference_golden(golden_dir):
+@pytest.mark.parametrize("numerics", ["chain", "split"])
+def test_eval_retrieval_matches_reference_golden(golden_dir, numerics, monkeypatch):
+    monkeypatch.setenv("GIGAPOSE_NUMERICS", numerics)   # read when the ViT / matcher / bank are constructed
     g = np.load(os.path.join(golden_dir, "e2e.npz"))
     model, _ = build_model()
+    assert model.ae_net.dinov2_model.numerics == numerics and model.testing_metric.numerics == numerics
     items, q = e2e_inputs(E2E["seed"], E2E["O"], E2E["N"], E2E["B"])
     model.template_datasets = {"syn": FakeTemplates(items)}
     model.test_dataset_name = "syn"

@@ -39,8 +39,11 @@ def test_matcher_vs_oracle_bit_exact(golden_dir, name):
         np.testing.assert_array_equal(hip[key].view(np.uint32), ref[key].view(np.uint32), err_msg=key)
 
 
+@pytest.mark.parametrize("numerics", ["chain", "split"])
 @pytest.mark.parametrize("name", CASES)
-def test_matcher_vs_reference_golden(golden_dir, name):
+def test_matcher_vs_reference_golden(golden_dir, name, numerics, monkeypatch):
+    """Both numerics modes against the outputs of the unmodified reference: indices bit-exact, scores 1e-6."""
+    monkeypatch.setenv("GIGAPOSE_NUMERICS", numerics)
     g, case, k = load_case(golden_dir, name)
     _, _, hip = run_hip(case, k)
     np.testing.assert_array_equal(hip["id_src"], g["id_src"])

@@ -1,0 +1,160 @@
+"""GPU: the split-f16 numerics mode (gp_split.hip, gp_match_tiles_split) -- opt-in, NOT bit-identical to the fmaf
+chain.  What is asserted: (1) its error against an f64 reference is not above the chain kernel's own error (i.e.
+the mode is f32-equivalent, not reduced precision); (2) ViT features agree with the chain mode to f32 round-off
+and with the HF stand-in to the same tolerance as the chain mode; (3) the matcher's index outputs agree with the
+chain mode except for a handful of threshold/argmax ties at config-2 size (the agreement rate is printed).
+Parity of the split mode with the REFERENCE goldens: tests/test_gpu_matcher.py, tests/test_gpu_e2e.py (both modes)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from gigapose_amd import synthetic as syn
+from test_gpu_vit import hip_gemm, run_vit
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def split_gemm(act, W, act_is_b, epi=0, bias=None, scale=None, res=None):
+    """act (K, n_act) f32 k-major, W (n_w, K) f32 [out][in]."""
+    from gigapose_amd import _lib
+    from gigapose_amd.vit import split_planes
+
+    K = act.shape[0]
+    I, J = (W.shape[0], act.shape[1]) if act_is_b else (act.shape[1], W.shape[0])
+    hi, lo = split_planes(torch.from_numpy(W).to(DEV))
+    ta = torch.from_numpy(act).to(DEV)
+    D = torch.empty(I, J, device=DEV)
+    tb = None if bias is None else torch.from_numpy(bias).to(DEV)
+    ts = None if scale is None else torch.from_numpy(scale).to(DEV)
+    tr = None if res is None else torch.from_numpy(res).to(DEV)
+    _lib.call("gp_gemm_split", _lib.ptr(ta), _lib.i(act.shape[1]), _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(D), _lib.i(J), _lib.i(I),
+              _lib.i(J), _lib.i(K), _lib.i(1 if act_is_b else 0), _lib.i(epi), _lib.ptr(tb), _lib.ptr(ts), _lib.ptr(tr), _lib.i(J),
+              _lib.stream_ptr())
+    torch.cuda.synchronize()
+    return D.cpu().numpy()
+
+
+@pytest.mark.parametrize("act_is_b", [True, False])
+@pytest.mark.parametrize("K", [96, 1024])
+def test_split_gemm_error_vs_f64_not_above_the_chain(act_is_b, K):
+    rs = np.random.RandomState(80 + K)
+    I, J = 256, 384
+    n_act, n_w = (J, I) if act_is_b else (I, J)
+    act = (rs.standard_normal((K, n_act)) * rs.uniform(0.01, 30, (K, 1))).astype(np.float32)   # wide dynamic range
+    W = (rs.standard_normal((n_w, K)) * 0.05).astype(np.float32)
+    got = split_gemm(act, W, act_is_b)
+    A, B = (np.ascontiguousarray(W.T), act) if act_is_b else (act, np.ascontiguousarray(W.T))
+    chain = hip_gemm(A, B)
+    ref = A.astype(np.float64).T @ B.astype(np.float64)
+    mag = np.abs(A).astype(np.float64).T @ np.abs(B).astype(np.float64)
+    e_split, e_chain = np.abs(got - ref) / mag, np.abs(chain - ref) / mag
+    print(f"K={K} act_is_b={act_is_b}: max err/sum|ab| split {e_split.max():.2e} chain {e_chain.max():.2e}; "
+          f"rms split {np.sqrt((e_split**2).mean()):.2e} chain {np.sqrt((e_chain**2).mean()):.2e}")
+    assert e_split.max() < 2.5e-7                                   # a few ulp of f32 relative to sum |a||b|
+    assert np.sqrt((e_split ** 2).mean()) <= 1.25 * np.sqrt((e_chain ** 2).mean())
+    assert e_split.max() <= 1.5 * e_chain.max()
+
+
+@pytest.mark.parametrize("epi", [1, 2, 3, 4, 5])
+def test_split_gemm_epilogues_match_chain_kernel(epi):
+    rs = np.random.RandomState(90 + epi)
+    I, J, K = 256, 256, 64
+    act = rs.standard_normal((K, J)).astype(np.float32)
+    W = rs.standard_normal((I, K)).astype(np.float32)
+    bias = rs.standard_normal(J if epi == 4 else I).astype(np.float32)
+    scale = rs.standard_normal(I).astype(np.float32)
+    res = rs.standard_normal((I, J)).astype(np.float32)
+    got = split_gemm(act, W, True, epi, bias, scale, res)
+    ref = hip_gemm(np.ascontiguousarray(W.T), act, epi, bias, scale, res)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
+
+
+def test_split_weights_kernel_equals_host_split():
+    from gigapose_amd import _lib
+    from gigapose_amd.vit import split_planes
+
+    rs = np.random.RandomState(3)
+    K, n = 100, 77                                                   # ragged: exercises the tile guards
+    Wt = (rs.standard_normal((K, n)) * rs.uniform(1e-6, 100, (K, 1))).astype(np.float32)
+    t = torch.from_numpy(Wt).to(DEV)
+    hi = torch.empty(n, K, dtype=torch.float16, device=DEV)
+    lo = torch.empty_like(hi)
+    _lib.call("gp_split_weights", _lib.ptr(t), _lib.i(K), _lib.i(n), _lib.i(n), _lib.ptr(hi), _lib.ptr(lo), _lib.stream_ptr())
+    h2, l2 = split_planes(t.t())
+    assert torch.equal(hi, h2) and torch.equal(lo, l2)
+    back = hi.float() + lo.float() / 2048.0
+    assert ((back - t.t()).abs() <= 2.0 ** -21 * t.t().abs() + 1e-12).all()   # 22 significant bits survive
+
+
+def test_vit_split_features_vs_chain_and_hf():
+    """ViT-S/14 stand-in: unit-norm patch features of the two numerics modes agree to f32 round-off, and the
+    split mode is as close to the HF Dinov2Model as the chain mode."""
+    hf, vit, x = run_vit(384, 12, 6, 3, seed=70)
+    chain = vit.set_numerics("chain").patch_features(x.to(DEV)).cpu()
+    split = vit.set_numerics("split").patch_features(x.to(DEV)).cpu()
+    with torch.no_grad():
+        hs = hf(pixel_values=x, output_hidden_states=True).hidden_states[-1][:, 1:]
+    ref = torch.nn.functional.normalize(hs.transpose(1, 2).reshape(3, 384, 16, 16), dim=1)
+    d_modes = (chain - split).abs().max().item()
+    e_chain, e_split = (chain - ref).abs().max().item(), (split - ref).abs().max().item()
+    print(f"ViT-S features: chain vs split {d_modes:.2e}; vs HF: chain {e_chain:.2e}, split {e_split:.2e}")
+    assert d_modes < 2e-6 and e_split < 5e-5 and e_split <= 1.5 * e_chain + 1e-6
+
+
+def test_matcher_split_agreement_at_config2_size():
+    """B=64, N=162, C=1024 with planted, graded matches: template ranking identical, patch indices identical up to a
+    handful of exact ties at the 0.5 threshold / argmax (f32 round-off class: the reference's own GEMM would differ
+    from the fmaf chain in the same way)."""
+    from gigapose_amd.matching import LocalSimilarity, MatchBank, patch_grid_mask
+
+    B, N, C = 64, 162, 1024
+    case = syn.matcher_case(seed=5, B=B, O=1, N=N, C=C)
+    feats, masks = torch.from_numpy(case["src_feats"]).to(DEV), torch.from_numpy(case["src_masks"]).to(DEV)
+    qf = torch.from_numpy(case["tar_feat"]).to(DEV)
+    qmask = patch_grid_mask(torch.from_numpy(case["tar_mask"]).to(DEV))
+    labels = torch.from_numpy(case["labels"]).to(DEV)
+    out = {}
+    for mode in ["chain", "split"]:
+        m = LocalSimilarity(5, 0.5, 3)
+        m.numerics = mode
+        out[mode] = m.match_tiles(m.normalize(qf), qmask, MatchBank(feats, masks, mode), labels)
+    (i0, s0, m0, a0), (i1, s1, m1, a1) = out["chain"], out["split"]
+    n_idx, n_mask = (i0 != i1).sum().item(), (m0 != m1).sum().item()
+    print(f"matcher chain vs split at B={B} N={N} C={C}: {n_idx} of {i0.numel()} patch ids differ, {n_mask} mask bits differ, "
+          f"sim_avg max |diff| {(a0 - a1).abs().max().item():.2e}")
+    assert (s0 != 0).sum().item() > 100000                              # the case is not degenerate
+    assert n_idx <= 40 and n_mask <= 40                                 # < 2e-5 of the entries
+    both = (s0 != 0) & (s1 != 0)
+    assert (s0 - s1)[both].abs().max().item() < 6e-6                    # K=1024 f32 chain round-off is ~1e-6 by itself
+    # which mode is closer to the truth?  f64 similarities of a few tiles from the SAME normalised f32 features
+    qn = LocalSimilarity(5, 0.5, 3).normalize(qf).double()                                   # (B, C, 256)
+    bn = MatchBank(feats, masks, "chain").features.double()                                  # (1, N, C, 256)
+    e_chain, e_split = [], []
+    for b, n in [(0, 0), (5, 17), (33, 100), (63, 161)]:
+        sim = qn[b].t() @ bn[0, n]                                                            # (t, s)
+        sim = sim * qmask[b].double()[:, None] * patch_grid_mask(masks)[0, n].double()[None, :]
+        row = sim.gather(1, i0[b, n].long()[:, None])[:, 0]                                  # f64 value at the chosen s
+        ok = both[b, n] & (i0[b, n] == i1[b, n])
+        e_chain.append((s0[b, n].double() - row)[ok].abs())
+        e_split.append((s1[b, n].double() - row)[ok].abs())
+    e_chain, e_split = torch.cat(e_chain), torch.cat(e_split)
+    print(f"score error vs f64 over {e_chain.numel()} matched patches: chain rms {e_chain.pow(2).mean().sqrt().item():.2e} "
+          f"max {e_chain.max().item():.2e}; split rms {e_split.pow(2).mean().sqrt().item():.2e} max {e_split.max().item():.2e}")
+    assert e_split.pow(2).mean().sqrt().item() <= 1.25 * e_chain.pow(2).mean().sqrt().item()
+    assert (a0 - a1).abs().max().item() < 2e-3                           # one flipped patch moves sim_avg by <= 1/256
+    assert torch.equal(torch.topk(a0, 5, dim=1).indices, torch.topk(a1, 5, dim=1).indices)
+
+
+def test_split_normalize_planes_reconstruct_unit_vectors():
+    from gigapose_amd.matching import LocalSimilarity, normalize_split
+
+    rs = np.random.RandomState(8)
+    x = (rs.standard_normal((5, 48, 256)) * rs.uniform(0.1, 30, (5, 1, 256))).astype(np.float32)   # C=48 -> Cp=64
+    hi, lo = normalize_split(torch.from_numpy(x).to(DEV))
+    assert hi.shape == (5, 256, 64) and (hi[..., 48:] == 0).all() and (lo[..., 48:] == 0).all()
+    chain = LocalSimilarity(5, 0.5, 3).normalize(torch.from_numpy(x).to(DEV))            # (5, 48, 256) f32
+    back = (hi.float() + lo.float())[..., :48].transpose(1, 2) / 32.0
+    assert (back - chain).abs().max().item() < 2e-7

@@ -1,0 +1,62 @@
+"""GPU probe: split-f16 (3 x f16 MFMA) GEMM vs the exact f32 fmaf-chain GEMM: error against an f64 reference and time."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gigapose_amd import _lib
+dev = "cuda"
+lib = _lib.lib()
+def timeit(fn, iters=8, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+def split_w(Wt):  # Wt [K][n] f32 -> hi, lo [n][K] f16
+    K, n = Wt.shape
+    hi = torch.empty(n, K, dtype=torch.float16, device=dev); lo = torch.empty_like(hi)
+    _lib.call("gp_split_weights", _lib.ptr(Wt), _lib.i(K), _lib.i(n), _lib.i(n), _lib.ptr(hi), _lib.ptr(lo), _lib.stream_ptr())
+    return hi, lo
+torch.manual_seed(0)
+# correctness on a small asymmetric case, both operand roles
+for act_is_b in [1, 0]:
+    I, J, K = 256, 384, 96
+    if act_is_b:
+        Wt = torch.randn(K, I, device=dev); X = torch.randn(K, J, device=dev) * 3
+        ref = (Wt.double().T @ X.double())
+    else:
+        X = torch.randn(K, I, device=dev) * 3; Wt = torch.randn(K, J, device=dev)
+        ref = (X.double().T @ Wt.double())
+    hi, lo = split_w(Wt)
+    D = torch.empty(I, J, device=dev)
+    _lib.call("gp_gemm_split", _lib.ptr(X), _lib.i(X.shape[1]), _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(D), _lib.i(J), _lib.i(I), _lib.i(J),
+              _lib.i(K), _lib.i(act_is_b), _lib.i(0), None, None, None, _lib.i(J), _lib.stream_ptr())
+    A_, B_ = (Wt, X) if act_is_b else (X, Wt)
+    De = torch.empty(I, J, device=dev)
+    _lib.call("gp_gemm_kmajor", _lib.ptr(A_), _lib.i(I), _lib.ptr(B_), _lib.i(J), _lib.ptr(De), _lib.i(J), _lib.i(I), _lib.i(J),
+              _lib.i(K), _lib.i(0), None, None, None, _lib.i(J), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    scale = (A_.double().abs().T @ B_.double().abs())
+    es = ((D.double() - ref).abs() / scale).max().item(); ee = ((De.double() - ref).abs() / scale).max().item()
+    print(f"act_is_b={act_is_b} small: max |err| / sum|a||b|: split {es:.3e}  exact-f32-chain {ee:.3e}  max abs split {(D.double()-ref).abs().max().item():.3e}")
+# ViT-L shapes: error + time
+for (I, J, K, act_is_b, name) in [(1024, 16512, 1024, 1, "proj"), (4096, 16512, 1024, 1, "fc1"), (1024, 16512, 4096, 1, "fc2"), (2048, 16512, 1024, 1, "qk"), (16512, 1024, 1024, 0, "v")]:
+    if act_is_b:
+        Wt = torch.randn(K, I, device=dev) * 0.05; X = torch.randn(K, J, device=dev)
+    else:
+        X = torch.randn(K, I, device=dev); Wt = torch.randn(K, J, device=dev) * 0.05
+    hi, lo = split_w(Wt)
+    A_, B_ = (Wt, X) if act_is_b else (X, Wt)
+    D = torch.empty(I, J, device=dev); De = torch.empty(I, J, device=dev)
+    fs = lambda: _lib.call("gp_gemm_split", _lib.ptr(X), _lib.i(X.shape[1]), _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(D), _lib.i(J), _lib.i(I), _lib.i(J),
+                           _lib.i(K), _lib.i(act_is_b), _lib.i(0), None, None, None, _lib.i(J), _lib.stream_ptr())
+    fe = lambda: _lib.call("gp_gemm_kmajor", _lib.ptr(A_), _lib.i(I), _lib.ptr(B_), _lib.i(J), _lib.ptr(De), _lib.i(J), _lib.i(I), _lib.i(J),
+                           _lib.i(K), _lib.i(0), None, None, None, _lib.i(J), _lib.stream_ptr())
+    ms_s, ms_e = timeit(fs), timeit(fe)
+    rows = slice(0, 256)
+    ref = (A_[:, rows].double().T @ B_.double())
+    scale = (A_[:, rows].double().abs().T @ B_.double().abs())
+    es = ((D[rows].double() - ref).abs() / scale); ee = ((De[rows].double() - ref).abs() / scale)
+    print(f"{name:5s} I={I} J={J} K={K}: split {ms_s:.3f} ms = {2.0*I*J*K/ms_s/1e9:.0f} TF-equivalent | exact {ms_e:.3f} ms = {2.0*I*J*K/ms_e/1e9:.0f} TF | "
+          f"err/sum|ab| max: split {es.max().item():.2e} exact {ee.max().item():.2e}; rms: split {es.pow(2).mean().sqrt().item():.2e} exact {ee.pow(2).mean().sqrt().item():.2e}")

@@ -215,6 +215,172 @@ void launch_split(const SplitArgs& a, bool act_is_b, hipStream_t st)
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-f16 convolution (IST backbone in split numerics): implicit GEMM on channel-LAST activations.
+//   Y[pix][co] = epi( sum_k W[co][k] * Xcol[pix][k] ),   k = (dy, dx, ci) with ci fastest
+// Activations are f16 planes hi / lo of shape (B, H, W, C): eight consecutive k at a fixed tap are eight consecutive
+// channels = one 16-byte chunk, which IS the MFMA operand fragment -- the im2col gather is a plain chunk copy (zero
+// for taps outside the image), no conversion.  Weights: planes (CoutPad, K), CoutPad = round_up(Cout, 128), K =
+// KH*KW*Cin.  Tile 128 co x 128 pixels, 4 waves (2 x 2 of 64 x 64), main loop identical to gemm_split_kernel.
+// Epilogue: folded eval-BatchNorm, residual (from planes), ReLU; output as planes (B, OH, OW, Cout) for the next
+// convolution, or f32 NCHW for the last one.
+struct ConvSplitArgs {
+    const _Float16* xhi; const _Float16* xlo;
+    const _Float16* whi; const _Float16* wlo;
+    const float* alpha; const float* beta;
+    const _Float16* rhi; const _Float16* rlo;
+    _Float16* ohi; _Float16* olo; float* of32;
+    int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, relu, K, tiles_co, tiles_pix;
+};
+
+__global__ __launch_bounds__(SNT, 2) void conv_split_kernel(const ConvSplitArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int q = xcd_chunked_tile(blockIdx.x, a.tiles_co * a.tiles_pix);
+    if (q < 0) return;
+    const int i0 = (q % a.tiles_co) * SBM, j0 = (q / a.tiles_co) * SBN;  // co fastest: neighbours share the pixel tile
+    constexpr int P_AHI = 0, P_ALO = SPLANE, P_BHI = 2 * SPLANE, P_BLO = 3 * SPLANE;
+    const int OHW = a.OH * a.OW;
+
+    // staging: 8 chunks per thread: weight rows r0, r0+64 and pixel rows r0, r0+64 (both planes), k-chunk kc
+    const int r0 = tid >> 2, kc = tid & 3;
+    int pb[2], py[2], px[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int pix = j0 + r0 + 64 * h;
+        const int b = pix / OHW, rem = pix - b * OHW;
+        pb[h] = b * a.H;
+        py[h] = (rem / a.OW) * a.stride - a.pad;
+        px[h] = (rem % a.OW) * a.stride - a.pad;
+    }
+    f16x8 rw[4], rx[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const size_t wo = (size_t)(i0 + r0 + 64 * h) * a.K + k0 + kc * 8;
+            rw[h] = *reinterpret_cast<const f16x8*>(a.whi + wo);
+            rw[2 + h] = *reinterpret_cast<const f16x8*>(a.wlo + wo);
+        }
+        const int tap = k0 / a.Cin, ci = k0 - tap * a.Cin + kc * 8;  // Cin % 32 == 0: one tap per 32-k slab
+        const int dy = tap / a.KW, dx = tap - dy * a.KW;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int iy = py[h] + dy, ix = px[h] + dx;
+            f16x8 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { vh[e] = (_Float16)0.f; vl[e] = (_Float16)0.f; }
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                const size_t xo = ((size_t)(pb[h] + iy) * a.W + ix) * a.Cin + ci;
+                vh = *reinterpret_cast<const f16x8*>(a.xhi + xo);
+                vl = *reinterpret_cast<const f16x8*>(a.xlo + xo);
+            }
+            rx[h] = vh;
+            rx[2 + h] = vl;
+        }
+    };
+    auto stage = [&](int buf) {
+        _Float16* L = lds + buf * SBUF;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int off = (r0 + 64 * h) * SROW + kc * 8;
+            *reinterpret_cast<f16x8*>(L + P_AHI + off) = rw[h];
+            *reinterpret_cast<f16x8*>(L + P_ALO + off) = rw[2 + h];
+            *reinterpret_cast<f16x8*>(L + P_BHI + off) = rx[h];
+            *reinterpret_cast<f16x8*>(L + P_BLO + off) = rx[2 + h];
+        }
+    };
+
+    f32x16 hh[2][2], xx[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { hh[mi][ni][r] = 0.f; xx[mi][ni][r] = 0.f; }
+
+    const int nstep = a.K / SBK;
+    gload(0);
+    stage(0);
+    __syncthreads();
+    const int arow = (wm * 64 + (lane & 31)) * SROW + (lane >> 5) * 8;
+    const int brow = (wn * 64 + (lane & 31)) * SROW + (lane >> 5) * 8;
+    for (int s = 0; s < nstep; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstep) gload((s + 1) * SBK);
+        const _Float16* L = lds + buf * SBUF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                ah[mi] = *reinterpret_cast<const f16x8*>(L + P_AHI + arow + mi * 32 * SROW + ks * 16);
+                al[mi] = *reinterpret_cast<const f16x8*>(L + P_ALO + arow + mi * 32 * SROW + ks * 16);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                bh[ni] = *reinterpret_cast<const f16x8*>(L + P_BHI + brow + ni * 32 * SROW + ks * 16);
+                bl[ni] = *reinterpret_cast<const f16x8*>(L + P_BLO + brow + ni * 32 * SROW + ks * 16);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    hh[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], hh[mi][ni], 0, 0, 0);
+                    xx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], xx[mi][ni], 0, 0, 0);
+                    xx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], xx[mi][ni], 0, 0, 0);
+                }
+        }
+        if (s + 1 < nstep) stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane = pixel column, registers = 4 x (4 consecutive output channels)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int pix = j0 + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = i0 + wm * 64 + mi * 32 + 8 * g + 4 * (lane >> 5);
+                if (co >= a.Cout) continue;  // padded weight rows (Cout % 128 == 64)
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = hh[mi][ni][4 * g + e] + xx[mi][ni][4 * g + e] * kLoInv;
+                    if (a.alpha) v[e] = v[e] * a.alpha[co + e] + a.beta[co + e];
+                }
+                if (a.rhi) {
+                    const f16x4 rh = *reinterpret_cast<const f16x4*>(a.rhi + (size_t)pix * a.Cout + co);
+                    const f16x4 rl = *reinterpret_cast<const f16x4*>(a.rlo + (size_t)pix * a.Cout + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ((float)rh[e] + (float)rl[e] * kLoInv) + v[e];
+                }
+                if (a.relu)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                if (a.of32) {  // (B, Cout, OH, OW)
+                    const int b = pix / OHW, rem = pix - b * OHW;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a.of32[((size_t)b * a.Cout + co + e) * OHW + rem] = v[e];
+                } else {
+                    f16x4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 h_, l_;
+                        split1(v[e], h_, l_);
+                        oh[e] = h_;
+                        ol[e] = l_;
+                    }
+                    *reinterpret_cast<f16x4*>(a.ohi + (size_t)pix * a.Cout + co) = oh;
+                    *reinterpret_cast<f16x4*>(a.olo + (size_t)pix * a.Cout + co) = ol;
+                }
+            }
+        }
+}
+
 // internal entry (gp_vit.hip).  act: f32 k-major activations [K][ld_act]; whi/wlo: pre-split weights [n_w][K].
 // act_is_b: D[i][j] = sum_k W[i][k] X[k][j]  (weights index i); else D[i][j] = sum_k X[k][i] W[j][k].
 int gp_gemm_split_launch(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J,
@@ -250,6 +416,39 @@ int gp_split_weights(const float* Wt, int K, int n, int ldw, void* hi, void* lo,
     hipLaunchKernelGGL(split_weights_kernel, dim3((n + 31) / 32, (K + 31) / 32), dim3(256), 0, (hipStream_t)stream, Wt, K, n,
                        ldw, (_Float16*)hi, (_Float16*)lo);
     GP_CHECK_LAUNCH("gp_split_weights");
+    return GP_OK;
+}
+
+int gp_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* alpha,
+                         const float* beta, const void* res_hi, const void* res_lo, int B, int H, int W, int Cin, int Cout,
+                         int KH, int KW, int stride, int pad, int relu, void* out_hi, void* out_lo, float* out_f32_nchw,
+                         void* stream)
+{
+    GP_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+               "gp_conv2d_nhwc_split: bad sizes");
+    if (B == 0) return GP_OK;
+    ConvSplitArgs a;
+    a.xhi = (const _Float16*)x_hi; a.xlo = (const _Float16*)x_lo; a.whi = (const _Float16*)w_hi; a.wlo = (const _Float16*)w_lo;
+    a.alpha = alpha; a.beta = beta; a.rhi = (const _Float16*)res_hi; a.rlo = (const _Float16*)res_lo;
+    a.ohi = (_Float16*)out_hi; a.olo = (_Float16*)out_lo; a.of32 = out_f32_nchw;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu;
+    a.OH = (H + 2 * pad - KH) / stride + 1;
+    a.OW = (W + 2 * pad - KW) / stride + 1;
+    a.K = KH * KW * Cin;
+    const long long npix = (long long)B * a.OH * a.OW;
+    GP_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "gp_conv2d_nhwc_split: Cin=%d must be a multiple of 32, Cout=%d of 64", Cin, Cout);
+    GP_REQUIRE(npix % SBN == 0 && npix < (1ll << 31), "gp_conv2d_nhwc_split: B*OH*OW=%lld must be a multiple of 128", npix);
+    GP_REQUIRE(x_hi && x_lo && w_hi && w_lo && ((out_hi && out_lo) || out_f32_nchw), "gp_conv2d_nhwc_split: null pointer");
+    GP_REQUIRE((alpha == nullptr) == (beta == nullptr) && (res_hi == nullptr) == (res_lo == nullptr),
+               "gp_conv2d_nhwc_split: alpha/beta and res_hi/res_lo go together");
+    a.tiles_co = (Cout + SBM - 1) / SBM;
+    a.tiles_pix = (int)(npix / SBN);
+    GpProfScope prof(GP_PROF_CONV, 2.0 * Cout * (double)npix * a.K, (hipStream_t)stream);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              SLDS_BYTES);
+    hipLaunchKernelGGL(conv_split_kernel, dim3(xcd_chunked_grid(a.tiles_co * a.tiles_pix)), dim3(SNT), SLDS_BYTES,
+                       (hipStream_t)stream, a);
+    GP_CHECK_LAUNCH("gp_conv2d_nhwc_split");
     return GP_OK;
 }
 

@@ -78,6 +78,7 @@ class GigaPose(_Base):
         Call before set_template_data (the bank is stored in the matcher's format)."""
         self.ae_net.dinov2_model.set_numerics(mode)
         self.testing_metric.numerics = mode
+        self.ist_net.backbone.set_numerics(mode)
         self.template_datas, self.match_banks, self.pose_recovery = {}, {}, {}
         return self
 

@@ -9,6 +9,7 @@ src/models/network/resnet.py:26-50, 318-381; Hydra targets in configs/model/ist_
   (gp_ist_regress) for every (detection, hypothesis, patch) row at once.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -58,6 +59,14 @@ class ResNet(nn.Module):
         self._packed = None
         self._bufs = None
         self._resized = None
+        self._split = None
+        self.numerics = os.environ.get("GIGAPOSE_NUMERICS", "chain")  # "chain" | "split" 
+
+    def set_numerics(self, mode):
+        if mode not in ("chain", "split"):
+            raise ValueError("numerics must be 'chain' or 'split'")
+        self.numerics = mode
+        return self
 
     # ------------------------------------------------------------------ torch fp32 reference
     def reference_forward(self, x):
@@ -94,6 +103,35 @@ class ResNet(nn.Module):
         self._packed = dict(device=device, stem=conv(self.conv1, self.bn1), blocks=blocks,
                             out=conv(self.layer4_outconv, None))
 
+    @torch.no_grad()
+    def _pack_split(self, device):
+        """Split numerics: weights as f16 planes (round_up(Cout,128), KH*KW*Cin), k = (dy, dx, ci) -- channel-last
+        im2col order -- from the same folded-BN packing."""
+        from .vit import split_planes
+
+        def conv(c):
+            co, ci, kh, kw = c.weight.shape
+            w = torch.zeros((co + 127) // 128 * 128, kh * kw * ci, dtype=torch.float32, device=device)
+            w[:co] = c.weight.detach().float().to(device).permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+            return split_planes(w)
+
+        blocks = []
+        for li in range(1, 5):
+            for blk in getattr(self, f"layer{li}"):
+                blocks.append((conv(blk.conv1), conv(blk.conv2), None if blk.downsample is None else conv(blk.downsample[0])))
+        self._split = dict(device=device, blocks=blocks, out=conv(self.layer4_outconv))
+
+    def _conv_split(self, cv, w, x, y, B, H, W, residual=None, relu=True, out_f32=None):
+        """x, y, residual: (hi, lo) f16 plane pairs, channel-last."""
+        _lib.call("gp_conv2d_nhwc_split", _lib.ptr(x[0]), _lib.ptr(x[1]), _lib.ptr(w[0]), _lib.ptr(w[1]),
+                  _lib.ptr(cv["alpha"]), _lib.ptr(cv["beta"]), _lib.ptr(None if residual is None else residual[0]),
+                  _lib.ptr(None if residual is None else residual[1]), _lib.i(B), _lib.i(H), _lib.i(W), _lib.i(cv["cin"]),
+                  _lib.i(cv["cout"]), _lib.i(cv["k"]), _lib.i(cv["k"]), _lib.i(cv["stride"]), _lib.i(cv["pad"]),
+                  _lib.i(1 if relu else 0), _lib.ptr(None if y is None else y[0]), _lib.ptr(None if y is None else y[1]),
+                  _lib.ptr(out_f32), _lib.stream_ptr())
+        oh = (H + 2 * cv["pad"] - cv["k"]) // cv["stride"] + 1
+        return oh, (W + 2 * cv["pad"] - cv["k"]) // cv["stride"] + 1
+
     def _conv(self, cv, x, y, B, H, W, residual=None, relu=True, nchw_out=False):
         _lib.call("gp_conv2d_cm", _lib.ptr(x), _lib.ptr(cv["wt"]), _lib.ptr(y), _lib.ptr(cv["alpha"]),
                   _lib.ptr(cv["beta"]), _lib.ptr(residual), _lib.i(cv["cin"]), _lib.i(B), _lib.i(H), _lib.i(W),
@@ -128,6 +166,8 @@ class ResNet(nn.Module):
                   _lib.i(x.shape[2]), _lib.i(x.shape[3]), _lib.i(S), _lib.stream_ptr())
         cur, y1, sc, nxt = self._bufs
         H, W = self._conv(pk["stem"], self._resized, cur, B, S, S)
+        if self.numerics == "split":
+            return self._forward_split(pk, cur, out, B, H, W, (y1, sc, nxt))
         for c1, c2, ds in pk["blocks"]:
             oh, ow = self._conv(c1, cur, y1, B, H, W)                       # relu(bn1(conv1(x)))
             short = cur
@@ -138,6 +178,41 @@ class ResNet(nn.Module):
             cur, nxt = nxt, cur
             H, W = oh, ow
         self._conv(pk["out"], cur, out, B, H, W, relu=False, nchw_out=True)
+        return out
+
+
+    def _forward_split(self, pk, stem_out, out, B, H, W, f32_bufs):
+        """Everything after the stem in split numerics: channel-last f16 planes, gp_conv2d_nhwc_split.  The stem
+        (7x7/2 on 3 channels, 1.6 % of the FLOPs) stays the f32 kernel; its channel-major output is split + transposed
+        once.  The plane buffers alias the f32 ping-pong buffers (same bytes: 2 planes x f16 = f32)."""
+        dev = stem_out.device
+        if self._split is None or self._split["device"] != dev:
+            self._pack_split(dev)
+        c0 = pk["stem"]["cout"]
+        npix = B * H * W
+
+        def planes(buf):  # one f32 buffer -> (hi, lo) f16 planes of the same total size
+            h = buf.view(torch.float16)
+            return h[: h.numel() // 2], h[h.numel() // 2:]
+
+        y1, sc, nxt = (planes(b) for b in f32_bufs)
+        if getattr(self, "_stem_planes", None) is None or self._stem_planes[0].numel() < c0 * npix or \
+                self._stem_planes[0].device != dev:
+            self._stem_planes = (torch.empty(c0 * npix, dtype=torch.float16, device=dev),
+                                 torch.empty(c0 * npix, dtype=torch.float16, device=dev))
+        cur = self._stem_planes
+        _lib.call("gp_split_weights", _lib.ptr(stem_out), _lib.i(c0), _lib.i(npix), _lib.i(npix), _lib.ptr(cur[0]),
+                  _lib.ptr(cur[1]), _lib.stream_ptr())                           # [C][npix] f32 -> [npix][C] planes
+        for (c1, c2, ds), (w1, w2, wd) in zip(pk["blocks"], self._split["blocks"]):
+            oh, ow = self._conv_split(c1, w1, cur, y1, B, H, W)                 # relu(bn1(conv1(x)))
+            short = cur
+            if ds is not None:
+                self._conv_split(ds, wd, cur, sc, B, H, W, relu=False)          # bn(conv1x1(x))
+                short = sc
+            self._conv_split(c2, w2, y1, nxt, B, oh, ow, residual=short)        # relu(shortcut + bn2(conv2(.)))
+            cur, nxt = nxt, cur
+            H, W = oh, ow
+        self._conv_split(pk["out"], self._split["out"], cur, None, B, H, W, relu=False, out_f32=out)
         return out
 
 
@@ -176,6 +251,7 @@ class ISTNet(nn.Module):
     def load_state_dict(self, *a, **k):
         self._packed = None
         self.backbone._packed = None
+        self.backbone._split = None
         return super().load_state_dict(*a, **k)
 
     @torch.no_grad()

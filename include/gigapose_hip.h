@@ -192,6 +192,18 @@ int gp_conv2d_cm(const float* X, const float* Wt, float* Y, const float* alpha, 
                  const float* residual, int Cin, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
                  int relu, int nchw_out, void* stream);
 
+/* Split-f16 numerics of the IST convolutions (opt-in; see gp_gemm_split): Conv2d(bias=False) + eval BatchNorm +
+ * optional residual + optional ReLU on channel-LAST activations stored as f16 planes hi / lo (value ~= hi + lo * 2^-11):
+ *   x_hi/x_lo (B,H,W,Cin); w_hi/w_lo (round_up(Cout,128), KH*KW*Cin) with k = (dy*KW + dx)*Cin + ci, padded rows zero;
+ *   alpha/beta (Cout) folded BN or NULL; res_hi/res_lo (B,OH,OW,Cout) or NULL;
+ *   output: planes out_hi/out_lo (B,OH,OW,Cout), or -- when out_f32_nchw != NULL -- f32 (B,Cout,OH,OW).
+ * Requires Cin % 32 == 0, Cout % 64 == 0, B*OH*OW % 128 == 0.  (A CNHW f32 tensor [C][npix] becomes planes [npix][C]
+ * with gp_split_weights(x, C, npix, npix, hi, lo).) */
+int gp_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* alpha,
+                         const float* beta, const void* res_hi, const void* res_lo, int B, int H, int W, int Cin, int Cout,
+                         int KH, int KW, int stride, int pad, int relu, void* out_hi, void* out_lo, float* out_f32_nchw,
+                         void* stream);
+
 /* ---- IST regressor: ISTNet.inference (src/models/network/ist_net.py:97-120) ----------------- */
 
 size_t gp_ist_workspace_bytes(int B, int k, int D, int H);

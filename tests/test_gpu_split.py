@@ -158,3 +158,59 @@ def test_split_normalize_planes_reconstruct_unit_vectors():
     chain = LocalSimilarity(5, 0.5, 3).normalize(torch.from_numpy(x).to(DEV))            # (5, 48, 256) f32
     back = (hi.float() + lo.float())[..., :48].transpose(1, 2) / 32.0
     assert (back - chain).abs().max().item() < 2e-7
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,hw,B,res", [(32, 64, 3, 1, 1, 16, 2, True), (64, 192, 3, 2, 1, 16, 2, False),
+                                                           (128, 128, 1, 2, 0, 16, 2, False), (32, 256, 1, 1, 0, 8, 2, True)])
+def test_split_conv_vs_f64(cin, cout, k, stride, pad, hw, B, res):
+    """gp_conv2d_nhwc_split (channel-last f16 planes) against an f64 convolution + BN + residual + ReLU."""
+    from gigapose_amd import _lib
+    from gigapose_amd.vit import split_planes
+
+    rs = np.random.RandomState(cin + cout + k)
+    X = rs.standard_normal((B, hw, hw, cin)).astype(np.float32)                       # NHWC
+    Wt = (rs.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    alpha = rs.uniform(0.5, 1.5, cout).astype(np.float32)
+    beta = rs.standard_normal(cout).astype(np.float32)
+    oh = (hw + 2 * pad - k) // stride + 1
+    R = rs.standard_normal((B, oh, oh, cout)).astype(np.float32) if res else None
+    wp = np.zeros(((cout + 127) // 128 * 128, k * k * cin), np.float32)
+    wp[:cout] = Wt.transpose(0, 2, 3, 1).reshape(cout, -1)
+    xh, xl = split_planes(torch.from_numpy(X).to(DEV))
+    wh, wl = split_planes(torch.from_numpy(wp).to(DEV))
+    rh, rl = split_planes(torch.from_numpy(R).to(DEV)) if res else (None, None)
+    oh_, ol_ = torch.empty(B, oh, oh, cout, dtype=torch.float16, device=DEV), torch.empty(B, oh, oh, cout, dtype=torch.float16, device=DEV)
+    of32 = torch.empty(B, cout, oh, oh, device=DEV)
+    ta, tb = torch.from_numpy(alpha).to(DEV), torch.from_numpy(beta).to(DEV)
+    for out_f32 in (None, of32):
+        _lib.call("gp_conv2d_nhwc_split", _lib.ptr(xh), _lib.ptr(xl), _lib.ptr(wh), _lib.ptr(wl), _lib.ptr(ta), _lib.ptr(tb),
+                  _lib.ptr(rh), _lib.ptr(rl), _lib.i(B), _lib.i(hw), _lib.i(hw), _lib.i(cin), _lib.i(cout), _lib.i(k), _lib.i(k),
+                  _lib.i(stride), _lib.i(pad), _lib.i(1), _lib.ptr(oh_), _lib.ptr(ol_), _lib.ptr(out_f32), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    t = torch.nn.functional.conv2d(torch.from_numpy(X).double().permute(0, 3, 1, 2), torch.from_numpy(Wt).double(),
+                                   stride=stride, padding=pad)
+    t = t * torch.from_numpy(alpha).double()[None, :, None, None] + torch.from_numpy(beta).double()[None, :, None, None]
+    if res:
+        t = t + torch.from_numpy(R).double().permute(0, 3, 1, 2)
+    t = torch.relu(t).numpy()
+    got_planes = (oh_.float() + ol_.float() / 2048.0).cpu().numpy().transpose(0, 3, 1, 2)
+    np.testing.assert_allclose(of32.cpu().numpy(), t, rtol=0, atol=2e-6 * max(1.0, np.abs(t).max()))
+    np.testing.assert_allclose(got_planes, t, rtol=0, atol=3e-6 * max(1.0, np.abs(t).max()))
+
+
+def test_ist_backbone_split_vs_chain_and_torch():
+    """The whole ResNet in split numerics: as close to the torch f32 reference as the chain kernels."""
+    from test_oracle_pose_ist import build_ist
+
+    net = build_ist(101)
+    tmpl, _ = syn.template_images(102, 2)
+    x = torch.from_numpy(np.concatenate([tmpl, tmpl[:1] * 0.5]))      # B=3
+    with torch.no_grad():
+        ref = net.backbone.double().reference_forward(x.double()).numpy()
+    net = net.float().to(DEV)
+    chain = net.backbone.set_numerics("chain")(x.to(DEV)).cpu().numpy()
+    split = net.backbone.set_numerics("split")(x.to(DEV)).cpu().numpy()
+    scale = np.abs(ref).max()
+    e_chain, e_split = np.abs(chain - ref).max() / scale, np.abs(split - ref).max() / scale
+    print(f"IST backbone vs f64 torch: chain {e_chain:.2e}, split {e_split:.2e} (relative to max |feature|)")
+    assert e_split < 2e-5 and e_split <= 1.5 * e_chain + 1e-7

@@ -233,78 +233,68 @@ struct ConvSplitArgs {
     int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, relu, K, tiles_co, tiles_pix;
 };
 
-__global__ __launch_bounds__(SNT, 2) void conv_split_kernel(const ConvSplitArgs a)
+// 8 waves as 4 (co) x 2 (pixels), wave tile 32 x 64 (two MFMA tiles, hh + xx = 64 accumulator registers): <= 128 VGPRs,
+// so two 80 KiB workgroups = 16 waves per CU = 4 per SIMD cover each other's LDS / barrier / memory stalls.
+__global__ __launch_bounds__(512, 4) void conv_split_kernel(const ConvSplitArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;  // wm 0..3, wn 0..1
     const int q = xcd_chunked_tile(blockIdx.x, a.tiles_co * a.tiles_pix);
     if (q < 0) return;
     const int i0 = (q % a.tiles_co) * SBM, j0 = (q / a.tiles_co) * SBN;  // co fastest: neighbours share the pixel tile
     constexpr int P_AHI = 0, P_ALO = SPLANE, P_BHI = 2 * SPLANE, P_BLO = 3 * SPLANE;
     const int OHW = a.OH * a.OW;
 
-    // staging: 8 chunks per thread: weight rows r0, r0+64 and pixel rows r0, r0+64 (both planes), k-chunk kc
-    const int r0 = tid >> 2, kc = tid & 3;
-    int pb[2], py[2], px[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int pix = j0 + r0 + 64 * h;
+    // staging: 4 chunks per thread: weight row r0 and pixel row r0 (both planes), k-chunk kc
+    const int r0 = tid >> 2, kc = tid & 3;  // r0 0..127
+    int pb, py, px;
+    {
+        const int pix = j0 + r0;
         const int b = pix / OHW, rem = pix - b * OHW;
-        pb[h] = b * a.H;
-        py[h] = (rem / a.OW) * a.stride - a.pad;
-        px[h] = (rem % a.OW) * a.stride - a.pad;
+        pb = b * a.H;
+        py = (rem / a.OW) * a.stride - a.pad;
+        px = (rem % a.OW) * a.stride - a.pad;
     }
-    f16x8 rw[4], rx[4];
+    f16x8 rw[2], rx[2];
     auto gload = [&](int k0) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const size_t wo = (size_t)(i0 + r0 + 64 * h) * a.K + k0 + kc * 8;
-            rw[h] = *reinterpret_cast<const f16x8*>(a.whi + wo);
-            rw[2 + h] = *reinterpret_cast<const f16x8*>(a.wlo + wo);
-        }
+        const size_t wo = (size_t)(i0 + r0) * a.K + k0 + kc * 8;
+        rw[0] = *reinterpret_cast<const f16x8*>(a.whi + wo);
+        rw[1] = *reinterpret_cast<const f16x8*>(a.wlo + wo);
         const int tap = k0 / a.Cin, ci = k0 - tap * a.Cin + kc * 8;  // Cin % 32 == 0: one tap per 32-k slab
         const int dy = tap / a.KW, dx = tap - dy * a.KW;
+        const int iy = py + dy, ix = px + dx;
+        f16x8 vh, vl;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int iy = py[h] + dy, ix = px[h] + dx;
-            f16x8 vh, vl;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { vh[e] = (_Float16)0.f; vl[e] = (_Float16)0.f; }
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-                const size_t xo = ((size_t)(pb[h] + iy) * a.W + ix) * a.Cin + ci;
-                vh = *reinterpret_cast<const f16x8*>(a.xhi + xo);
-                vl = *reinterpret_cast<const f16x8*>(a.xlo + xo);
-            }
-            rx[h] = vh;
-            rx[2 + h] = vl;
+        for (int e = 0; e < 8; ++e) { vh[e] = (_Float16)0.f; vl[e] = (_Float16)0.f; }
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+            const size_t xo = ((size_t)(pb + iy) * a.W + ix) * a.Cin + ci;
+            vh = *reinterpret_cast<const f16x8*>(a.xhi + xo);
+            vl = *reinterpret_cast<const f16x8*>(a.xlo + xo);
         }
+        rx[0] = vh;
+        rx[1] = vl;
     };
     auto stage = [&](int buf) {
         _Float16* L = lds + buf * SBUF;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int off = (r0 + 64 * h) * SROW + kc * 8;
-            *reinterpret_cast<f16x8*>(L + P_AHI + off) = rw[h];
-            *reinterpret_cast<f16x8*>(L + P_ALO + off) = rw[2 + h];
-            *reinterpret_cast<f16x8*>(L + P_BHI + off) = rx[h];
-            *reinterpret_cast<f16x8*>(L + P_BLO + off) = rx[2 + h];
-        }
+        const int off = r0 * SROW + kc * 8;
+        *reinterpret_cast<f16x8*>(L + P_AHI + off) = rw[0];
+        *reinterpret_cast<f16x8*>(L + P_ALO + off) = rw[1];
+        *reinterpret_cast<f16x8*>(L + P_BHI + off) = rx[0];
+        *reinterpret_cast<f16x8*>(L + P_BLO + off) = rx[1];
     };
 
-    f32x16 hh[2][2], xx[2][2];
+    f32x16 hh[1][2], xx[1][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { hh[mi][ni][r] = 0.f; xx[mi][ni][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { hh[0][ni][r] = 0.f; xx[0][ni][r] = 0.f; }
 
     const int nstep = a.K / SBK;
     gload(0);
     stage(0);
     __syncthreads();
-    const int arow = (wm * 64 + (lane & 31)) * SROW + (lane >> 5) * 8;
+    const int arow = (wm * 32 + (lane & 31)) * SROW + (lane >> 5) * 8;
     const int brow = (wn * 64 + (lane & 31)) * SROW + (lane >> 5) * 8;
     for (int s = 0; s < nstep; ++s) {
         const int buf = s & 1;
@@ -312,19 +302,16 @@ __global__ __launch_bounds__(SNT, 2) void conv_split_kernel(const ConvSplitArgs 
         const _Float16* L = lds + buf * SBUF;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            f16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                ah[mi] = *reinterpret_cast<const f16x8*>(L + P_AHI + arow + mi * 32 * SROW + ks * 16);
-                al[mi] = *reinterpret_cast<const f16x8*>(L + P_ALO + arow + mi * 32 * SROW + ks * 16);
-            }
+            f16x8 ah[1], al[1], bh[2], bl[2];
+            ah[0] = *reinterpret_cast<const f16x8*>(L + P_AHI + arow + ks * 16);
+            al[0] = *reinterpret_cast<const f16x8*>(L + P_ALO + arow + ks * 16);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 bh[ni] = *reinterpret_cast<const f16x8*>(L + P_BHI + brow + ni * 32 * SROW + ks * 16);
                 bl[ni] = *reinterpret_cast<const f16x8*>(L + P_BLO + brow + ni * 32 * SROW + ks * 16);
             }
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < 1; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     hh[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], hh[mi][ni], 0, 0, 0);
@@ -338,13 +325,13 @@ __global__ __launch_bounds__(SNT, 2) void conv_split_kernel(const ConvSplitArgs 
 
     // epilogue: lane = pixel column, registers = 4 x (4 consecutive output channels)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 1; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int pix = j0 + wn * 64 + ni * 32 + (lane & 31);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int co = i0 + wm * 64 + mi * 32 + 8 * g + 4 * (lane >> 5);
+                const int co = i0 + wm * 32 + 8 * g + 4 * (lane >> 5);
                 if (co >= a.Cout) continue;  // padded weight rows (Cout % 128 == 64)
                 float v[4];
 #pragma unroll
@@ -446,7 +433,7 @@ int gp_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* w_hi, c
     GpProfScope prof(GP_PROF_CONV, 2.0 * Cout * (double)npix * a.K, (hipStream_t)stream);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               SLDS_BYTES);
-    hipLaunchKernelGGL(conv_split_kernel, dim3(xcd_chunked_grid(a.tiles_co * a.tiles_pix)), dim3(SNT), SLDS_BYTES,
+    hipLaunchKernelGGL(conv_split_kernel, dim3(xcd_chunked_grid(a.tiles_co * a.tiles_pix)), dim3(512), SLDS_BYTES,
                        (hipStream_t)stream, a);
     GP_CHECK_LAUNCH("gp_conv2d_nhwc_split");
     return GP_OK;

@@ -205,7 +205,8 @@ def test_ist_outputs_as_close_to_f64_truth_as_the_reference(golden_dir):
     assert np.median(em) <= 3 * np.median(er) + 1e-6 and np.percentile(em, 99) <= 5 * np.percentile(er, 99) + 1e-5
 
 
-def test_template_sharded_path_over_rccl_equals_unsharded(monkeypatch):
+@pytest.mark.parametrize("numerics", ["chain", "split"])
+def test_template_sharded_path_over_rccl_equals_unsharded(monkeypatch, numerics):
     """The N>1 path on the 1-GPU box: torch.distributed 'nccl' (= RCCL) process group of ONE rank with the
     all-gathers forced (GIGAPOSE_FORCE_COLLECTIVES): exchange #1/#2, packing, merge and the hand-over to IST /
     RANSAC / recovery run on device buffers through RCCL and must reproduce the unsharded predict() exactly.
@@ -223,6 +224,7 @@ def test_template_sharded_path_over_rccl_equals_unsharded(monkeypatch):
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", str(port))
     monkeypatch.setenv("GIGAPOSE_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("GIGAPOSE_NUMERICS", numerics)   # split: the exchange carries the f16 hi/lo query planes
     dev = torch.device("cuda", 0)
     tset = factory.TemplateSet(2, 9, seed=60)
     q = tset.crops(61, 5, dev)

@@ -168,6 +168,19 @@ class LocalSimilarity(torch.nn.Module):
         return PandasTensorCollection(infos=pd.DataFrame(), id_src=ids.long(), score_src=score_src,
                                       score_pts=rec_score, tar_pts=tar_pts, src_pts=src_pts)
 
+    # ---- validation-time matcher (reference matching.py:115-186) ---------------------------
+    def val(self, src_feat, tar_feat, src_mask, tar_mask):
+        """src_feat / tar_feat (B,C,16,16), masks (B,224,224): detection b against ITS OWN template -- the same
+        fused tile kernel with one template per 'object'.  Returns src_pts, tar_pts (B,256,2) int64 (-1 = invalid)
+        and score (B,256) = the raw best similarity per query patch."""
+        B = tar_feat.shape[0]
+        dev = tar_feat.device
+        bank = MatchBank(src_feat.unsqueeze(1), src_mask.unsqueeze(1), self.numerics)      # O = B objects x N = 1
+        labels0 = torch.arange(B, dtype=torch.int32, device=dev)
+        idx, sc, ma, _ = self.match_tiles(self.normalize(tar_feat), patch_grid_mask(tar_mask), bank, labels0)
+        tar_pts, src_pts = self.format_points(idx.contiguous(), ma.contiguous())            # (B,1,256,2)
+        return PandasTensorCollection(infos=pd.DataFrame(), src_pts=src_pts[:, 0], tar_pts=tar_pts[:, 0], score=sc[:, 0])
+
     # ---- reference-signature entry point ---------------------------------------------------
     def test(self, src_feats, tar_feat, src_masks, tar_mask, max_batch_size=None):
         """Reference signature (matching.py:188): src_feats (B,N,C,H,W) is a per-detection

@@ -125,6 +125,18 @@ def local_similarity_test(src_feats, tar_feat, src_masks224, tar_mask224, labels
                 mask_all=ma)
 
 
+def local_similarity_val(src_feat, tar_feat, src_mask224, tar_mask224, thr=0.5, patch_thr=3.0):
+    """LocalSimilarity.val (matching.py:115-186): detection b against ITS OWN template src_feat[b] -- the same tile
+    arithmetic as `test` with N = 1; returns the reference's src_pts / tar_pts (B,256,2) and score (B,256)."""
+    B, C = tar_feat.shape[:2]
+    q = l2norm_cp(np.asarray(tar_feat).reshape(B, C, P))
+    bank = l2norm_cp(np.asarray(src_feat).reshape(B, 1, C, P))
+    idx, sc, ma, _ = match(q, bank, patch_mask(tar_mask224), patch_mask(src_mask224).reshape(B, 1, P),
+                           np.arange(B, dtype=np.int32), thr, patch_thr)
+    _, tar_pts, src_pts = gather_format(np.zeros((B, 1), np.int32), idx, sc, ma)
+    return dict(src_pts=src_pts[:, 0], tar_pts=tar_pts[:, 0], score=sc[:, 0])
+
+
 def gemm_kmajor(A, B, epi=0, bias=None, scale=None, res=None):
     """D[i][j] = epi(sum_k A[k][i] B[k][j]) with the sequential-fmaf order of gp_gemm.hip."""
     A, B = _f32(A), _f32(B)

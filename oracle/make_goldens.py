@@ -49,6 +49,22 @@ def gen_matcher():
               "valid pts:", int((out.tar_pts[..., 0] >= 0).sum()))
 
 
+def gen_val():
+    """LocalSimilarity.val (reference matching.py:115-186): one template per detection (the validation-time matcher)."""
+    ref_shim.install()
+    from src.models.matching import LocalSimilarity
+
+    kw = dict(seed=16, B=6, O=3, N=1, C=64, noise=0.25, shift=False)
+    case = syn.matcher_case(**kw)
+    metric = LocalSimilarity(k=1, sim_threshold=0.5, patch_threshold=3)
+    out = metric.val(src_feat=torch.from_numpy(case["src_feats"][case["labels"], 0]), tar_feat=torch.from_numpy(case["tar_feat"]),
+                     src_mask=torch.from_numpy(case["src_masks"][case["labels"], 0]), tar_mask=torch.from_numpy(case["tar_mask"]))
+    np.savez_compressed(os.path.join(GOLD, "match_val.npz"), input_checksum=syn.checksum(*[case[x] for x in sorted(case)]),
+                        case_kwargs=repr(kw), src_pts=out.src_pts.numpy().astype(np.int16),
+                        tar_pts=out.tar_pts.numpy().astype(np.int16), score=out.score.numpy())
+    print("val: valid pts", int((out.tar_pts[..., 0] >= 0).sum()), "score max", float(out.score.max()))
+
+
 IST_CFG = dict(n_heads=0, input_dim=3, input_size=256, initial_dim=128, block_dims=[128, 192, 256, 512],
                descriptor_size=256)
 
@@ -271,7 +287,7 @@ def gen_bop_csv():
     print("bop_csv:", [k for k in gold if k != "seed"])
 
 
-STAGES = {"bop_csv": gen_bop_csv, "matcher": gen_matcher, "ist": gen_ist, "pose": gen_pose, "e2e": gen_e2e, "crop": gen_crop}
+STAGES = {"bop_csv": gen_bop_csv, "val": gen_val, "matcher": gen_matcher, "ist": gen_ist, "pose": gen_pose, "e2e": gen_e2e, "crop": gen_crop}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

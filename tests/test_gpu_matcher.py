@@ -142,3 +142,25 @@ def test_full_size_config2_properties():
     np.testing.assert_array_equal(perm[hip2["id_src"][:, 0]], hip["id_src"][:, 0])
     np.testing.assert_array_equal(hip2["src_pts"][:, 0], hip["src_pts"][:, 0])
     np.testing.assert_array_equal(hip2["score_src"][:, 0].view(np.uint32), hip["score_src"][:, 0].view(np.uint32))
+
+
+@pytest.mark.parametrize("numerics", ["chain", "split"])
+def test_val_matches_reference_golden_and_oracle(golden_dir, numerics, monkeypatch):
+    """LocalSimilarity.val through the HIP tile kernel: reference golden (indices bit-exact, scores 1e-6); chain mode
+    additionally bit-exact against the oracle."""
+    import ast
+
+    from gigapose_amd.matching import LocalSimilarity
+
+    monkeypatch.setenv("GIGAPOSE_NUMERICS", numerics)
+    g = np.load(os.path.join(golden_dir, "match_val.npz"))
+    case = syn.matcher_case(**ast.literal_eval(str(g["case_kwargs"])))
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    out = LocalSimilarity(k=1, sim_threshold=0.5, patch_threshold=3).val(t(case["src_feats"][case["labels"], 0]), t(case["tar_feat"]),
+                                                                         t(case["src_masks"][case["labels"], 0]), t(case["tar_mask"]))
+    np.testing.assert_array_equal(out.src_pts.cpu().numpy(), g["src_pts"].astype(np.int64))
+    np.testing.assert_array_equal(out.tar_pts.cpu().numpy(), g["tar_pts"].astype(np.int64))
+    np.testing.assert_allclose(out.score.cpu().numpy(), g["score"], rtol=0, atol=1e-6)
+    if numerics == "chain":
+        ref = oracle.local_similarity_val(case["src_feats"][case["labels"], 0], case["tar_feat"], case["src_masks"][case["labels"], 0], case["tar_mask"])
+        np.testing.assert_array_equal(out.score.cpu().numpy().view(np.uint32), ref["score"].view(np.uint32))

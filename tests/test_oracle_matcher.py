@@ -65,3 +65,14 @@ def test_all_zero_rows_and_topk_ties():
     assert ids.tolist() == [[0, 1, 2, 3, 4]] and not s.any()
     sp, tp, srcp = oracle.gather_format(ids, idx, sc, ma)
     assert (tp == -1).all() and (srcp == -1).all()
+
+
+def test_oracle_val_matches_reference_golden(golden_dir):
+    """LocalSimilarity.val (validation-time matcher, one template per detection)."""
+    g = np.load(os.path.join(golden_dir, "match_val.npz"))
+    case = syn.matcher_case(**ast.literal_eval(str(g["case_kwargs"])))
+    assert syn.checksum(*[case[x] for x in sorted(case)]) == str(g["input_checksum"])
+    out = oracle.local_similarity_val(case["src_feats"][case["labels"], 0], case["tar_feat"], case["src_masks"][case["labels"], 0], case["tar_mask"])
+    np.testing.assert_array_equal(out["src_pts"], g["src_pts"].astype(np.int64))
+    np.testing.assert_array_equal(out["tar_pts"], g["tar_pts"].astype(np.int64))
+    np.testing.assert_allclose(out["score"], g["score"], rtol=0, atol=1e-6)

@@ -190,7 +190,7 @@ def main():
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if args.variant == "dinov2_vitl14" and args.batch == 64 and args.templates == 162:
-            traffic = round(pmc["gemm_kmajor"]["hbm_bytes_per_launch"])
+            traffic = round(pmc["gemm_split" if args.numerics == "split" else "gemm_kmajor"]["hbm_bytes_per_launch"])
     except Exception:
         pass
     F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
@@ -204,7 +204,7 @@ def main():
                     "algorithmic_tflops_f32_equivalent": alg,
                     "note": "achieved = 3 x algorithmic 2IJK flops / launch time (the three f16 products per f32-equivalent "
                             "product all execute on the matrix core); the f32-input MFMA peak this mode replaces is 157.3",
-                    "traffic": None}
+                    "traffic": traffic}
     else:
         g = kern.get("gemm_kmajor", {})
         achieved = g.get("TFLOP/s", 0.0)

@@ -15,7 +15,9 @@ def short(n):
 
 
 FAMILIES = [("gemm_kmajor", ("gemm_kmajor_kernel", "gemm_streamk_kernel")), ("match_tiles", ("match_tiles_kernel",)),
-            ("attention", ("attention_kernel",)), ("layernorm", ("layernorm",)), ("conv", ("conv_kernel", "conv3x3_kernel"))]
+            ("attention", ("attention_kernel",)), ("layernorm", ("layernorm",)), ("conv", ("conv_kernel", "conv3x3_kernel")),
+            ("gemm_split", ("gemm_split_kernel",)), ("match_split", ("match_tiles_split_kernel",)),
+            ("conv_split", ("conv_split_kernel",))]
 
 
 def family_json(acc, path):
@@ -51,7 +53,7 @@ def main(root, json_path=None):
         for (d, c), v in per_dispatch.items():
             acc[names[d]][c].append(v)
     for k in sorted(acc):
-        if "gemm" not in k[0] and "match" not in k[0] and "conv" not in k[0] and "attention" not in k[0] and "layernorm" not in k[0]:
+        if not any(t in k[0] for t in ("gemm", "match", "conv", "attention", "layernorm", "split")):
             continue
         print(f"{k[0]}  grid={k[1]}")
         for c, v in sorted(acc[k].items()):

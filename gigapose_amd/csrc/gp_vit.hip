@@ -136,48 +136,190 @@ int launch_layernorm(const float* X, float* Y, const float* g, const float* b, i
 // dot product equals scaling q first).
 constexpr int NKT = 9;  // ceil(257 / 32) key tiles
 
-__global__ __launch_bounds__(64, 4) void attention_kernel(const float* __restrict__ QK /*[2C][Mpad]*/,
-                                                           const float* __restrict__ Vt /*[Mpad][C]*/,
-                                                           float* __restrict__ O /*[C][Mpad]*/, int B, int H,
-                                                           int C, int Mpad, float scale)
+// NQ query tiles of 32 per wave share every K / V operand load (one 4-byte global load feeds NQ MFMAs).
+template <int NQ>
+__device__ __forceinline__ void attention_body(const float* __restrict__ Qp, const float* __restrict__ Kp,
+                                               const float* __restrict__ Vp, float* __restrict__ Op, int q0, int C,
+                                               int Mpad, float scale)
 {
-    const int q = xcd_chunked_tile(blockIdx.x, B * H * NKT);
-    if (q < 0) return;
-    const int qb = q % NKT, bh = q / NKT, h = bh % H, b = bh / H;
     const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
-    const float* Qp = QK + (size_t)(h * 64) * Mpad + (size_t)b * T_TOK;
-    const float* Kp = QK + (size_t)(C + h * 64) * Mpad + (size_t)b * T_TOK;
-    const float* Vp = Vt + (size_t)b * T_TOK * C + h * 64;
-    const int tq = qb * 32 + l31;
-    const int tq_c = tq < T_TOK ? tq : T_TOK - 1;
-
-    // Online softmax over 3 chunks of 3 key tiles (96 keys): 48 score registers instead of 144, so
-    // four waves fit per SIMD and hide the L2 latency of the operand loads.
-    f32x16 o0, o1;
+    int tq[NQ], tq_c[NQ];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m_run = -INFINITY, l_part = 0.f;  // l_part: this lane-half's share of the softmax denominator
+    for (int u = 0; u < NQ; ++u) {
+        tq[u] = q0 + 32 * u + l31;
+        tq_c[u] = tq[u] < T_TOK ? tq[u] : T_TOK - 1;
+    }
+    // Online softmax over 3 chunks of 3 key tiles (96 keys).
+    f32x16 o0[NQ], o1[NQ];
+    float m_run[NQ], l_part[NQ];  // l_part: this lane-half's share of the softmax denominator
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[u][r] = 0.f; o1[u][r] = 0.f; }
+        m_run[u] = -INFINITY;
+        l_part[u] = 0.f;
+    }
 
 #pragma unroll 1
     for (int ch = 0; ch < 3; ++ch) {
-        f32x16 s[3];
+        f32x16 s[3][NQ];
         int tk_c[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+            for (int u = 0; u < NQ; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t][u][r] = 0.f;
             const int tk = (ch * 3 + t) * 32 + l31;
             tk_c[t] = tk < T_TOK ? tk : T_TOK - 1;
         }
 #pragma unroll 8
         for (int kk = 0; kk < 32; ++kk) {
             const size_t drow = (size_t)(2 * kk + half) * Mpad;
-            const float qv = Qp[drow + tq_c];
+            float qv[NQ];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) qv[u] = Qp[drow + tq_c[u]];
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const float kv = Kp[drow + tk_c[t]];
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv, s[t], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) s[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv[u], s[t][u], 0, 0, 0);
             }
+        }
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            float cmax = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tk = (ch * 3 + t) * 32 + frag_row(r, lane);
+                    const float v = (tk < T_TOK) ? s[t][u][r] * scale : -INFINITY;
+                    s[t][u][r] = v;
+                    cmax = fmaxf(cmax, v);
+                }
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+            const float m_new = fmaxf(m_run[u], cmax);
+            const float alpha = expf(m_run[u] - m_new);  // first chunk: exp(-inf) = 0
+            float psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = expf(s[t][u][r] - m_new);
+                    s[t][u][r] = p;
+                    psum += p;
+                }
+            l_part[u] = l_part[u] * alpha + psum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[u][r] *= alpha; o1[u][r] *= alpha; }
+            m_run[u] = m_new;
+        }
+        // O[d][tq] += sum_tk V[tk][d] * P[tk][tq]; the A-operand lane (i = d, k-slot = half) reads
+        // V[tk = tile*32 + frag_row(r, lane)][d] -- the key this lane's P register r belongs to.
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int tk = (ch * 3 + t) * 32 + frag_row(r, lane);
+                tk = tk < T_TOK ? tk : T_TOK - 1;  // P is 0 there; keep the load in bounds / finite
+                const float* vrow = Vp + (size_t)tk * C + l31;
+                const float v0 = vrow[0], v1 = vrow[32];
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) {
+                    o0[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[t][u][r], o0[u], 0, 0, 0);
+                    o1[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[t][u][r], o1[u], 0, 0, 0);
+                }
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const float inv = 1.0f / (l_part[u] + __shfl_xor(l_part[u], 32));
+        if (tq[u] < T_TOK) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = frag_row(r, lane);
+                Op[(size_t)d * Mpad + tq[u]] = o0[u][r] * inv;
+                Op[(size_t)(32 + d) * Mpad + tq[u]] = o1[u][r] * inv;
+            }
+        }
+    }
+}
+
+// One wave per (image, head, query block).  NQ = 1: nine blocks of 32 queries (the first version; kept as the A/B
+// reference, results are bit-identical).  NQ = 2: four blocks of 64 queries + one of 32 (the 257th token), so eight
+// of the nine query tiles share their K / V operand loads pairwise.
+template <int NQ>
+__global__ __launch_bounds__(64, NQ == 1 ? 4 : 2) void attention_kernel(const float* __restrict__ QK /*[2C][Mpad]*/,
+                                                                         const float* __restrict__ Vt /*[Mpad][C]*/,
+                                                                         float* __restrict__ O /*[C][Mpad]*/, int B, int H,
+                                                                         int C, int Mpad, float scale)
+{
+    constexpr int NB = NQ == 1 ? NKT : 5;
+    const int q = xcd_chunked_tile(blockIdx.x, B * H * NB);
+    if (q < 0) return;
+    const int qb = q % NB, bh = q / NB, h = bh % H, b = bh / H;
+    const float* Qp = QK + (size_t)(h * 64) * Mpad + (size_t)b * T_TOK;
+    const float* Kp = QK + (size_t)(C + h * 64) * Mpad + (size_t)b * T_TOK;
+    const float* Vp = Vt + (size_t)b * T_TOK * C + h * 64;
+    float* Op = O + (size_t)(h * 64) * Mpad + (size_t)b * T_TOK;
+    if (NQ == 1) attention_body<1>(Qp, Kp, Vp, Op, qb * 32, C, Mpad, scale);
+    else if (qb < 4) attention_body<2>(Qp, Kp, Vp, Op, qb * 64, C, Mpad, scale);
+    else attention_body<1>(Qp, Kp, Vp, Op, 256, C, Mpad, scale);
+}
+
+// K and V of one (image, head) staged in LDS ONCE and shared by the nine query-tile waves of the workgroup (the
+// register-resident kernel above re-reads them from L2 with one 4-byte load per MFMA, nine times per (image, head)).
+//   sK [64 d][288 keys] (keys >= 257 zero), sV [288 keys][64 d]: 147 KB -> one workgroup per CU, 9 waves.
+// Operand reads are conflict-free ds_read_b32 (lanes = consecutive keys / consecutive d).  Q fragments are loaded once
+// per wave (32 registers).  Arithmetic per (key, query) is the same MFMA chain and the same 3-chunk online softmax
+// as attention_body, so the result is bit-identical.
+constexpr int AK = 288;  // padded key count
+__global__ __launch_bounds__(576, 1) void attention_lds_kernel(const float* __restrict__ QK, const float* __restrict__ Vt,
+                                                                float* __restrict__ O, int B, int H, int C, int Mpad,
+                                                                float scale)
+{
+    __shared__ float sK[64 * AK];
+    __shared__ float sV[AK * 64];
+    const int bh = xcd_chunked_tile(blockIdx.x, B * H);
+    if (bh < 0) return;
+    const int h = bh % H, b = bh / H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const float* Qp = QK + (size_t)(h * 64) * Mpad + (size_t)b * T_TOK;
+    const float* Kp = QK + (size_t)(C + h * 64) * Mpad + (size_t)b * T_TOK;
+    const float* Vp = Vt + (size_t)b * T_TOK * C + h * 64;
+    float* Op = O + (size_t)(h * 64) * Mpad + (size_t)b * T_TOK;
+    for (int e = tid; e < 64 * AK; e += 576) {
+        const int d = e / AK, key = e - d * AK;
+        sK[e] = key < T_TOK ? Kp[(size_t)d * Mpad + key] : 0.f;
+    }
+    for (int e = tid; e < AK * 64; e += 576) {
+        const int key = e >> 6, d = e & 63;
+        sV[e] = key < T_TOK ? Vp[(size_t)key * C + d] : 0.f;
+    }
+    const int tq = wave * 32 + l31;
+    const int tq_c = tq < T_TOK ? tq : T_TOK - 1;
+    float qreg[32];
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) qreg[kk] = Qp[(size_t)(2 * kk + half) * Mpad + tq_c];
+    __syncthreads();
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_part = 0.f;
+#pragma unroll 1
+    for (int ch = 0; ch < 3; ++ch) {
+        f32x16 s[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const float* krow = sK + (2 * kk + half) * AK + ch * 96 + l31;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) s[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[32 * t], qreg[kk], s[t], 0, 0, 0);
         }
         float cmax = -INFINITY;
 #pragma unroll
@@ -191,7 +333,7 @@ __global__ __launch_bounds__(64, 4) void attention_kernel(const float* __restric
             }
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
         const float m_new = fmaxf(m_run, cmax);
-        const float alpha = expf(m_run - m_new);  // first chunk: exp(-inf) = 0
+        const float alpha = expf(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -205,15 +347,12 @@ __global__ __launch_bounds__(64, 4) void attention_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
         m_run = m_new;
-        // O[d][tq] += sum_tk V[tk][d] * P[tk][tq]; the A-operand lane (i = d, k-slot = half) reads
-        // V[tk = tile*32 + frag_row(r, lane)][d] -- the key this lane's P register r belongs to.
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int tk = (ch * 3 + t) * 32 + frag_row(r, lane);
-                tk = tk < T_TOK ? tk : T_TOK - 1;  // P is 0 there; keep the load in bounds / finite
-                const float* vrow = Vp + (size_t)tk * C + l31;
+                const int tk = (ch * 3 + t) * 32 + frag_row(r, lane);  // < 288; rows >= 257 are zero and P is 0 there
+                const float* vrow = sV + tk * 64 + l31;
                 o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], s[t][r], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], s[t][r], o1, 0, 0, 0);
             }
@@ -223,11 +362,17 @@ __global__ __launch_bounds__(64, 4) void attention_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = frag_row(r, lane);
-            O[(size_t)(h * 64 + d) * Mpad + (size_t)b * T_TOK + tq] = o0[r] * inv;
-            O[(size_t)(h * 64 + 32 + d) * Mpad + (size_t)b * T_TOK + tq] = o1[r] * inv;
+            Op[(size_t)d * Mpad + tq] = o0[r] * inv;
+            Op[(size_t)(32 + d) * Mpad + tq] = o1[r] * inv;
         }
     }
 }
+
+// Measured on ViT-L, B=64 (tools/probe_attn.py, whole forward in split numerics): register-resident with one query tile
+// per wave 58.2 ms; two tiles per wave (operand loads shared, 226 VGPR -> 2 waves/SIMD) 60.4 ms; K/V through LDS (one
+// 147 KB workgroup per CU, staging not overlapped) 60.8 ms.  Occupancy wins: the default stays 1.
+static int g_attn_nq = 1;  // 0: LDS-shared K/V kernel; 1 / 2: register-resident kernel with 1 / 2 query tiles per wave
+extern "C" void gp_attention_set_nq(int nq) { g_attn_nq = (nq >= 0 && nq <= 2) ? nq : 1; }
 
 // ---- x_prenorm[:, 1:] -> (B, C, 256), F.normalize over C (ae_net.py:64-69); fixed fmaf order
 __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__ X, float* __restrict__ out,
@@ -351,8 +496,15 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
         if (rc) return rc;
         {
             GpProfScope prof(GP_PROF_ATTN, 4.0 * B * heads * 257.0 * 257.0 * 64.0, st);
-            hipLaunchKernelGGL(attention_kernel, dim3(xcd_chunked_grid(B * heads * NKT)), dim3(64), 0, st, QK, Vt,
-                               Hn, B, heads, C, Mpad, 0.125f);
+            if (g_attn_nq == 0)
+                hipLaunchKernelGGL(attention_lds_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(576), 0, st, QK, Vt, Hn, B, heads, C,
+                                   Mpad, 0.125f);
+            else if (g_attn_nq == 1)
+                hipLaunchKernelGGL(attention_kernel<1>, dim3(xcd_chunked_grid(B * heads * NKT)), dim3(64), 0, st, QK, Vt, Hn, B,
+                                   heads, C, Mpad, 0.125f);
+            else
+                hipLaunchKernelGGL(attention_kernel<2>, dim3(xcd_chunked_grid(B * heads * 5)), dim3(64), 0, st, QK, Vt, Hn, B,
+                                   heads, C, Mpad, 0.125f);
         }
         GP_CHECK_LAUNCH("gp_vit_forward/attention");
         // x = x + ls1 * proj(attn)

@@ -164,6 +164,9 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
                    const float* const* weights, int n_weights, float* workspace, size_t workspace_bytes,
                    float* out_features, int normalize, int stop_after_layers, void* stream);
 
+void gp_attention_set_nq(int nq); /* tuning / test hook: 1 (default) / 2 = register-resident kernel with 1 / 2 query tiles
+                                     per wave; 0 = K/V shared through LDS (results identical) */
+
 /* gp_vit_forward with the linear layers in split-f16 numerics: `split` = HOST array of n_split = 10*depth DEVICE
  * pointers, per layer: qk_hi, qk_lo (2dim, dim), v_hi, v_lo (dim, dim), proj_hi, proj_lo (dim, dim),
  * fc1_hi, fc1_lo (mlp, dim), fc2_hi, fc2_lo (dim, mlp) -- f16 planes of the PyTorch-native [out][in] weights,

@@ -175,3 +175,19 @@ def test_aenet_interface_chunks():
     assert tuple(a.shape) == (5, 128, 16, 16)
     np.testing.assert_array_equal(a.cpu().numpy().view(np.uint32), b.cpu().numpy().view(np.uint32))
     assert tuple(net(x[:0].to(DEV)).shape) == (0, 128, 16, 16)
+
+
+def test_attention_variants_are_bit_identical():
+    """The three attention kernels (1 or 2 query tiles per wave, K/V through LDS) run the same MFMA chains."""
+    from gigapose_amd import _lib
+
+    hf, vit, x = run_vit(128, 2, 2, 3, seed=61)
+    lib = _lib.lib()
+    outs = []
+    try:
+        for nq in (1, 2, 0):
+            lib.gp_attention_set_nq(nq)
+            outs.append(vit.patch_features(x.to(DEV), normalize=False).cpu())
+    finally:
+        lib.gp_attention_set_nq(1)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

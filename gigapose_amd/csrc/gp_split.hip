@@ -66,7 +66,9 @@ struct SplitArgs {
 __device__ __forceinline__ float gelu_erf_s(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // ACT_IS_B: activations are the j operand (D = W . X: qk / proj / fc1 / fc2); else the i operand (token-major V).
-template <int EPI, bool ACT_IS_B>
+__device__ unsigned long long g_split_clk[4][5];  // [wave][phase] cycle totals of one mid-grid block (tools/probe_split.py)
+
+template <int EPI, bool ACT_IS_B, bool TIMING = false>
 __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
@@ -85,52 +87,45 @@ __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
     const int act_hi = ACT_IS_B ? P_BHI : P_AHI, act_lo = ACT_IS_B ? P_BLO : P_ALO;
     const int w_hi = ACT_IS_B ? P_AHI : P_BHI, w_lo = ACT_IS_B ? P_ALO : P_BLO;
 
-    // staging roles: waves 0-1 convert the activation tile (4 n x 8 k micro-block per thread), waves 2-3 copy the
-    // pre-split weight tile (8 x 16-byte chunks per thread)
-    const bool act_role = tid < 128;
-    const int t7 = tid & 127;
-    f32x4 ract[8];   // activation role: rows k = kg*8 .. +7, columns n = ng*4 .. +3
-    f16x8 rw[8];     // weight role: chunk c = t7 + 128*u: plane (c >> 9), row (c & 511) >> 2, k-chunk c & 3
-    const int ng = t7 & 31, kg = t7 >> 5;
+    // Staging, balanced over all 256 threads: every thread converts a 2 n x 8 k activation micro-block (8 float2
+    // loads, 16 splits, 4 ds_write_b128) and copies four 16-byte chunks of the pre-split weight tile.  (With the
+    // conversion on two of the four waves only, those two set the pace of every k-step: 1760 of 3585 cycles, the other
+    // two waiting 1400 at the barrier -- measured with gp_gemm_split_timing.)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 ract[8];
+    f16x8 rw[4];
+    const int ng = tid & 63, kg = tid >> 6;  // 64 column pairs x 4 k-groups of 8
     auto gload = [&](int k0) {
-        if (act_role) {
-            const float* src = a.act + (size_t)(k0 + kg * 8) * a.ld_act + n_act0 + ng * 4;
+        const float* src = a.act + (size_t)(k0 + kg * 8) * a.ld_act + n_act0 + ng * 2;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) ract[r] = *reinterpret_cast<const f32x4*>(src + (size_t)r * a.ld_act);
-        } else {
+        for (int r = 0; r < 8; ++r) ract[r] = *reinterpret_cast<const f32x2*>(src + (size_t)r * a.ld_act);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = t7 + 128 * u;
-                const int row = (c & 511) >> 2, kc = c & 3;
-                const _Float16* base = (c >> 9) ? a.wlo : a.whi;
-                rw[u] = *reinterpret_cast<const f16x8*>(base + (size_t)(n_w0 + row) * a.K + k0 + kc * 8);
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int c = tid + 256 * u;  // plane c >> 9, row (c & 511) >> 2, k-chunk c & 3
+            const _Float16* base = (c >> 9) ? a.wlo : a.whi;
+            rw[u] = *reinterpret_cast<const f16x8*>(base + (size_t)(n_w0 + ((c & 511) >> 2)) * a.K + k0 + (c & 3) * 8);
         }
     };
     auto stage = [&](int buf) {
         _Float16* L = lds + buf * SBUF;
-        if (act_role) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {  // column n = ng*4 + c: 8 consecutive k
-                f16x8 h, l;
+        for (int u = 0; u < 4; ++u) {
+            const int c = tid + 256 * u;
+            *reinterpret_cast<f16x8*>(L + ((c >> 9) ? w_lo : w_hi) + ((c & 511) >> 2) * SROW + (c & 3) * 8) = rw[u];
+        }
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    _Float16 hh, ll;
-                    split1(ract[r][c], hh, ll);
-                    h[r] = hh;
-                    l[r] = ll;
-                }
-                const int off = (ng * 4 + c) * SROW + kg * 8;
-                *reinterpret_cast<f16x8*>(L + act_hi + off) = h;
-                *reinterpret_cast<f16x8*>(L + act_lo + off) = l;
+        for (int c = 0; c < 2; ++c) {  // column n = ng*2 + c: 8 consecutive k
+            f16x8 h, l;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                _Float16 hh_, ll_;
+                split1(ract[r][c], hh_, ll_);
+                h[r] = hh_;
+                l[r] = ll_;
             }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = t7 + 128 * u;
-                const int row = (c & 511) >> 2, kc = c & 3;
-                *reinterpret_cast<f16x8*>(L + ((c >> 9) ? w_lo : w_hi) + row * SROW + kc * 8) = rw[u];
-            }
+            const int off = (ng * 2 + c) * SROW + kg * 8;
+            *reinterpret_cast<f16x8*>(L + act_hi + off) = h;
+            *reinterpret_cast<f16x8*>(L + act_lo + off) = l;
         }
     };
 
@@ -148,9 +143,13 @@ __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
     __syncthreads();
     const int arow = (wm * 64 + (lane & 31)) * SROW + (lane >> 5) * 8;
     const int brow = (wn * 64 + (lane & 31)) * SROW + (lane >> 5) * 8;
+    const bool timed = TIMING && blockIdx.x == gridDim.x / 2 && lane == 0;
+    unsigned long long tc[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     for (int s = 0; s < nstep; ++s) {
         const int buf = s & 1;
+        if (TIMING) t0 = __builtin_readcyclecounter();
         if (s + 1 < nstep) gload((s + 1) * SBK);
+        if (TIMING) { t1 = __builtin_readcyclecounter(); tc[0] += t1 - t0; t0 = t1; }
         const _Float16* L = lds + buf * SBUF;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {  // two k16 blocks per staged slab
@@ -174,9 +173,18 @@ __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
                     xx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], xx[mi][ni], 0, 0, 0);
                 }
         }
+        if (TIMING) {  // issue of the LDS reads + MFMAs, then their completion (an accumulator element is read)
+            t1 = __builtin_readcyclecounter(); tc[1] += t1 - t0; t0 = t1;
+            asm volatile("" :: "v"(hh[1][1][15]), "v"(xx[1][1][15]));
+            t1 = __builtin_readcyclecounter(); tc[2] += t1 - t0; t0 = t1;
+        }
         if (s + 1 < nstep) stage(buf ^ 1);
+        if (TIMING) { t1 = __builtin_readcyclecounter(); tc[3] += t1 - t0; t0 = t1; }
         __syncthreads();
+        if (TIMING) { t1 = __builtin_readcyclecounter(); tc[4] += t1 - t0; }
     }
+    if (timed)
+        for (int ph = 0; ph < 5; ++ph) g_split_clk[wave][ph] = tc[ph];
 
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -437,6 +445,22 @@ int gp_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* w_hi, c
                        (hipStream_t)stream, a);
     GP_CHECK_LAUNCH("gp_conv2d_nhwc_split");
     return GP_OK;
+}
+
+/* probe: the fc-shaped GEMM (act_is_b, no epilogue) with per-phase cycle counters of one mid-grid block;
+ * out20 (host): [wave 0..3][gload issue, LDS-read+MFMA issue, MFMA drain, convert+LDS-write, barrier] */
+int gp_gemm_split_timing(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J, int K,
+                         unsigned long long* out20, void* stream)
+{
+    GP_REQUIRE(I % SBM == 0 && J % SBN == 0 && K % SBK == 0 && out20, "gp_gemm_split_timing: bad arguments");
+    SplitArgs a{act, ld_act, (const _Float16*)whi, (const _Float16*)wlo, D, ldd, K, nullptr, nullptr, nullptr, 0, I / SBM, J / SBN, 8};
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<SEPI_NONE, true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SLDS_BYTES);
+    hipLaunchKernelGGL((gemm_split_kernel<SEPI_NONE, true, true>), dim3(xcd_chunked_grid(a.tiles_i * a.tiles_j)), dim3(SNT),
+                       SLDS_BYTES, (hipStream_t)stream, a);
+    GP_CHECK_LAUNCH("gp_gemm_split_timing");
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
+    return hipMemcpyFromSymbol(out20, HIP_SYMBOL(g_split_clk), 20 * sizeof(unsigned long long)) == hipSuccess ? GP_OK : GP_ELAUNCH;
 }
 
 int gp_gemm_split(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J, int K,

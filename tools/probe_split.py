@@ -60,3 +60,15 @@ for (I, J, K, act_is_b, name) in [(1024, 16512, 1024, 1, "proj"), (4096, 16512, 
     es = ((D[rows].double() - ref).abs() / scale); ee = ((De[rows].double() - ref).abs() / scale)
     print(f"{name:5s} I={I} J={J} K={K}: split {ms_s:.3f} ms = {2.0*I*J*K/ms_s/1e9:.0f} TF-equivalent | exact {ms_e:.3f} ms = {2.0*I*J*K/ms_e/1e9:.0f} TF | "
           f"err/sum|ab| max: split {es.max().item():.2e} exact {ee.max().item():.2e}; rms: split {es.pow(2).mean().sqrt().item():.2e} exact {ee.pow(2).mean().sqrt().item():.2e}")
+
+# per-phase cycle breakdown of one mid-grid block (fc1 shape)
+I, J, K = 4096, 16512, 1024
+Wt = torch.randn(K, I, device=dev) * 0.05; X = torch.randn(K, J, device=dev)
+hi, lo = split_w(Wt); D = torch.empty(I, J, device=dev)
+out = (ctypes.c_ulonglong * 20)()
+for rep in range(2):
+    lib.gp_gemm_split_timing(_lib.ptr(X), J, _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(D), J, I, J, K, out, _lib.stream_ptr())
+names = ["gload issue", "LDS read + MFMA issue", "MFMA drain", "convert + LDS write", "barrier"]
+for w in range(4):
+    v = [out[w * 5 + p] for p in range(5)]
+    print(f"wave {w}: " + ", ".join(f"{n} {x / 32:.0f}" for n, x in zip(names, v)) + f"  (cycles per k-step; total {sum(v) / 32:.0f}; MFMA pipe time 768)")

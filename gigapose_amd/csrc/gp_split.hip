@@ -50,8 +50,13 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 enum { SEPI_NONE = 0, SEPI_BIAS_I = 1, SEPI_BIAS_I_GELU = 2, SEPI_BIAS_I_SCALE_RES = 3, SEPI_BIAS_J = 4, SEPI_BIAS_I_RELU = 5 };
 
 constexpr int SBM = 128, SBN = 128, SBK = 32, SNT = 256;
-constexpr int SROW = 40;                       // halfs per LDS row: 32 data + 8 pad (80 B: conflict-free ds_read_b128)
+constexpr int SROW = 32;                       // halfs per LDS row (64 B, no padding): the 16-byte chunk kc of row r sits at chunk
+                                               // position kc ^ ((r >> 2) & 3), so a ds_read_b128 lane group covers all 64 banks once
 constexpr int SPLANE = 128 * SROW;             // halfs per (operand, hi|lo) plane
+// 2 buffers x 4 planes x 8 KiB = 64 KiB per workgroup: TWO workgroups per CU.  (With 80-byte padded rows the kernel needed
+// 80 KiB; 2 x 80 KiB = the whole 160 KiB LDS did not co-reside, occupancy was one 4-wave workgroup per CU -- found with the
+// per-phase cycle probe: block time x tile count only matched the kernel time for ONE resident workgroup.)
+__device__ __forceinline__ int lds_off(int row, int kc) { return row * SROW + ((kc ^ ((row >> 2) & 3)) << 3); }
 constexpr int SBUF = 4 * SPLANE;               // A hi, A lo, B hi, B lo
 constexpr int SLDS_BYTES = 2 * SBUF * 2;       // double buffered: 81920 B
 
@@ -66,7 +71,8 @@ struct SplitArgs {
 __device__ __forceinline__ float gelu_erf_s(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // ACT_IS_B: activations are the j operand (D = W . X: qk / proj / fc1 / fc2); else the i operand (token-major V).
-__device__ unsigned long long g_split_clk[4][5];  // [wave][phase] cycle totals of one mid-grid block (tools/probe_split.py)
+__device__ unsigned long long g_split_clk[4][5];
+__device__ unsigned long long g_split_wall[4];  // block cycles, block 100 MHz wall ticks, occupancy query, unused  // [wave][phase] cycle totals of one mid-grid block (tools/probe_split.py)
 
 template <int EPI, bool ACT_IS_B, bool TIMING = false>
 __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = tid + 256 * u;
-            *reinterpret_cast<f16x8*>(L + ((c >> 9) ? w_lo : w_hi) + ((c & 511) >> 2) * SROW + (c & 3) * 8) = rw[u];
+            *reinterpret_cast<f16x8*>(L + ((c >> 9) ? w_lo : w_hi) + lds_off((c & 511) >> 2, c & 3)) = rw[u];
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {  // column n = ng*2 + c: 8 consecutive k
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
                 h[r] = hh_;
                 l[r] = ll_;
             }
-            const int off = (ng * 2 + c) * SROW + kg * 8;
+            const int off = lds_off(ng * 2 + c, kg);
             *reinterpret_cast<f16x8*>(L + act_hi + off) = h;
             *reinterpret_cast<f16x8*>(L + act_lo + off) = l;
         }
@@ -140,51 +146,116 @@ __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
     const int nstep = a.K / SBK;
     gload(0);
     stage(0);
+    if (nstep > 1) gload(SBK);  // slab 1 waits in registers for the first loop iteration
     __syncthreads();
-    const int arow = (wm * 64 + (lane & 31)) * SROW + (lane >> 5) * 8;
-    const int brow = (wn * 64 + (lane & 31)) * SROW + (lane >> 5) * 8;
+    // fragment addresses: row base + swizzled chunk of k16 block 0 / 1 (the swizzle depends on row bits 2-3 only, so it is
+    // the same for the rows +32 of the second MFMA tile)
+    const int ar_ = wm * 64 + (lane & 31), br_ = wn * 64 + (lane & 31), kh_ = lane >> 5;
+    const int arow = ar_ * SROW, brow = br_ * SROW;
+    const int ak0 = ((kh_ ^ ((ar_ >> 2) & 3)) << 3), ak1 = (((kh_ + 2) ^ ((ar_ >> 2) & 3)) << 3);
+    const int bk0 = ((kh_ ^ ((br_ >> 2) & 3)) << 3), bk1 = (((kh_ + 2) ^ ((br_ >> 2) & 3)) << 3);
     const bool timed = TIMING && blockIdx.x == gridDim.x / 2 && lane == 0;
     unsigned long long tc[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+    const unsigned long long blk_c0 = TIMING ? __builtin_readcyclecounter() : 0, blk_w0 = TIMING ? wall_clock64() : 0;
+    // running source pointers of this thread's 12 loads per k-step (8 activation float2 rows, 4 weight chunks)
+    const int nstep_ = a.K / SBK;
+    const int first = nstep_ > 2 ? 2 * SBK : (nstep_ > 1 ? SBK : 0);  // slab prefetched during step 0 (short K: an in-bounds, unused one)
+    const float* pa = a.act + (size_t)(first + kg * 8) * a.ld_act + n_act0 + ng * 2;
+    const _Float16* pw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = tid + 256 * u;
+        pw[u] = ((c >> 9) ? a.wlo : a.whi) + (size_t)(n_w0 + ((c & 511) >> 2)) * a.K + first + (c & 3) * 8;
+    }
+    const size_t act_step = (size_t)SBK * a.ld_act;
+    // One load between every two MFMAs: a global load takes ~85 cycles to ISSUE here (the CU's vector-memory path
+    // moves 64 B/clk and a k-step pulls 64 KB per CU) -- time a wave otherwise spends before its first MFMA of the
+    // step; behind an MFMA it overlaps with the matrix pipe.  sched_barrier pins the order (the scheduler otherwise
+    // clusters all loads).  MFMAs on one accumulator are never issued back to back.  The loads are unconditional: a
+    // branch around each one makes the compiler wait vmcnt(0) at every join (12 serialized round trips per step).
+#define GP_LD(g)                                                                                              \
+    do {                                                                                                      \
+        if ((g) < 8) ract[(g)] = *reinterpret_cast<const f32x2*>(pa + (size_t)(g) * a.ld_act);                \
+        else rw[(g) - 8] = *reinterpret_cast<const f16x8*>(pw[(g) - 8]);                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
+#define GP_GROUP_LD(mi, g0)  /* 6 MFMAs, a load behind each */                                             \
+    do {                                                                                                      \
+        hh[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[0], hh[mi][0], 0, 0, 0);                \
+        GP_LD(g0);                                                                                            \
+        xx[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[0], xx[mi][0], 0, 0, 0);                \
+        GP_LD(g0 + 1);                                                                                        \
+        hh[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[1], hh[mi][1], 0, 0, 0);                \
+        GP_LD(g0 + 2);                                                                                        \
+        xx[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[1], xx[mi][1], 0, 0, 0);                \
+        GP_LD(g0 + 3);                                                                                        \
+        xx[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[0], xx[mi][0], 0, 0, 0);                \
+        GP_LD(g0 + 4);                                                                                        \
+        xx[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[1], xx[mi][1], 0, 0, 0);                \
+        GP_LD(g0 + 5);                                                                                        \
+    } while (0)
+#define GP_GROUP(mi)                                                                                          \
+    do {                                                                                                      \
+        hh[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[0], hh[mi][0], 0, 0, 0);                \
+        xx[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[0], xx[mi][0], 0, 0, 0);                \
+        hh[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[1], hh[mi][1], 0, 0, 0);                \
+        xx[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[1], xx[mi][1], 0, 0, 0);                \
+        xx[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[0], xx[mi][0], 0, 0, 0);                \
+        xx[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[1], xx[mi][1], 0, 0, 0);                \
+    } while (0)
+    // Order inside a step: (1) convert + write slab s+1 (loaded during step s-1: it has had a whole MFMA phase and a
+    // barrier to arrive) into the other LDS buffer, (2) the MFMAs of slab s with the loads of slab s+2 behind the first
+    // twelve of them (so each has >= half an MFMA phase + the next step's head before it is needed), (3) barrier.
     for (int s = 0; s < nstep; ++s) {
         const int buf = s & 1;
         if (TIMING) t0 = __builtin_readcyclecounter();
-        if (s + 1 < nstep) gload((s + 1) * SBK);
-        if (TIMING) { t1 = __builtin_readcyclecounter(); tc[0] += t1 - t0; t0 = t1; }
+        if (s + 1 < nstep) stage(buf ^ 1);
+        if (TIMING) { t1 = __builtin_readcyclecounter(); tc[3] += t1 - t0; t0 = t1; }
         const _Float16* L = lds + buf * SBUF;
+        f16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {  // two k16 blocks per staged slab
-            f16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                ah[mi] = *reinterpret_cast<const f16x8*>(L + P_AHI + arow + mi * 32 * SROW + ks * 16);
-                al[mi] = *reinterpret_cast<const f16x8*>(L + P_ALO + arow + mi * 32 * SROW + ks * 16);
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                bh[ni] = *reinterpret_cast<const f16x8*>(L + P_BHI + brow + ni * 32 * SROW + ks * 16);
-                bl[ni] = *reinterpret_cast<const f16x8*>(L + P_BLO + brow + ni * 32 * SROW + ks * 16);
-            }
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    hh[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], hh[mi][ni], 0, 0, 0);
-                    xx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], xx[mi][ni], 0, 0, 0);
-                    xx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], xx[mi][ni], 0, 0, 0);
-                }
+        for (int mi = 0; mi < 2; ++mi) {
+            ah[mi] = *reinterpret_cast<const f16x8*>(L + P_AHI + arow + mi * 32 * SROW + ak0);
+            al[mi] = *reinterpret_cast<const f16x8*>(L + P_ALO + arow + mi * 32 * SROW + ak0);
         }
-        if (TIMING) {  // issue of the LDS reads + MFMAs, then their completion (an accumulator element is read)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            bh[ni] = *reinterpret_cast<const f16x8*>(L + P_BHI + brow + ni * 32 * SROW + bk0);
+            bl[ni] = *reinterpret_cast<const f16x8*>(L + P_BLO + brow + ni * 32 * SROW + bk0);
+        }
+        GP_GROUP_LD(0, 0);
+        ah[0] = *reinterpret_cast<const f16x8*>(L + P_AHI + arow + ak1);  // second k16 block of the slab
+        al[0] = *reinterpret_cast<const f16x8*>(L + P_ALO + arow + ak1);
+        GP_GROUP_LD(1, 6);
+        ah[1] = *reinterpret_cast<const f16x8*>(L + P_AHI + arow + 32 * SROW + ak1);
+        al[1] = *reinterpret_cast<const f16x8*>(L + P_ALO + arow + 32 * SROW + ak1);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            bh[ni] = *reinterpret_cast<const f16x8*>(L + P_BHI + brow + ni * 32 * SROW + bk1);
+            bl[ni] = *reinterpret_cast<const f16x8*>(L + P_BLO + brow + ni * 32 * SROW + bk1);
+        }
+        GP_GROUP(0);
+        GP_GROUP(1);
+        if (s + 3 < nstep) {  // the last steps re-load an in-bounds slab (unused): the k-step stays branch-free
+            pa += act_step;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pw[u] += SBK;
+        }
+        if (TIMING) {  // issue of the LDS reads + MFMAs + loads, then the MFMA drain (an accumulator element is read)
             t1 = __builtin_readcyclecounter(); tc[1] += t1 - t0; t0 = t1;
             asm volatile("" :: "v"(hh[1][1][15]), "v"(xx[1][1][15]));
             t1 = __builtin_readcyclecounter(); tc[2] += t1 - t0; t0 = t1;
         }
-        if (s + 1 < nstep) stage(buf ^ 1);
-        if (TIMING) { t1 = __builtin_readcyclecounter(); tc[3] += t1 - t0; t0 = t1; }
         __syncthreads();
         if (TIMING) { t1 = __builtin_readcyclecounter(); tc[4] += t1 - t0; }
     }
-    if (timed)
+#undef GP_GROUP_LD
+#undef GP_GROUP
+#undef GP_LD
+    if (timed) {
         for (int ph = 0; ph < 5; ++ph) g_split_clk[wave][ph] = tc[ph];
+        if (wave == 0) { g_split_wall[0] = __builtin_readcyclecounter() - blk_c0; g_split_wall[1] = wall_clock64() - blk_w0; }
+    }
 
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -285,7 +356,7 @@ __global__ __launch_bounds__(512, 4) void conv_split_kernel(const ConvSplitArgs 
     };
     auto stage = [&](int buf) {
         _Float16* L = lds + buf * SBUF;
-        const int off = r0 * SROW + kc * 8;
+        const int off = lds_off(r0, kc);
         *reinterpret_cast<f16x8*>(L + P_AHI + off) = rw[0];
         *reinterpret_cast<f16x8*>(L + P_ALO + off) = rw[1];
         *reinterpret_cast<f16x8*>(L + P_BHI + off) = rx[0];
@@ -301,9 +372,12 @@ __global__ __launch_bounds__(512, 4) void conv_split_kernel(const ConvSplitArgs 
     const int nstep = a.K / SBK;
     gload(0);
     stage(0);
+    if (nstep > 1) gload(SBK);  // slab 1 waits in registers for the first loop iteration
     __syncthreads();
-    const int arow = (wm * 32 + (lane & 31)) * SROW + (lane >> 5) * 8;
-    const int brow = (wn * 64 + (lane & 31)) * SROW + (lane >> 5) * 8;
+    const int ar_ = wm * 32 + (lane & 31), br_ = wn * 64 + (lane & 31), kh_ = lane >> 5;
+    const int arow = ar_ * SROW, brow = br_ * SROW;
+    const int akx[2] = {((kh_ ^ ((ar_ >> 2) & 3)) << 3), (((kh_ + 2) ^ ((ar_ >> 2) & 3)) << 3)};
+    const int bkx[2] = {((kh_ ^ ((br_ >> 2) & 3)) << 3), (((kh_ + 2) ^ ((br_ >> 2) & 3)) << 3)};
     for (int s = 0; s < nstep; ++s) {
         const int buf = s & 1;
         if (s + 1 < nstep) gload((s + 1) * SBK);
@@ -311,12 +385,12 @@ __global__ __launch_bounds__(512, 4) void conv_split_kernel(const ConvSplitArgs 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             f16x8 ah[1], al[1], bh[2], bl[2];
-            ah[0] = *reinterpret_cast<const f16x8*>(L + P_AHI + arow + ks * 16);
-            al[0] = *reinterpret_cast<const f16x8*>(L + P_ALO + arow + ks * 16);
+            ah[0] = *reinterpret_cast<const f16x8*>(L + P_AHI + arow + akx[ks]);
+            al[0] = *reinterpret_cast<const f16x8*>(L + P_ALO + arow + akx[ks]);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                bh[ni] = *reinterpret_cast<const f16x8*>(L + P_BHI + brow + ni * 32 * SROW + ks * 16);
-                bl[ni] = *reinterpret_cast<const f16x8*>(L + P_BLO + brow + ni * 32 * SROW + ks * 16);
+                bh[ni] = *reinterpret_cast<const f16x8*>(L + P_BHI + brow + ni * 32 * SROW + bkx[ks]);
+                bl[ni] = *reinterpret_cast<const f16x8*>(L + P_BLO + brow + ni * 32 * SROW + bkx[ks]);
             }
 #pragma unroll
             for (int mi = 0; mi < 1; ++mi)
@@ -450,7 +524,7 @@ int gp_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* w_hi, c
 /* probe: the fc-shaped GEMM (act_is_b, no epilogue) with per-phase cycle counters of one mid-grid block;
  * out20 (host): [wave 0..3][gload issue, LDS-read+MFMA issue, MFMA drain, convert+LDS-write, barrier] */
 int gp_gemm_split_timing(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J, int K,
-                         unsigned long long* out20, void* stream)
+                         unsigned long long* out20 /* 23 entries */, void* stream)
 {
     GP_REQUIRE(I % SBM == 0 && J % SBN == 0 && K % SBK == 0 && out20, "gp_gemm_split_timing: bad arguments");
     SplitArgs a{act, ld_act, (const _Float16*)whi, (const _Float16*)wlo, D, ldd, K, nullptr, nullptr, nullptr, 0, I / SBM, J / SBN, 8};
@@ -460,7 +534,13 @@ int gp_gemm_split_timing(const float* act, int ld_act, const void* whi, const vo
                        SLDS_BYTES, (hipStream_t)stream, a);
     GP_CHECK_LAUNCH("gp_gemm_split_timing");
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
-    return hipMemcpyFromSymbol(out20, HIP_SYMBOL(g_split_clk), 20 * sizeof(unsigned long long)) == hipSuccess ? GP_OK : GP_ELAUNCH;
+    if (hipMemcpyFromSymbol(out20, HIP_SYMBOL(g_split_clk), 20 * sizeof(unsigned long long)) != hipSuccess) return GP_ELAUNCH;
+    int occ = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gemm_split_kernel<SEPI_NONE, true, true>, SNT, SLDS_BYTES);
+    unsigned long long w[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(w, HIP_SYMBOL(g_split_wall), sizeof(w)) != hipSuccess) return GP_ELAUNCH;
+    out20[20] = w[0]; out20[21] = w[1]; out20[22] = (unsigned long long)occ;
+    return GP_OK;
 }
 
 int gp_gemm_split(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J, int K,

@@ -65,10 +65,11 @@ for (I, J, K, act_is_b, name) in [(1024, 16512, 1024, 1, "proj"), (4096, 16512, 
 I, J, K = 4096, 16512, 1024
 Wt = torch.randn(K, I, device=dev) * 0.05; X = torch.randn(K, J, device=dev)
 hi, lo = split_w(Wt); D = torch.empty(I, J, device=dev)
-out = (ctypes.c_ulonglong * 20)()
+out = (ctypes.c_ulonglong * 23)()
 for rep in range(2):
     lib.gp_gemm_split_timing(_lib.ptr(X), J, _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(D), J, I, J, K, out, _lib.stream_ptr())
 names = ["gload issue", "LDS read + MFMA issue", "MFMA drain", "convert + LDS write", "barrier"]
 for w in range(4):
     v = [out[w * 5 + p] for p in range(5)]
     print(f"wave {w}: " + ", ".join(f"{n} {x / 32:.0f}" for n, x in zip(names, v)) + f"  (cycles per k-step; total {sum(v) / 32:.0f}; MFMA pipe time 768)")
+print(f"timed block: {out[20]} shader cycles in {out[21] * 10} ns -> {out[20] / (out[21] * 10.0):.3f} GHz effective clock; occupancy API: {out[22]} workgroups/CU")

@@ -72,7 +72,8 @@ __device__ __forceinline__ float gelu_erf_s(float x) { return 0.5f * x * (1.0f +
 
 // ACT_IS_B: activations are the j operand (D = W . X: qk / proj / fc1 / fc2); else the i operand (token-major V).
 __device__ unsigned long long g_split_clk[4][5];
-__device__ unsigned long long g_split_wall[4];  // block cycles, block 100 MHz wall ticks, occupancy query, unused  // [wave][phase] cycle totals of one mid-grid block (tools/probe_split.py)
+__device__ unsigned long long g_split_wall[4];
+__device__ unsigned long long* g_split_trace = nullptr;  // optional per-block trace: [block][start tick, end tick, hw id]  // block cycles, block 100 MHz wall ticks, occupancy query, unused  // [wave][phase] cycle totals of one mid-grid block (tools/probe_split.py)
 
 template <int EPI, bool ACT_IS_B, bool TIMING = false>
 __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
@@ -157,6 +158,14 @@ __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
     const bool timed = TIMING && blockIdx.x == gridDim.x / 2 && lane == 0;
     unsigned long long tc[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     const unsigned long long blk_c0 = TIMING ? __builtin_readcyclecounter() : 0, blk_w0 = TIMING ? wall_clock64() : 0;
+    if (TIMING && g_split_trace && tid == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_split_trace[3 * (size_t)blockIdx.x + 0] = blk_w0;
+        g_split_trace[3 * (size_t)blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
     // running source pointers of this thread's 12 loads per k-step (8 activation float2 rows, 4 weight chunks)
     const int nstep_ = a.K / SBK;
     const int first = nstep_ > 2 ? 2 * SBK : (nstep_ > 1 ? SBK : 0);  // slab prefetched during step 0 (short K: an in-bounds, unused one)
@@ -252,6 +261,7 @@ __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
 #undef GP_GROUP_LD
 #undef GP_GROUP
 #undef GP_LD
+    if (TIMING && g_split_trace && tid == 0) g_split_trace[3 * (size_t)blockIdx.x + 1] = wall_clock64();
     if (timed) {
         for (int ph = 0; ph < 5; ++ph) g_split_clk[wave][ph] = tc[ph];
         if (wave == 0) { g_split_wall[0] = __builtin_readcyclecounter() - blk_c0; g_split_wall[1] = wall_clock64() - blk_w0; }
@@ -523,6 +533,11 @@ int gp_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* w_hi, c
 
 /* probe: the fc-shaped GEMM (act_is_b, no epilogue) with per-phase cycle counters of one mid-grid block;
  * out20 (host): [wave 0..3][gload issue, LDS-read+MFMA issue, MFMA drain, convert+LDS-write, barrier] */
+int gp_gemm_split_set_trace(unsigned long long* dev_buf)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_split_trace), &dev_buf, sizeof(dev_buf)) == hipSuccess ? GP_OK : GP_ELAUNCH;
+}
+
 int gp_gemm_split_timing(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J, int K,
                          unsigned long long* out20 /* 23 entries */, void* stream)
 {

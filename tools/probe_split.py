@@ -73,3 +73,25 @@ for w in range(4):
     v = [out[w * 5 + p] for p in range(5)]
     print(f"wave {w}: " + ", ".join(f"{n} {x / 32:.0f}" for n, x in zip(names, v)) + f"  (cycles per k-step; total {sum(v) / 32:.0f}; MFMA pipe time 768)")
 print(f"timed block: {out[20]} shader cycles in {out[21] * 10} ns -> {out[20] / (out[21] * 10.0):.3f} GHz effective clock; occupancy API: {out[22]} workgroups/CU")
+
+# per-block trace: how many workgroups are really resident, per CU?
+import numpy as np
+grid = 8 * ((32 * 129 + 7) // 8)
+trace = torch.zeros(grid * 3, dtype=torch.int64, device=dev)
+lib.gp_gemm_split_set_trace(ctypes.c_void_p(trace.data_ptr()))
+lib.gp_gemm_split_timing(_lib.ptr(X), J, _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(D), J, I, J, K, out, _lib.stream_ptr())
+lib.gp_gemm_split_set_trace(ctypes.c_void_p(0))
+t = trace.cpu().numpy().reshape(grid, 3)
+t = t[t[:, 1] > 0]
+start, end, hw = t[:, 0], t[:, 1], t[:, 2]
+t0 = start.min(); dur = (end - start) * 10e-3  # us (100 MHz ticks)
+print(f"{len(t)} blocks; kernel span {(end.max() - t0) * 10e-3:.1f} us; block duration us: min {dur.min():.1f} median {np.median(dur):.1f} max {dur.max():.1f}")
+# concurrency over time
+ev = np.concatenate([np.stack([start, np.ones_like(start)], 1), np.stack([end, -np.ones_like(end)], 1)])
+ev = ev[np.argsort(ev[:, 0], kind="stable")]
+conc = np.cumsum(ev[:, 1]); dt = np.diff(ev[:, 0], append=ev[-1, 0])
+print(f"time-averaged resident workgroups: {(conc * dt).sum() / dt.sum():.1f} (of 512 slots); max {conc.max()}")
+xcc = hw >> 32; hwid = hw & 0xffffffff
+cu = (hwid >> 8) & 0xf; sh = (hwid >> 12) & 1; se = (hwid >> 13) & 0x7
+key = xcc * 1000 + se * 100 + sh * 20 + cu
+print("distinct (xcc,se,sh,cu):", len(np.unique(key)), " blocks per key min/max:", np.bincount(np.unique(key, return_inverse=True)[1]).min(), np.bincount(np.unique(key, return_inverse=True)[1]).max())

@@ -17,6 +17,10 @@ int gp_gemm_launch(const float* A, int lda, const float* B, int ldb, float* D, i
 int gp_gemm_split_launch(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J,
                          int K, int act_is_b, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
                          hipStream_t st);
+bool gp_gemm_split256_usable(int I, int J, int K);
+int gp_gemm_split256_launch(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J,
+                            int K, int act_is_b, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
+                            float* scratch, hipStream_t st);
 size_t gp_gemm_streamk_bytes();
 int gp_gemm_streamk_reset_launch(float* sk_ws, hipStream_t st);
 
@@ -407,7 +411,7 @@ extern "C" {
 size_t gp_vit_workspace_bytes(int B, int dim, int mlp_dim)
 {
     if (B <= 0 || dim <= 0 || mlp_dim <= 0) return 0;
-    const size_t Mpad = (size_t)round_up(B * T_TOK, 128);
+    const size_t Mpad = (size_t)round_up(B * T_TOK, 256);
     // X, H (C each), QK (2C), Vt (C), F (mlp_dim; also hosts im2col + patch-embed output)
     size_t f = (size_t)mlp_dim * Mpad;
     const size_t pe_need = (size_t)KPE_PAD * B * GP_P + (size_t)dim * B * GP_P;
@@ -417,6 +421,7 @@ size_t gp_vit_workspace_bytes(int B, int dim, int mlp_dim)
 }
 
 // per-layer table of pre-split weight planes (f16 hi / lo, PyTorch-native [out][in]) for the split-f16 mode
+// (entries 10..19, optional: the same five weights as x64 single-accumulator planes for the 256 x 256 kernel of gp_split256.hip)
 enum { S_QK_HI = 0, S_QK_LO, S_V_HI, S_V_LO, S_PROJ_HI, S_PROJ_LO, S_FC1_HI, S_FC1_LO, S_FC2_HI, S_FC2_LO, S_PER_LAYER = 10 };
 
 int gp_vit_forward_split(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
@@ -447,14 +452,15 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
     GP_REQUIRE(images && weights && workspace && out_features, "gp_vit_forward: null pointer");
     GP_REQUIRE(workspace_bytes >= gp_vit_workspace_bytes(B, dim, mlp_dim), "gp_vit_forward: workspace too small");
     for (int i = 0; i < n_weights; ++i) GP_REQUIRE(weights[i], "gp_vit_forward: weight pointer %d is null", i);
-    GP_REQUIRE(split == nullptr || n_split == depth * S_PER_LAYER, "gp_vit_forward_split: expected %d split planes, got %d",
-               depth * S_PER_LAYER, n_split);
+    GP_REQUIRE(split == nullptr || n_split == depth * S_PER_LAYER || n_split == 2 * depth * S_PER_LAYER,
+               "gp_vit_forward_split: expected %d (or %d) split planes, got %d", depth * S_PER_LAYER, 2 * depth * S_PER_LAYER, n_split);
+    const int sp_stride = (split && n_split == 2 * depth * S_PER_LAYER) ? 2 * S_PER_LAYER : S_PER_LAYER;
     if (split) {
         GP_REQUIRE(dim % 32 == 0 && mlp_dim % 32 == 0, "gp_vit_forward_split: dim / mlp_dim must be multiples of 32");
         for (int i = 0; i < n_split; ++i) GP_REQUIRE(split[i], "gp_vit_forward_split: split plane %d is null", i);
     }
 
-    const int C = dim, Mpad = round_up(B * T_TOK, 128), BP = B * GP_P;
+    const int C = dim, Mpad = round_up(B * T_TOK, 256), BP = B * GP_P;
     float* X = workspace;
     float* Hn = X + (size_t)C * Mpad;
     float* QK = Hn + (size_t)C * Mpad;
@@ -483,15 +489,22 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
         const float* const* w = weights + W_HEADER + l * L_PER_LAYER;
         launch_layernorm(X, Hn, w[L_LN1_G], w[L_LN1_B], C, Mpad, ln_eps, st);
         GP_CHECK_LAUNCH("gp_vit_forward/layernorm");
-        const void* const* sp = split ? split + l * S_PER_LAYER : nullptr;
+        const void* const* sp = split ? split + l * sp_stride : nullptr;
+        const void* const* sq = (sp && sp_stride == 2 * S_PER_LAYER) ? sp + S_PER_LAYER : nullptr;  // x64 planes (256-tile kernel)
+        // split GEMM dispatch: 256 x 256 stream-K kernel when the shape fills the chip with 256-tiles, else 128 x 128
+        auto sgemm = [&](const float* act, int ld_act, int which, float* D, int ldd, int I, int J, int K, int act_is_b, int epi,
+                         const float* bias, const float* scale, const float* res, int ldr) -> int {
+            if (sq && gp_gemm_split256_usable(I, J, K))
+                return gp_gemm_split256_launch(act, ld_act, sq[which], sq[which + 1], D, ldd, I, J, K, act_is_b, epi, bias, scale, res,
+                                               ldr, SK, st);
+            return gp_gemm_split_launch(act, ld_act, sp[which], sp[which + 1], D, ldd, I, J, K, act_is_b, epi, bias, scale, res, ldr, st);
+        };
         // Q,K channel-major [2C][Mpad]
-        if (sp) rc = gp_gemm_split_launch(Hn, Mpad, sp[S_QK_HI], sp[S_QK_LO], QK, Mpad, 2 * C, Mpad, C, 1, 1, w[L_QK_B],
-                                          nullptr, nullptr, 0, st);
+        if (sp) rc = sgemm(Hn, Mpad, S_QK_HI, QK, Mpad, 2 * C, Mpad, C, 1, 1, w[L_QK_B], nullptr, nullptr, 0);
         else rc = gp_gemm_launch(w[L_QK_WT], 2 * C, Hn, Mpad, QK, Mpad, 2 * C, Mpad, C, 1, w[L_QK_B], nullptr, nullptr, 0, SK, st);
         if (rc) return rc;
         // V token-major [Mpad][C]: swap operand roles (A = activations, B = weights), bias along j
-        if (sp) rc = gp_gemm_split_launch(Hn, Mpad, sp[S_V_HI], sp[S_V_LO], Vt, C, Mpad, C, C, 0, 4 /*BIAS_J*/, w[L_V_B],
-                                          nullptr, nullptr, 0, st);
+        if (sp) rc = sgemm(Hn, Mpad, S_V_HI, Vt, C, Mpad, C, C, 0, 4 /*BIAS_J*/, w[L_V_B], nullptr, nullptr, 0);
         else rc = gp_gemm_launch(Hn, Mpad, w[L_V_WT], C, Vt, C, Mpad, C, C, 4 /*BIAS_J*/, w[L_V_B], nullptr, nullptr, 0, SK, st);
         if (rc) return rc;
         {
@@ -508,20 +521,17 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
         }
         GP_CHECK_LAUNCH("gp_vit_forward/attention");
         // x = x + ls1 * proj(attn)
-        if (sp) rc = gp_gemm_split_launch(Hn, Mpad, sp[S_PROJ_HI], sp[S_PROJ_LO], X, Mpad, C, Mpad, C, 1, 3, w[L_PROJ_B],
-                                          w[L_LS1], X, Mpad, st);
+        if (sp) rc = sgemm(Hn, Mpad, S_PROJ_HI, X, Mpad, C, Mpad, C, 1, 3, w[L_PROJ_B], w[L_LS1], X, Mpad);
         else rc = gp_gemm_launch(w[L_PROJ_WT], C, Hn, Mpad, X, Mpad, C, Mpad, C, 3, w[L_PROJ_B], w[L_LS1], X, Mpad, SK, st);
         if (rc) return rc;
         launch_layernorm(X, Hn, w[L_LN2_G], w[L_LN2_B], C, Mpad, ln_eps, st);
         GP_CHECK_LAUNCH("gp_vit_forward/layernorm");
-        if (sp) rc = gp_gemm_split_launch(Hn, Mpad, sp[S_FC1_HI], sp[S_FC1_LO], F, Mpad, mlp_dim, Mpad, C, 1, 2 /*GELU*/,
-                                          w[L_FC1_B], nullptr, nullptr, 0, st);
+        if (sp) rc = sgemm(Hn, Mpad, S_FC1_HI, F, Mpad, mlp_dim, Mpad, C, 1, 2 /*GELU*/, w[L_FC1_B], nullptr, nullptr, 0);
         else rc = gp_gemm_launch(w[L_FC1_WT], mlp_dim, Hn, Mpad, F, Mpad, mlp_dim, Mpad, C, 2 /*GELU*/, w[L_FC1_B], nullptr,
                                  nullptr, 0, SK, st);
         if (rc) return rc;
         // x = x + ls2 * fc2(gelu(fc1))
-        if (sp) rc = gp_gemm_split_launch(F, Mpad, sp[S_FC2_HI], sp[S_FC2_LO], X, Mpad, C, Mpad, mlp_dim, 1, 3, w[L_FC2_B],
-                                          w[L_LS2], X, Mpad, st);
+        if (sp) rc = sgemm(F, Mpad, S_FC2_HI, X, Mpad, C, Mpad, mlp_dim, 1, 3, w[L_FC2_B], w[L_LS2], X, Mpad);
         else rc = gp_gemm_launch(w[L_FC2_WT], C, F, Mpad, X, Mpad, C, Mpad, mlp_dim, 3, w[L_FC2_B], w[L_LS2], X, Mpad, SK, st);
         if (rc) return rc;
     }

@@ -37,6 +37,16 @@ def split_planes(w):
     return hi.contiguous(), lo.contiguous()
 
 
+def split_planes_x64(w):
+    """[out][in] f32 weight -> (hi, lo) f16 planes of 64 w with the low half NOT rescaled: 64 w ~= hi + lo
+    (gp_split256.hip's single-accumulator convention; gp_split256_weights on the device)."""
+    w = w.detach().float().contiguous()
+    hi = torch.empty(w.shape, dtype=torch.float16, device=w.device)
+    lo = torch.empty_like(hi)
+    _lib.call("gp_split256_weights", _lib.ptr(w), ctypes.c_size_t(w.numel()), _lib.ptr(hi), _lib.ptr(lo), _lib.stream_ptr())
+    return hi, lo
+
+
 class _Block(nn.Module):
     def __init__(self, dim, mlp_dim):
         super().__init__()
@@ -167,9 +177,12 @@ class Dinov2ViT(nn.Module):
         if self.numerics == "split":  # pre-split weight planes, PyTorch-native [out][in] (k contiguous)
             for blk in self.blocks:
                 qkv_w = blk.attn.qkv.weight.detach().to(device)
-                for w in (qkv_w[:2 * C], qkv_w[2 * C:], blk.attn.proj.weight.to(device), blk.mlp.fc1.weight.to(device),
-                          blk.mlp.fc2.weight.to(device)):
+                ws = (qkv_w[:2 * C], qkv_w[2 * C:], blk.attn.proj.weight.to(device), blk.mlp.fc1.weight.to(device),
+                      blk.mlp.fc2.weight.to(device))
+                for w in ws:                       # entries 0..9: hi + lo * 2^-11 planes (128 x 128 kernel)
                     split += list(split_planes(w))
+                for w in ws:                       # entries 10..19: x64 single-accumulator planes (256 x 256 kernel)
+                    split += list(split_planes_x64(w))
             split_table = (ctypes.c_void_p * len(split))(*[t.data_ptr() for t in split])
         self._packed = (device, tensors, table, split, split_table)
 
@@ -209,6 +222,6 @@ class Dinov2ViT(nn.Module):
         """hub-API compatibility: {"x_prenorm": (B, 257, C)} (token-major view of the workspace)."""
         B = images.shape[0]
         self.patch_features(images, normalize=False)
-        mpad = (B * T + 127) // 128 * 128
+        mpad = (B * T + 255) // 256 * 256
         xt = self._ws[: self.dim * mpad].view(self.dim, mpad)[:, : B * T]
         return {"x_prenorm": xt.t().reshape(B, T, self.dim).contiguous()}

@@ -159,7 +159,7 @@ size_t gp_vit_workspace_bytes(int B, int dim, int mlp_dim);
  *                             bfc1, Wfc2^T (mlp, dim), bfc2, ls2
  * stop_after_layers: < 0 = all layers (otherwise run only that many blocks; test hook).
  * After the call the workspace's first dim*Mpad floats hold x_prenorm^T (dim, Mpad),
- * column b*257 + t, Mpad = round_up(257*B, 128). */
+ * column b*257 + t, Mpad = round_up(257*B, 256). */
 int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                    const float* const* weights, int n_weights, float* workspace, size_t workspace_bytes,
                    float* out_features, int normalize, int stop_after_layers, void* stream);
@@ -167,10 +167,25 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
 void gp_attention_set_nq(int nq); /* tuning / test hook: 1 (default) / 2 = register-resident kernel with 1 / 2 query tiles
                                      per wave; 0 = K/V shared through LDS (results identical) */
 
+/* Second-generation split GEMM (gp_split256.hip): 256 x 256 tiles, ONE accumulator on operands pre-scaled by powers
+ * of two (activations x 8 while staging, weights x 64 in the planes made by gp_split256_weights: hi = f16(64 w),
+ * lo = f16(64 w - hi)), work balanced by stream-K with deterministic accumulator hand-offs.  Same arguments as
+ * gp_gemm_split plus a device scratch of gp_gemm_split256_workspace_bytes() bytes (one per stream); requires
+ * I, J % 256 == 0, K % 32 == 0, (I/256)*(J/256) >= 256, |activation| < 8190.  gp_gemm_split256_error: scratch error
+ * word (0 = every hand-off arrived). */
+size_t gp_gemm_split256_workspace_bytes(void);
+int gp_split256_weights(const float* W, size_t count, void* hi, void* lo, void* stream);
+int gp_gemm_split256(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J, int K,
+                     int act_is_b, int epilogue, const float* bias, const float* scale, const float* residual, int ldr,
+                     float* scratch, size_t scratch_bytes, void* stream);
+int gp_gemm_split256_error(const float* scratch, void* stream);
+
 /* gp_vit_forward with the linear layers in split-f16 numerics: `split` = HOST array of n_split = 10*depth DEVICE
  * pointers, per layer: qk_hi, qk_lo (2dim, dim), v_hi, v_lo (dim, dim), proj_hi, proj_lo (dim, dim),
  * fc1_hi, fc1_lo (mlp, dim), fc2_hi, fc2_lo (dim, mlp) -- f16 planes of the PyTorch-native [out][in] weights,
- * w ~= hi + lo * 2^-11.  split == NULL: identical to gp_vit_forward.  (Patch embedding, LayerNorm, attention and
+ * w ~= hi + lo * 2^-11.  With n_split = 20*depth each layer carries ten more pointers: the same five weights as
+ * gp_split256_weights planes; GEMMs whose shape fills the chip with 256 x 256 tiles then use gp_gemm_split256.
+ * split == NULL: identical to gp_vit_forward.  (Patch embedding, LayerNorm, attention and
  * the feature epilogue are the same f32 kernels in both modes.) */
 int gp_vit_forward_split(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                          const float* const* weights, int n_weights, const void* const* split, int n_split,

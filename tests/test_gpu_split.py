@@ -214,3 +214,76 @@ def test_ist_backbone_split_vs_chain_and_torch():
     e_chain, e_split = np.abs(chain - ref).max() / scale, np.abs(split - ref).max() / scale
     print(f"IST backbone vs f64 torch: chain {e_chain:.2e}, split {e_split:.2e} (relative to max |feature|)")
     assert e_split < 2e-5 and e_split <= 1.5 * e_chain + 1e-7
+
+
+def split256_gemm(act, W, act_is_b, epi=0, bias=None, scale=None, res=None):
+    """gp_gemm_split256 through the C-ABI.  act (K, n_act) f32 k-major, W (n_w, K) f32 [out][in]."""
+    from gigapose_amd import _lib
+    from gigapose_amd.vit import split_planes_x64
+
+    lib = _lib.lib()
+    lib.gp_gemm_split256_workspace_bytes.restype = ctypes.c_size_t
+    nb = lib.gp_gemm_split256_workspace_bytes()
+    K = act.shape[0]
+    I, J = (W.shape[0], act.shape[1]) if act_is_b else (act.shape[1], W.shape[0])
+    hi, lo = split_planes_x64(torch.from_numpy(W).to(DEV))
+    ta = torch.from_numpy(act).to(DEV)
+    D = torch.from_numpy(res).to(DEV).clone() if epi == 3 else torch.empty(I, J, device=DEV)
+    tb = None if bias is None else torch.from_numpy(bias).to(DEV)
+    ts = None if scale is None else torch.from_numpy(scale).to(DEV)
+    ws = torch.full((nb // 4,), float("nan"), device=DEV)
+    for _ in range(2):  # second launch: stale flags of the first must not satisfy it
+        if epi == 3:
+            D.copy_(torch.from_numpy(res))
+        _lib.call("gp_gemm_split256", _lib.ptr(ta), _lib.i(act.shape[1]), _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(D), _lib.i(J), _lib.i(I),
+                  _lib.i(J), _lib.i(K), _lib.i(1 if act_is_b else 0), _lib.i(epi), _lib.ptr(tb), _lib.ptr(ts), _lib.ptr(D if epi == 3 else None),
+                  _lib.i(J), _lib.ptr(ws), ctypes.c_size_t(nb), _lib.stream_ptr())
+    assert lib.gp_gemm_split256_error(_lib.ptr(ws), _lib.stream_ptr()) == 0, "a stream-K hand-off timed out"
+    return D.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", ["proj", "v", "qk"])
+def test_split256_gemm_vs_f64_and_vs_the_128_tile_kernel(shape):
+    """ViT-L shapes at B=64 (4 x 65, 65 x 4, 8 x 65 tiles of 256 x 256 on 256 slots: every slot hands a partial tile
+    over): error vs f64 at the level of the two-accumulator kernel, epilogues included."""
+    rs = np.random.RandomState(17)
+    M = 65 * 256
+    I, J, K, epi, act_is_b = {"proj": (1024, M, 96, 3, True), "v": (M, 1024, 64, 4, False), "qk": (2048, M, 160, 1, True)}[shape]
+    n_act, n_w = (J, I) if act_is_b else (I, J)
+    act = (rs.standard_normal((K, n_act)) * rs.uniform(0.05, 20, (K, 1))).astype(np.float32)
+    W = (rs.standard_normal((n_w, K)) * 0.03).astype(np.float32)
+    bias = rs.standard_normal(J if epi == 4 else I).astype(np.float32)
+    scale = rs.standard_normal(I).astype(np.float32)
+    res = rs.standard_normal((I, J)).astype(np.float32)
+    # (1) the contraction itself against f64, next to the two-accumulator 128-tile kernel
+    got = split256_gemm(act, W, act_is_b)
+    ref128 = split_gemm(act, W, act_is_b)
+    rows = np.r_[0:48, I // 2:I // 2 + 16, I - 48:I]
+    A = (W.T if act_is_b else act).astype(np.float64)[:, rows]
+    B = (act if act_is_b else W.T).astype(np.float64)
+    ref, mag = A.T @ B, np.abs(A).T @ np.abs(B)
+    e256, e128 = np.abs(got[rows] - ref) / mag, np.abs(ref128[rows] - ref) / mag
+    print(f"{shape}: err vs f64 / sum|ab|: 256-tile rms {np.sqrt((e256**2).mean()):.2e} max {e256.max():.2e}; "
+          f"128-tile rms {np.sqrt((e128**2).mean()):.2e} max {e128.max():.2e}")
+    assert e256.max() < 2.5e-7 and np.sqrt((e256 ** 2).mean()) <= 2.0 * np.sqrt((e128 ** 2).mean()) + 1e-9
+    # (2) the fused epilogue (in-place residual for epi 3) against the 128-tile kernel's, whole output
+    got = split256_gemm(act, W, act_is_b, epi, bias, scale, res)
+    ref128 = split_gemm(act, W, act_is_b, epi, bias, scale, res)
+    np.testing.assert_allclose(got, ref128, rtol=3e-5, atol=3e-5)
+
+
+def test_vit_large_split_uses_256_tiles_and_matches_chain():
+    """ViT-L/14, B=64 (BASELINE config 2): the split forward (256-tile stream-K GEMMs) vs the chain forward."""
+    from gigapose_amd.vit import Dinov2ViT
+
+    torch.manual_seed(0)
+    vit = Dinov2ViT.from_name("dinov2_vitl14")
+    for p in vit.parameters():
+        torch.nn.init.normal_(p, std=0.02)
+    vit = vit.to(DEV)
+    x = torch.randn(64, 3, 224, 224, device=DEV)
+    chain = vit.set_numerics("chain").patch_features(x)
+    split = vit.set_numerics("split").patch_features(x)
+    d = (chain - split).abs().max().item()
+    print(f"ViT-L B=64 unit-norm features chain vs split (256-tile GEMMs): max |diff| {d:.2e}")
+    assert d < 2e-6

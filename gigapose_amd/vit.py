@@ -181,8 +181,10 @@ class Dinov2ViT(nn.Module):
                       blk.mlp.fc2.weight.to(device))
                 for w in ws:                       # entries 0..9: hi + lo * 2^-11 planes (128 x 128 kernel)
                     split += list(split_planes(w))
-                for w in ws:                       # entries 10..19: x64 single-accumulator planes (256 x 256 kernel)
-                    split += list(split_planes_x64(w))
+                if os.environ.get("GIGAPOSE_SPLIT_GEMM", "256") != "128":
+                    for w in ws:                   # entries 10..19: x64 single-accumulator planes (256 x 256 kernel;
+                        split += list(split_planes_x64(w))  # needs |activation| < 8190 -- GIGAPOSE_SPLIT_GEMM=128 keeps
+                                                            # every GEMM on the two-accumulator kernel, range 65504)
             split_table = (ctypes.c_void_p * len(split))(*[t.data_ptr() for t in split])
         self._packed = (device, tensors, table, split, split_table)
 

@@ -72,8 +72,8 @@ def cpu_baseline(variant, n_templates, k, sample_crops=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step")
     ap.add_argument("--objects", type=int, default=1)
     ap.add_argument("--templates", type=int, default=162)

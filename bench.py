@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "sharded", "replicas"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the IST backbone on the main stream")
+    ap.add_argument("--no-other", action="store_true", help="skip timing the other numerics mode")
     ap.add_argument("--numerics", default="split", choices=["split", "chain"],
                     help="numerics of `value`: split = 3 x f16 MFMA on split f32 operands (f32-equivalent, DESIGN.md 2); "
                          "chain = f32-input MFMA fmaf chain (bit-exact vs the CPU oracle).  The other mode is timed too "
@@ -172,7 +173,7 @@ def main():
 
     dt, dt_serial, kern, kern_timed = run_mode(args.numerics)
     other = None
-    if world == 1 and not dist.is_initialized():
+    if world == 1 and not dist.is_initialized() and not args.no_other:
         other_mode = "chain" if args.numerics == "split" else "split"
         odt, odt_serial, okern, _ = run_mode(other_mode)
         other = {"numerics": other_mode, "value": round(args.batch * args.steps / odt, 2), "unit": "query-crops/sec",

@@ -21,6 +21,7 @@ namespace {
 __global__ __launch_bounds__(256) void l2norm_cp_kernel(const float* __restrict__ x,
                                                          float* __restrict__ out, int C)
 {
+    // grid (rows, C / 32): each block recomputes the row's 256 norms (same sequential fma chain) and writes 32 channels
     const size_t base = (size_t)blockIdx.x * C * GP_P + threadIdx.x;
     float ss = 0.f;
     for (int c = 0; c < C; ++c) {
@@ -28,7 +29,8 @@ __global__ __launch_bounds__(256) void l2norm_cp_kernel(const float* __restrict_
         ss = __builtin_fmaf(v, v, ss);
     }
     const float d = fmaxf(__builtin_sqrtf(ss), 1e-12f);
-    for (int c = 0; c < C; ++c) out[base + (size_t)c * GP_P] = x[base + (size_t)c * GP_P] / d;
+    const int c0 = blockIdx.y * 32;
+    for (int c = c0; c < c0 + 32 && c < C; ++c) out[base + (size_t)c * GP_P] = x[base + (size_t)c * GP_P] / d;
 }
 
 // ------------------------------------------------------------------ fused match tile
@@ -351,7 +353,8 @@ __global__ __launch_bounds__(256) void l2norm_split_kernel(const float* __restri
         ss = __builtin_fmaf(v, v, ss);
     }
     dn[p] = fmaxf(__builtin_sqrtf(ss), 1e-12f);
-    for (int c0 = 0; c0 < Cp; c0 += 32) {  // Cp = round_up(C, 32): the planes are zero-padded along C
+    {   // grid (rows, Cp / 32): this block's 32-channel chunk (Cp = round_up(C, 32): the planes are zero-padded along C)
+        const int c0 = blockIdx.y * 32;
         __syncthreads();
         for (int r = 0; r < 32; ++r) t[r][p] = (c0 + r < C) ? xr[(size_t)(c0 + r) * GP_P + p] : 0.f;  // coalesced along p
         __syncthreads();
@@ -447,7 +450,7 @@ int gp_l2norm_cp(const float* x, float* out, int rows, int C, void* stream)
     GP_REQUIRE(rows >= 0 && C > 0, "gp_l2norm_cp: bad arguments (rows=%d C=%d)", rows, C);
     if (rows == 0) return GP_OK;  // empty batch: nothing to do (pointers may be NULL)
     GP_REQUIRE(x && out, "gp_l2norm_cp: null pointer");
-    hipLaunchKernelGGL(l2norm_cp_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, out, C);
+    hipLaunchKernelGGL(l2norm_cp_kernel, dim3(rows, (C + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, out, C);
     GP_CHECK_LAUNCH("gp_l2norm_cp");
     return GP_OK;
 }
@@ -475,8 +478,8 @@ int gp_l2norm_split(const float* x, void* hi, void* lo, int rows, int C, void* s
     GP_REQUIRE(rows >= 0 && C > 0, "gp_l2norm_split: bad arguments (rows=%d C=%d)", rows, C);
     if (rows == 0) return GP_OK;
     GP_REQUIRE(x && hi && lo, "gp_l2norm_split: null pointer");
-    hipLaunchKernelGGL(l2norm_split_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)hi, (_Float16*)lo, C,
-                       (C + 31) / 32 * 32);
+    hipLaunchKernelGGL(l2norm_split_kernel, dim3(rows, (C + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)hi,
+                       (_Float16*)lo, C, (C + 31) / 32 * 32);
     GP_CHECK_LAUNCH("gp_l2norm_split");
     return GP_OK;
 }

@@ -382,7 +382,9 @@ extern "C" void gp_attention_set_nq(int nq) { g_attn_nq = (nq >= 0 && nq <= 2) ?
 __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__ X, float* __restrict__ out,
                                                         int C, int Mpad, int normalize)
 {
-    const int b = blockIdx.x, p = threadIdx.x;
+    // grid (B, C / 32): every block recomputes the full norm of its 256 patches (same sequential fma chain; the C/32-fold
+    // re-read is L2 traffic) and writes its own 32 channels -- B blocks alone cannot fill 256 CUs.
+    const int b = blockIdx.x, p = threadIdx.x, c0 = blockIdx.y * 32;
     const float* x = X + (size_t)b * T_TOK + 1 + p;
     float d = 1.f;
     if (normalize) {
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
         d = fmaxf(__builtin_sqrtf(ss), 1e-12f);
     }
     float* o = out + (size_t)b * C * GP_P + p;
-    for (int c = 0; c < C; ++c) o[(size_t)c * GP_P] = normalize ? x[(size_t)c * Mpad] / d : x[(size_t)c * Mpad];
+    for (int c = c0; c < c0 + 32 && c < C; ++c) o[(size_t)c * GP_P] = normalize ? x[(size_t)c * Mpad] / d : x[(size_t)c * Mpad];
 }
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -535,7 +537,7 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
         else rc = gp_gemm_launch(w[L_FC2_WT], C, F, Mpad, X, Mpad, C, Mpad, mlp_dim, 3, w[L_FC2_B], w[L_LS2], X, Mpad, SK, st);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(features_kernel, dim3(B), dim3(256), 0, st, X, out_features, C, Mpad, normalize);
+    hipLaunchKernelGGL(features_kernel, dim3(B, (C + 31) / 32), dim3(256), 0, st, X, out_features, C, Mpad, normalize);
     GP_CHECK_LAUNCH("gp_vit_forward/features");
     return GP_OK;
 }

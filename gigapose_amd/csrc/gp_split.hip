@@ -70,10 +70,12 @@ struct SplitArgs {
 
 __device__ __forceinline__ float gelu_erf_s(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// probe state (tools/probe_split.py; TIMING instantiation only)
+__device__ unsigned long long g_split_clk[4][5];         // [wave][phase] cycle totals of one mid-grid block
+__device__ unsigned long long g_split_wall[4];           // that block's shader cycles and 100 MHz wall ticks
+__device__ unsigned long long* g_split_trace = nullptr;  // optional per-block trace: [block][start tick, end tick, hw id]
+
 // ACT_IS_B: activations are the j operand (D = W . X: qk / proj / fc1 / fc2); else the i operand (token-major V).
-__device__ unsigned long long g_split_clk[4][5];
-__device__ unsigned long long g_split_wall[4];
-__device__ unsigned long long* g_split_trace = nullptr;  // optional per-block trace: [block][start tick, end tick, hw id]  // block cycles, block 100 MHz wall ticks, occupancy query, unused  // [wave][phase] cycle totals of one mid-grid block (tools/probe_split.py)
 
 template <int EPI, bool ACT_IS_B, bool TIMING = false>
 __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)

@@ -22,7 +22,7 @@ def planes256(W):  # W [n][K] f32
     return hi, lo
 torch.manual_seed(0)
 M = 16640
-for (I, J, K, act_is_b, name, epi) in [(1024, M, 1024, 1, "proj", 3), (4096, M, 1024, 1, "fc1", 2), (1024, M, 4096, 1, "fc2", 3), (2048, M, 1024, 1, "qk", 1), (M, 1024, 1024, 0, "v", 4)]:
+for (I, J, K, act_is_b, name, epi) in [(1024, M, 1024, 1, "proj", 3), (4096, M, 1024, 1, "fc1", 2), (4096, M, 1024, 1, "fc1-bias-only", 1), (1024, M, 4096, 1, "fc2", 3), (2048, M, 1024, 1, "qk", 1), (M, 1024, 1024, 0, "v", 4)]:
     nw, na = (I, J) if act_is_b else (J, I)
     W = torch.randn(nw, K, device=dev) * 0.03
     X = torch.randn(K, na, device=dev) * 1.5

@@ -199,12 +199,14 @@ def main():
         g = kern.get("gemm_split", {})
         alg = g.get("TFLOP/s", 0.0)
         achieved = round(3.0 * alg, 2)  # executed on the matrix core: 3 f16 MFMAs per f32-equivalent product block
-        roofline = {"kernel": "gemm_split_kernel (ViT linear layers; 3 x v_mfma_f32_32x32x16_f16 per k-block on f16-split f32 "
-                              "operands, f32 accumulate)", "bound": "mfma", "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS,
+        roofline = {"kernel": "gemm_planes256_kernel (ViT linear layers; 3 x v_mfma_f32_32x32x16_f16 per k-block on f16-split f32 "
+                              "operands held as hi / lo planes, f32 accumulate)", "bound": "mfma", "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / F16_MFMA_PEAK_TFLOPS, 4),
                     "algorithmic_tflops_f32_equivalent": alg,
                     "note": "achieved = 3 x algorithmic 2IJK flops / launch time (the three f16 products per f32-equivalent "
-                            "product all execute on the matrix core); the f32-input MFMA peak this mode replaces is 157.3",
+                            "product all execute on the matrix core); the f32-input MFMA peak this mode replaces is 157.3. "
+                            "The kernel runs power-limited: 1.62-1.78 GHz measured in-kernel against the 2.4 GHz the peak "
+                            "assumes (profiles/r01_probe_planes256_variants.txt), matrix pipe 84 % busy in its k loop",
                     "traffic": traffic}
     else:
         g = kern.get("gemm_kmajor", {})

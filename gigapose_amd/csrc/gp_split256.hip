@@ -46,7 +46,28 @@ struct Args256 {
 };
 
 __device__ __forceinline__ int toff(int row, int kc) { return row * TROW + ((kc ^ ((row >> 2) & 3)) << 3); }
-__device__ __forceinline__ float gelu_x(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) without libm's erff (which costs 0.15 ms of the 0.66 ms fc1 launch at ViT-L, B=64):
+// erfc(z) = t P9(t) exp(-z^2), t = 1 / (1 + 0.3275911 z), z = |x| / sqrt 2, with P9 a degree-9 least-squares fit of
+// erfcx on [0, 6.2] (|error| < 1e-8 on erfc, fitted by tools' offline script); 1 + erf = erfc(z) for x < 0 and
+// 2 - erfc(z) for x >= 0 -- no cancellation in the negative tail.  In f32 the result is within 1.2e-7 (|x| + 1) of the
+// exact value over [-8, 8] (torch's f32 GELU: 2.8e-7).
+__device__ __forceinline__ float gelu_fast(float x)
+{
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = 0.02651038324816011f;
+    p = fmaf(p, t, -0.284242067130941f);
+    p = fmaf(p, t, 0.8274675429718052f);
+    p = fmaf(p, t, -0.8329329722108324f);
+    p = fmaf(p, t, 0.7896692586773671f);
+    p = fmaf(p, t, -0.14005398441300523f);
+    p = fmaf(p, t, 0.25548806601570556f);
+    p = fmaf(p, t, 0.17245176856740801f);
+    p = fmaf(p, t, 0.18564199446374482f);
+    const float c = p * t * __expf(-z * z);  // erfc(z)
+    return 0.5f * x * (x >= 0.f ? 2.0f - c : c);
+}
+__device__ __forceinline__ float gelu_x(float x) { return gelu_fast(x); }
 
 // W [n][K] f32 (PyTorch [out][in]) -> planes hi = f16(64 w), lo = f16(64 w - hi), same shape
 __global__ __launch_bounds__(256) void split256_weights_kernel(const float* __restrict__ W, size_t count, _Float16* __restrict__ hi,
@@ -307,6 +328,296 @@ __global__ __launch_bounds__(TNT, 2) void gemm_split256_kernel(const Args256 a)
 unsigned g_epoch256 = 0;
 #undef X_T
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Third generation: BOTH operands arrive as pre-split f16 planes [n][K] (weights x 64 as above; activations x 8, written
+// token-major by their producers: gp_vit.hip's LayerNorm / attention kernels and this kernel's GELU epilogue), so the
+// staging of a k-step is eight 16-byte copies per thread -- no conversion, one address register (buffer loads:
+// descriptor + per-thread voffset + scalar offset) -- and the two wave groups of the workgroup (waves 0-3 and 4-7, one
+// wave of each per SIMD) run half a step apart: while one group issues the 48 MFMAs of slab s (matrix phase C(s)) the
+// other writes its share of slab s+1 to LDS and issues its loads of slab s+2 (memory phase M(s+1)), see the loop below.
+// The lock-step kernel above idles the matrix pipe during every staging phase (60 % busy in-loop,
+// profiles/r01_probe_split256.txt).  Tile, LDS layout, single accumulator, stream-K hand-off and epilogues are those
+// of gemm_split256_kernel; the arithmetic (operand values, k order) is identical, so results are bit-identical to it.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 g16x4 __attribute__((ext_vector_type(4)));
+
+enum { PEPI_GELU_PLANES = 6 };  // bias along i, GELU, output as activation planes O[j][i] (x 8)
+
+struct ArgsP {
+    const _Float16* ahi; const _Float16* alo;  // A planes [I][K]
+    const _Float16* bhi; const _Float16* blo;  // B planes [J][K]
+    float* D; int ldd;                         // f32 output D[i][j]
+    _Float16* ohi; _Float16* olo; int ldo;     // PEPI_GELU_PLANES: O[j][i]
+    int K;
+    const float* bias; const float* scale; const float* res; int ldr;
+    int tiles_i, tiles_j, group;
+    int* flags; float* partial; int epoch;
+    float out_scale;
+};
+
+template <int EPI, bool TIMING = false>
+__global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
+{
+    unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+    const unsigned long long k_c0 = TIMING ? __builtin_readcyclecounter() : 0, k_w0 = TIMING ? wall_clock64() : 0;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * TBUF];  // 128 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, grp = wave >> 2;
+    constexpr int P_AHI = 0, P_ALO = TPLANE, P_BHI = 2 * TPLANE, P_BLO = 3 * TPLANE;
+
+    // ---- this slot's range of (tile, k-step) units inside its XCD's tile chunk (as gemm_split256_kernel)
+    const int p = blockIdx.x, x = p & 7, n = p >> 3, slots_x = gridDim.x >> 3;
+    const int T = a.tiles_i * a.tiles_j;
+    const int t_lo = (int)((long long)T * x / 8), n_t = (int)((long long)T * (x + 1) / 8) - t_lo;
+    const int nstep = a.K / TBK;
+    const long long U = (long long)n_t * nstep;
+    const long long u0 = U * n / slots_x, u1 = U * (n + 1) / slots_x;
+    const int ta = (int)(u0 / nstep), sa = (int)(u0 % nstep);
+    const int tb = (int)(u1 / nstep), sb = (int)(u1 % nstep);
+    const int n_head = sb > 0 ? 1 : 0, n_rest = sa > 0 ? 1 : 0;
+    const int first_whole = ta + n_rest;
+    const int n_seg = n_head + (tb - first_whole) + n_rest;
+
+    // staging: thread = (row tid >> 2 [+128], 16-byte k-chunk tid & 3) of each of the four planes
+    const __amdgpu_buffer_rsrc_t r_ahi = __builtin_amdgcn_make_buffer_rsrc((void*)a.ahi, 0, a.tiles_i * TB * a.K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_alo = __builtin_amdgcn_make_buffer_rsrc((void*)a.alo, 0, a.tiles_i * TB * a.K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_bhi = __builtin_amdgcn_make_buffer_rsrc((void*)a.bhi, 0, a.tiles_j * TB * a.K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_blo = __builtin_amdgcn_make_buffer_rsrc((void*)a.blo, 0, a.tiles_j * TB * a.K * 2, 0x00020000);
+    const unsigned voff = (unsigned)(tid >> 2) * (unsigned)a.K * 2u + (unsigned)(tid & 3) * 16u;
+    const unsigned half_rows = 128u * (unsigned)a.K * 2u;  // byte distance of row + 128
+    const int wofs = toff(tid >> 2, tid & 3);
+    u32x4 rg[8];
+    // fragment addressing
+    const int ar_ = 64 * wr + (lane & 31), br_ = 128 * wc + (lane & 31), kh_ = lane >> 5;
+    const int arow = ar_ * TROW, brow = br_ * TROW;
+    const int ak0 = ((kh_ ^ ((ar_ >> 2) & 3)) << 3), ak1 = (((kh_ + 2) ^ ((ar_ >> 2) & 3)) << 3);
+    const int bk0 = ((kh_ ^ ((br_ >> 2) & 3)) << 3), bk1 = (((kh_ + 2) ^ ((br_ >> 2) & 3)) << 3);
+
+    for (int seg = 0; seg < n_seg; ++seg) {
+        const bool is_head = seg < n_head;
+        const bool is_rest = n_rest && seg == n_seg - 1;
+        const int t = is_head ? tb : (is_rest ? ta : first_whole + seg - n_head);
+        const int s0 = is_rest ? sa : 0, s1 = is_head ? sb : nstep;
+        const int q = t_lo + t;
+        const int per_band = a.group * a.tiles_j;
+        const int band = q / per_band, rr = q - band * per_band;
+        const int first_i = band * a.group;
+        const int gsz = min(a.group, a.tiles_i - first_i);
+        const int i0 = (first_i + rr % gsz) * TB, j0 = (rr / gsz) * TB;
+
+        f32x16 acc[2][4];
+        if (is_rest) {
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(a.flags + (p - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > kSpin) {
+                        __hip_atomic_store(a.flags + kSlots, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            const f32x4* w = reinterpret_cast<const f32x4*>(a.partial + (size_t)(p - 8) * kFragFloats) + tid * 32;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 v = w[(mi * 4 + ni) * 4 + r4];
+                        acc[mi][ni][r4 * 4 + 0] = v[0]; acc[mi][ni][r4 * 4 + 1] = v[1];
+                        acc[mi][ni][r4 * 4 + 2] = v[2]; acc[mi][ni][r4 * 4 + 3] = v[3];
+                    }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
+
+        // ---- k loop over steps [s0, s1)
+        const int ns = s1 - s0;
+        const unsigned sA0 = ((unsigned)i0 * (unsigned)a.K + (unsigned)s0 * TBK) * 2u;  // scalar byte offsets of slab s0
+        const unsigned sB0 = ((unsigned)j0 * (unsigned)a.K + (unsigned)s0 * TBK) * 2u;
+        auto gload = [&](int slab) {
+            const unsigned sA = sA0 + (unsigned)slab * (TBK * 2u), sB = sB0 + (unsigned)slab * (TBK * 2u);
+            rg[0] = __builtin_amdgcn_raw_buffer_load_b128(r_ahi, voff, sA, 0);
+            rg[1] = __builtin_amdgcn_raw_buffer_load_b128(r_ahi, voff, sA + half_rows, 0);
+            rg[2] = __builtin_amdgcn_raw_buffer_load_b128(r_alo, voff, sA, 0);
+            rg[3] = __builtin_amdgcn_raw_buffer_load_b128(r_alo, voff, sA + half_rows, 0);
+            rg[4] = __builtin_amdgcn_raw_buffer_load_b128(r_bhi, voff, sB, 0);
+            rg[5] = __builtin_amdgcn_raw_buffer_load_b128(r_bhi, voff, sB + half_rows, 0);
+            rg[6] = __builtin_amdgcn_raw_buffer_load_b128(r_blo, voff, sB, 0);
+            rg[7] = __builtin_amdgcn_raw_buffer_load_b128(r_blo, voff, sB + half_rows, 0);
+        };
+        auto stage = [&](int buf) {
+            _Float16* L = lds + buf * TBUF + wofs;
+            *reinterpret_cast<u32x4*>(L + P_AHI) = rg[0];
+            *reinterpret_cast<u32x4*>(L + P_AHI + 128 * TROW) = rg[1];
+            *reinterpret_cast<u32x4*>(L + P_ALO) = rg[2];
+            *reinterpret_cast<u32x4*>(L + P_ALO + 128 * TROW) = rg[3];
+            *reinterpret_cast<u32x4*>(L + P_BHI) = rg[4];
+            *reinterpret_cast<u32x4*>(L + P_BHI + 128 * TROW) = rg[5];
+            *reinterpret_cast<u32x4*>(L + P_BLO) = rg[6];
+            *reinterpret_cast<u32x4*>(L + P_BLO + 128 * TROW) = rg[7];
+        };
+        gload(0);
+        stage(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ns > 1) gload(1);
+        __syncthreads();
+
+#define X_MFMA(A_, B_, mi, ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[mi], B_[ni], acc[mi][ni], 0, 0, 0)
+        auto c_phase = [&](int s) __attribute__((always_inline)) {
+            if (TIMING) { t0 = __builtin_readcyclecounter(); tc[5] += 1; }
+            const _Float16* L = lds + (s & 1) * TBUF;
+            __builtin_amdgcn_s_setprio(1);  // before the fragment reads: they must not queue behind the other group's staging
+            g16x8 ah[2], al[2], bh[4], bl[4], ch[2], cl[2], dh[4], dl[4];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) ah[mi] = *reinterpret_cast<const g16x8*>(L + P_AHI + arow + mi * 32 * TROW + ak0);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bh[ni] = *reinterpret_cast<const g16x8*>(L + P_BHI + brow + ni * 32 * TROW + bk0);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bl[ni] = *reinterpret_cast<const g16x8*>(L + P_BLO + brow + ni * 32 * TROW + bk0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) al[mi] = *reinterpret_cast<const g16x8*>(L + P_ALO + arow + mi * 32 * TROW + ak0);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) { X_MFMA(ah, bh, 0, ni); X_MFMA(ah, bh, 1, ni); }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) { X_MFMA(ah, bl, 0, ni); X_MFMA(ah, bl, 1, ni); }
+            // second k16 block's fragments replace the dead ones (ah, bl) under the MFMAs in flight
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) ch[mi] = *reinterpret_cast<const g16x8*>(L + P_AHI + arow + mi * 32 * TROW + ak1);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) dh[ni] = *reinterpret_cast<const g16x8*>(L + P_BHI + brow + ni * 32 * TROW + bk1);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) { X_MFMA(al, bh, 0, ni); X_MFMA(al, bh, 1, ni); }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) dl[ni] = *reinterpret_cast<const g16x8*>(L + P_BLO + brow + ni * 32 * TROW + bk1);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) cl[mi] = *reinterpret_cast<const g16x8*>(L + P_ALO + arow + mi * 32 * TROW + ak1);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) { X_MFMA(ch, dh, 0, ni); X_MFMA(ch, dh, 1, ni); }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) { X_MFMA(ch, dl, 0, ni); X_MFMA(ch, dl, 1, ni); }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) { X_MFMA(cl, dh, 0, ni); X_MFMA(cl, dh, 1, ni); }
+            __builtin_amdgcn_s_setprio(0);
+            if (TIMING) { t1 = __builtin_readcyclecounter(); tc[0] += t1 - t0; t0 = t1; }
+        };
+        auto m_phase = [&](int slab) __attribute__((always_inline)) {  // stages `slab`, loads slab + 1
+            if (TIMING) { t0 = __builtin_readcyclecounter(); tc[5] += 1; }
+            if (slab < ns) stage(slab & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            gload(min(slab + 1, ns - 1));  // unconditional (the last ones re-load an L2-hot slab, unused)
+            if (TIMING) { t1 = __builtin_readcyclecounter(); tc[2] += t1 - t0; t0 = t1; }
+        };
+        // One loop body for both groups; waves 4-7 run one memory phase ahead.  ONE barrier per k-step (ns - 1 for every
+        // wave); what it orders: C(s+1) after every wave's M(s+1), M(s+2) after every wave's C(s):
+        //     waves 0-3:  C0 M1 | C1 M2 | ...          waves 4-7:  M1 C0 | M2 C1 | ...
+        // After a barrier waves 0-3 start their MFMAs at once and waves 4-7 stage first, so the offset is kept by the code
+        // order; the matrix phases overlap in part (the pipe is shared, its work per step is the same).  Measured on the
+        // fc2 shape (profiles/r01_probe_planes256_variants.txt): strict alternation with two barriers per step 4170
+        // cycles per step, this 3670 (matrix pipe 84 % busy in-loop), without the matrix-phase priority 3850.
+        if (grp) m_phase(1);
+        for (int s = 0; s < ns; ++s) {
+            c_phase(s);
+            if (grp && s + 1 < ns) __syncthreads();
+            if (TIMING) { t1 = __builtin_readcyclecounter(); tc[1] += t1 - t0; }
+            m_phase(s + 1 + grp);
+            if (!grp && s + 1 < ns) __syncthreads();
+            if (TIMING) { t1 = __builtin_readcyclecounter(); tc[3] += t1 - t0; }
+        }
+#undef X_MFMA
+
+        if (is_head) {  // publish the fragment for slot n+1 (agent-scope release by one lane)
+            f32x4* w = reinterpret_cast<f32x4*>(a.partial + (size_t)p * kFragFloats) + tid * 32;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        f32x4 v;
+                        v[0] = acc[mi][ni][r4 * 4 + 0]; v[1] = acc[mi][ni][r4 * 4 + 1];
+                        v[2] = acc[mi][ni][r4 * 4 + 2]; v[3] = acc[mi][ni][r4 * 4 + 3];
+                        w[(mi * 4 + ni) * 4 + r4] = v;
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(a.flags + p, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            int tid_ = threadIdx.x;
+            asm volatile("" : "+v"(tid_));  // keep the epilogue's address arithmetic inside the segment loop
+            const int ln = tid_ & 63, l31 = ln & 31;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int j = j0 + 128 * wc + 32 * ni + l31;
+                    if (EPI == PEPI_GELU_PLANES) {
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const int i = i0 + 64 * wr + 32 * mi + frag_row(4 * r4, ln);
+                            g16x4 oh, ol;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = gelu_x(acc[mi][ni][4 * r4 + e] * a.out_scale + a.bias[i + e]) * kActScale;
+                                const _Float16 hh = (_Float16)v;
+                                oh[e] = hh;
+                                ol[e] = (_Float16)(v - (float)hh);
+                            }
+                            const size_t o = (size_t)(unsigned)j * (unsigned)a.ldo + (unsigned)i;
+                            *reinterpret_cast<g16x4*>(a.ohi + o) = oh;
+                            *reinterpret_cast<g16x4*>(a.olo + o) = ol;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int i = i0 + 64 * wr + 32 * mi + frag_row(r, ln);
+                            float v = acc[mi][ni][r] * a.out_scale;
+                            if (EPI == XEPI_BIAS_I || EPI == XEPI_BIAS_I_GELU || EPI == XEPI_BIAS_I_SCALE_RES || EPI == XEPI_BIAS_I_RELU)
+                                v = v + a.bias[i];
+                            if (EPI == XEPI_BIAS_J) v = v + a.bias[j];
+                            if (EPI == XEPI_BIAS_I_GELU) v = gelu_x(v);
+                            if (EPI == XEPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
+                            if (EPI == XEPI_BIAS_I_SCALE_RES) v = a.res[(unsigned)i * (unsigned)a.ldr + (unsigned)j] + a.scale[i] * v;
+                            a.D[(unsigned)i * (unsigned)a.ldd + (unsigned)j] = v;
+                        }
+                    }
+                }
+            __syncthreads();  // LDS buffer 0 is re-staged by the next segment's prologue
+        }
+    }
+    if (TIMING && blockIdx.x == 100 && tid == 0) {
+        for (int i = 0; i < 6; ++i) g_t256[i] = tc[i];
+        g_t256[6] = __builtin_readcyclecounter() - k_c0;  // whole kernel, shader cycles
+        g_t256[7] = wall_clock64() - k_w0;                // whole kernel, 100 MHz ticks
+    }
+}
+
+// x [count] f32 -> planes hi = f16(scale x), lo = f16(scale x - hi)  (probe / test producer of activation planes)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ X, size_t count, float scale,
+                                                            _Float16* __restrict__ hi, _Float16* __restrict__ lo)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float v = X[i] * scale;
+    const _Float16 h = (_Float16)v;
+    hi[i] = h;
+    lo[i] = (_Float16)(v - (float)h);
+}
+
 template <int EPI>
 void launch256(Args256& a, bool act_is_b, int grid, hipStream_t st)
 {
@@ -351,6 +662,40 @@ int gp_gemm_split256_launch(const float* act, int ld_act, const void* whi, const
     return GP_OK;
 }
 
+// internal entry (gp_vit.hip): D[i][j] = epi( out_scale * sum_k A[i][k] B[j][k] ), A / B = pre-split planes (see above)
+int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
+                             void* olo, int ldo, int I, int J, int K, int epilogue, const float* bias, const float* scale,
+                             const float* res, int ldr, float out_scale, float* scratch, hipStream_t st)
+{
+    GP_REQUIRE(gp_gemm_split256_usable(I, J, K), "gp_gemm_planes256: I=%d, J=%d must be multiples of 256 with >= 256 tiles, K=%d of 32", I, J, K);
+    GP_REQUIRE(ahi && alo && bhi && blo && scratch && ((uintptr_t)ahi % 16 == 0) && ((uintptr_t)alo % 16 == 0) &&
+                   ((uintptr_t)bhi % 16 == 0) && ((uintptr_t)blo % 16 == 0) && ((uintptr_t)scratch % 16 == 0),
+               "gp_gemm_planes256: null / misaligned operand");
+    GP_REQUIRE((long long)I * K * 2 < (1ll << 31) && (long long)J * K * 2 < (1ll << 31), "gp_gemm_planes256: operand planes too large");
+    if (epilogue == PEPI_GELU_PLANES)
+        GP_REQUIRE(ohi && olo && ldo % 4 == 0 && ((uintptr_t)ohi % 8 == 0) && ((uintptr_t)olo % 8 == 0) && bias, "gp_gemm_planes256: bad plane output");
+    else
+        GP_REQUIRE(D && (long long)I * ldd < (1ll << 31) && (long long)I * (ldr > 0 ? ldr : 1) < (1ll << 31), "gp_gemm_planes256: bad f32 output");
+    ArgsP a{(const _Float16*)ahi, (const _Float16*)alo, (const _Float16*)bhi, (const _Float16*)blo, D, ldd, (_Float16*)ohi, (_Float16*)olo, ldo,
+            K, bias, scale, res, ldr, I / TB, J / TB, 4, reinterpret_cast<int*>(scratch),
+            reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, out_scale};
+    g_epoch256 = (g_epoch256 + 1) & 0x3fffffff;
+    a.epoch = (int)(0x40000000u | g_epoch256);
+    GpProfScope prof(GP_PROF_GEMM_SPLIT, 2.0 * I * J * K, st);
+    switch (epilogue) {
+        case XEPI_NONE: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_NONE>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        case XEPI_BIAS_I: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        case XEPI_BIAS_I_GELU: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_GELU>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        case XEPI_BIAS_I_SCALE_RES: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        case XEPI_BIAS_J: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_J>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        case XEPI_BIAS_I_RELU: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_RELU>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        case PEPI_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_GELU_PLANES>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        default: GP_REQUIRE(false, "gp_gemm_planes256: unknown epilogue %d", epilogue);
+    }
+    GP_CHECK_LAUNCH("gp_gemm_planes256");
+    return GP_OK;
+}
+
 extern "C" {
 
 size_t gp_gemm_split256_workspace_bytes(void) { return gp_gemm_split256_scratch_bytes(); }
@@ -389,6 +734,44 @@ int gp_gemm_split256_timing(const float* act, int ld_act, const void* whi, const
     GP_CHECK_LAUNCH("gp_gemm_split256_timing");
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
     return hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_t256), 6 * sizeof(unsigned long long)) == hipSuccess ? GP_OK : GP_ELAUNCH;
+}
+
+
+int gp_split_planes(const float* X, size_t count, float scale, void* hi, void* lo, void* stream)
+{
+    GP_REQUIRE(X && hi && lo && count > 0, "gp_split_planes: bad arguments");
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, count, scale,
+                       (_Float16*)hi, (_Float16*)lo);
+    GP_CHECK_LAUNCH("gp_split_planes");
+    return GP_OK;
+}
+
+int gp_gemm_planes256(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
+                      void* out_lo, int ldo, int I, int J, int K, int epilogue, const float* bias, const float* scale,
+                      const float* residual, int ldr, float out_scale, float* scratch, size_t scratch_bytes, void* stream)
+{
+    GP_REQUIRE(scratch && scratch_bytes >= gp_gemm_split256_scratch_bytes(), "gp_gemm_planes256: scratch too small");
+    if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
+    return gp_gemm_planes256_launch(a_hi, a_lo, b_hi, b_lo, D, ldd, out_hi, out_lo, ldo, I, J, K, epilogue, bias, scale, residual, ldr,
+                                    out_scale, scratch, (hipStream_t)stream);
+}
+
+/* probe: no-epilogue launch with per-phase cycle counters of wave 0 of block 100; out6 (host, 8 entries): matrix phase,
+ * barrier after it, memory phase, barrier after it, 0, phases, whole-kernel shader cycles, whole-kernel 100 MHz ticks */
+int gp_gemm_planes256_timing(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, int I, int J,
+                             int K, float* scratch, unsigned long long* out6, void* stream)
+{
+    GP_REQUIRE(gp_gemm_split256_usable(I, J, K) && out6, "gp_gemm_planes256_timing: bad arguments");
+    if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
+    ArgsP a{(const _Float16*)a_hi, (const _Float16*)a_lo, (const _Float16*)b_hi, (const _Float16*)b_lo, D, ldd, nullptr, nullptr, 0,
+            K, nullptr, nullptr, nullptr, 0, I / TB, J / TB, 4, reinterpret_cast<int*>(scratch),
+            reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, kOutScale};
+    if (++g_epoch256 == 0) ++g_epoch256;
+    a.epoch = (int)g_epoch256;
+    hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_NONE, true>), dim3(kSlots), dim3(TNT), 0, (hipStream_t)stream, a);
+    GP_CHECK_LAUNCH("gp_gemm_planes256_timing");
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
+    return hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_t256), 8 * sizeof(unsigned long long)) == hipSuccess ? GP_OK : GP_ELAUNCH;
 }
 
 int gp_gemm_split256_error(const float* scratch, void* stream)

@@ -23,6 +23,10 @@ int gp_gemm_split256_launch(const float* act, int ld_act, const void* whi, const
                             float* scratch, hipStream_t st);
 size_t gp_gemm_streamk_bytes();
 int gp_gemm_streamk_reset_launch(float* sk_ws, hipStream_t st);
+bool gp_gemm_split256_usable(int I, int J, int K);
+int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
+                             void* olo, int ldo, int I, int J, int K, int epilogue, const float* bias, const float* scale,
+                             const float* res, int ldr, float out_scale, float* scratch, hipStream_t st);
 
 namespace {
 
@@ -131,6 +135,88 @@ int launch_layernorm(const float* X, float* Y, const float* g, const float* b, i
     return 0;
 }
 
+
+// ---- activation planes (split numerics, gp_split256.hip's plane x plane GEMM): the consumer wants its activations
+// token-major as two f16 planes hi = f16(8 y), lo = f16(8 y - hi).  Same block shape and the same arithmetic as
+// layernorm_wide_kernel for the statistics (so y is bit-identical); the last pass transposes through LDS so that the
+// plane stores are 256 contiguous bytes per token row.
+typedef _Float16 v16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 v16x4 __attribute__((ext_vector_type(4)));
+constexpr float kPlaneScale = 8.0f;  // == kActScale of gp_split256.hip
+
+__global__ __launch_bounds__(1024) void layernorm_planes_kernel(const float* __restrict__ X, _Float16* __restrict__ Yhi,
+                                                                 _Float16* __restrict__ Ylo, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int C, int Mpad, float eps)
+{
+    __shared__ float red[16][64];
+    const int tok = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int per = C >> 4, c0 = sl * per;
+    const float* x = X + (size_t)c0 * Mpad + (size_t)blockIdx.x * 64 + tok;
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < per; ++i) s += x[(size_t)i * Mpad];
+    red[sl][tok] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tot += red[j][tok];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < per; ++i) {
+        const float d = x[(size_t)i * Mpad] - mean;
+        q = __builtin_fmaf(d, d, q);
+    }
+    red[sl][tok] = q;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tot += red[j][tok];
+    const float rstd = 1.0f / __builtin_sqrtf(tot / (float)C + eps);
+    // pass 3, re-sliced: chunks of 128 channels; wave sl computes channels 8 sl .. 8 sl + 7 of the chunk for its 64 tokens
+    // (coalesced reads along tokens), packs (hi, lo) into one word and writes tile[channel][token]; after the barrier the
+    // block reads it transposed: wave sl = (token octet sl & 7, channel half sl >> 3), lane = (token lane & 7, channel
+    // group lane >> 3) -> 8 lanes x 16 bytes cover 128 contiguous bytes of a token row per plane (bank = 8 g + t + e:
+    // two lanes per bank, the minimum for 64 lanes).  Two tiles, one barrier per chunk.
+    __shared__ unsigned int tile[2][128 * 65];
+    const float* xb = X + (size_t)blockIdx.x * 64 + tok;
+    const int t2 = 8 * (sl & 7) + (tok & 7), g2 = 8 * (sl >> 3) + (tok >> 3);
+    const size_t row = ((size_t)blockIdx.x * 64 + t2) * C + 8 * g2;
+    const int nchunk = C >> 7;
+    for (int k = 0; k < nchunk; ++k) {
+        unsigned int* T = tile[k & 1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int cl = 8 * sl + e, c = 128 * k + cl;
+            const float y = (xb[(size_t)c * Mpad] - mean) * rstd * gamma[c] + beta[c];
+            const float v = y * kPlaneScale;
+            const _Float16 hh = (_Float16)v;
+            const _Float16 ll = (_Float16)(v - (float)hh);
+            T[cl * 65 + tok] = (unsigned int)__builtin_bit_cast(unsigned short, hh) |
+                               ((unsigned int)__builtin_bit_cast(unsigned short, ll) << 16);
+        }
+        __syncthreads();
+        v16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned int w = T[(8 * g2 + e) * 65 + t2];
+            h[e] = __builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu));
+            l[e] = __builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+        }
+        *reinterpret_cast<v16x8*>(Yhi + row + 128 * k) = h;
+        *reinterpret_cast<v16x8*>(Ylo + row + 128 * k) = l;
+    }
+}
+
+int launch_layernorm_planes(const float* X, _Float16* hi, _Float16* lo, const float* g, const float* b, int C, int Mpad, float eps,
+                            hipStream_t st)
+{
+    GpProfScope prof(GP_PROF_LN, 8.0 * C * Mpad, st);
+    hipLaunchKernelGGL(layernorm_planes_kernel, dim3(Mpad / 64), dim3(1024), 0, st, X, hi, lo, g, b, C, Mpad, eps);
+    return 0;
+}
+
 // ---- attention, one wave per (image, head, 32-query block); everything in registers.
 // S^T tile trick: compute D[i=key][j=query] = sum_d K[d][key] * Q[d][query] so that a lane owns ONE
 // query column and 16 key rows per tile: softmax over keys is in-register (+1 cross-half shuffle),
@@ -141,10 +227,13 @@ int launch_layernorm(const float* X, float* Y, const float* g, const float* b, i
 constexpr int NKT = 9;  // ceil(257 / 32) key tiles
 
 // NQ query tiles of 32 per wave share every K / V operand load (one 4-byte global load feeds NQ MFMAs).
-template <int NQ>
+// PLANES: the output goes to token-major activation planes (Ohi / Olo pre-offset to this image's first token and this
+// head's first channel; row stride C) instead of channel-major f32 -- the same values o * inv, split as 8 x.
+template <int NQ, bool PLANES = false>
 __device__ __forceinline__ void attention_body(const float* __restrict__ Qp, const float* __restrict__ Kp,
                                                const float* __restrict__ Vp, float* __restrict__ Op, int q0, int C,
-                                               int Mpad, float scale)
+                                               int Mpad, float scale, _Float16* __restrict__ Ohi = nullptr,
+                                               _Float16* __restrict__ Olo = nullptr, unsigned int* Tile = nullptr)
 {
     const int lane = threadIdx.x, half = lane >> 5, l31 = lane & 31;
     int tq[NQ], tq_c[NQ];
@@ -239,7 +328,37 @@ __device__ __forceinline__ void attention_body(const float* __restrict__ Qp, con
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
         const float inv = 1.0f / (l_part[u] + __shfl_xor(l_part[u], 32));
-        if (tq[u] < T_TOK) {
+        if (PLANES) {
+            // transpose through the wave's LDS tile [32 queries][64 channels (+1)] of packed (hi, lo) words, then 16-byte
+            // stores: 8 lanes cover the 128 contiguous bytes of a token row's head slice
+#pragma unroll
+            for (int half_d = 0; half_d < 2; ++half_d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = ((half_d ? o1[u][r] : o0[u][r]) * inv) * kPlaneScale;
+                    const _Float16 hh = (_Float16)v;
+                    const _Float16 ll = (_Float16)(v - (float)hh);
+                    Tile[l31 * 65 + 32 * half_d + frag_row(r, lane)] =
+                        (unsigned int)__builtin_bit_cast(unsigned short, hh) | ((unsigned int)__builtin_bit_cast(unsigned short, ll) << 16);
+                }
+            __syncthreads();
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int tok = 8 * pass + (lane >> 3), g = lane & 7;
+                v16x8 h, l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned int w = Tile[tok * 65 + 8 * g + e];
+                    h[e] = __builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu));
+                    l[e] = __builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+                }
+                if (q0 + 32 * u + tok < T_TOK) {
+                    const size_t o = (size_t)(q0 + 32 * u + tok) * C + 8 * g;
+                    *reinterpret_cast<v16x8*>(Ohi + o) = h;
+                    *reinterpret_cast<v16x8*>(Olo + o) = l;
+                }
+            }
+        } else if (tq[u] < T_TOK) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = frag_row(r, lane);
@@ -270,6 +389,23 @@ __global__ __launch_bounds__(64, NQ == 1 ? 4 : 2) void attention_kernel(const fl
     if (NQ == 1) attention_body<1>(Qp, Kp, Vp, Op, qb * 32, C, Mpad, scale);
     else if (qb < 4) attention_body<2>(Qp, Kp, Vp, Op, qb * 64, C, Mpad, scale);
     else attention_body<1>(Qp, Kp, Vp, Op, 256, C, Mpad, scale);
+}
+
+// NQ = 1 with the output written as activation planes [Mpad][C] (split numerics, plane x plane GEMMs).  Direct 8-byte
+// stores from the accumulator layout instead of the LDS transpose measured the same end to end (966-969 crops/s).
+__global__ __launch_bounds__(64, 4) void attention_planes_kernel(const float* __restrict__ QK, const float* __restrict__ Vt,
+                                                                  _Float16* __restrict__ Ohi, _Float16* __restrict__ Olo, int B, int H,
+                                                                  int C, int Mpad, float scale)
+{
+    const int q = xcd_chunked_tile(blockIdx.x, B * H * NKT);
+    if (q < 0) return;
+    const int qb = q % NKT, bh = q / NKT, h = bh % H, b = bh / H;
+    const float* Qp = QK + (size_t)(h * 64) * Mpad + (size_t)b * T_TOK;
+    const float* Kp = QK + (size_t)(C + h * 64) * Mpad + (size_t)b * T_TOK;
+    const float* Vp = Vt + (size_t)b * T_TOK * C + h * 64;
+    const size_t o = (size_t)b * T_TOK * C + h * 64;
+    __shared__ unsigned int tile[32 * 65];
+    attention_body<1, true>(Qp, Kp, Vp, nullptr, qb * 32, C, Mpad, scale, Ohi + o, Olo + o, tile);
 }
 
 // K and V of one (image, head) staged in LDS ONCE and shared by the nine query-tile waves of the workgroup (the
@@ -375,6 +511,10 @@ __global__ __launch_bounds__(576, 1) void attention_lds_kernel(const float* __re
 // Measured on ViT-L, B=64 (tools/probe_attn.py, whole forward in split numerics): register-resident with one query tile
 // per wave 58.2 ms; two tiles per wave (operand loads shared, 226 VGPR -> 2 waves/SIMD) 60.4 ms; K/V through LDS (one
 // 147 KB workgroup per CU, staging not overlapped) 60.8 ms.  Occupancy wins: the default stays 1.
+// split numerics: activation planes + plane x plane GEMMs when every GEMM of a layer fits them (0: f32 activations and
+// the lock-step kernels, kept for A/B runs and the bit-identity test)
+static int g_vit_planes = 1;
+extern "C" void gp_vit_set_planes(int on) { g_vit_planes = on ? 1 : 0; }
 static int g_attn_nq = 1;  // 0: LDS-shared K/V kernel; 1 / 2: register-resident kernel with 1 / 2 query tiles per wave
 extern "C" void gp_attention_set_nq(int nq) { g_attn_nq = (nq >= 0 && nq <= 2) ? nq : 1; }
 
@@ -487,7 +627,56 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
     GP_CHECK_LAUNCH("gp_vit_forward/embed");
 
     const int nl = (stop_after_layers >= 0 && stop_after_layers < depth) ? stop_after_layers : depth;
-    for (int l = 0; l < nl; ++l) {
+    // Split numerics, third generation: when all five GEMMs of a layer fill the chip with 256 x 256 tiles, the
+    // activations between the kernels travel as token-major f16 planes (written by LayerNorm, attention and fc1's GELU
+    // epilogue; the f32 residual stream X, Q/K and V stay as they are) and every GEMM is gemm_planes256_kernel.  The
+    // planes alias the f32 buffers they replace (2 planes x 2 bytes = 4 bytes per element).  Bit-identical to the
+    // f32-activation kernels (same values, same split, same k order).
+    const bool planes = split && sp_stride == 2 * S_PER_LAYER && g_vit_planes && gp_gemm_split256_usable(2 * C, Mpad, C) &&
+                        gp_gemm_split256_usable(Mpad, C, C) && gp_gemm_split256_usable(C, Mpad, C) &&
+                        gp_gemm_split256_usable(mlp_dim, Mpad, C) && gp_gemm_split256_usable(C, Mpad, mlp_dim);
+    if (planes) {
+        _Float16* Hhi = reinterpret_cast<_Float16*>(Hn);
+        _Float16* Hlo = Hhi + (size_t)C * Mpad;
+        _Float16* Fhi = reinterpret_cast<_Float16*>(F);
+        _Float16* Flo = Fhi + (size_t)mlp_dim * Mpad;
+        const float os = 1.0f / (8.0f * 64.0f);  // activations x 8, weights x 64
+        for (int l = 0; l < nl; ++l) {
+            const float* const* w = weights + W_HEADER + l * L_PER_LAYER;
+            const void* const* sq = split + l * sp_stride + S_PER_LAYER;  // x64 weight planes [out][in]
+            launch_layernorm_planes(X, Hhi, Hlo, w[L_LN1_G], w[L_LN1_B], C, Mpad, ln_eps, st);
+            GP_CHECK_LAUNCH("gp_vit_forward/layernorm_planes");
+            // Q,K channel-major [2C][Mpad] = W_qk (A) x tokens (B)
+            if ((rc = gp_gemm_planes256_launch(sq[S_QK_HI], sq[S_QK_LO], Hhi, Hlo, QK, Mpad, nullptr, nullptr, 0, 2 * C, Mpad, C,
+                                               1 /*BIAS_I*/, w[L_QK_B], nullptr, nullptr, 0, os, SK, st)))
+                return rc;
+            // V token-major [Mpad][C] = tokens (A) x W_v (B), bias along j
+            if ((rc = gp_gemm_planes256_launch(Hhi, Hlo, sq[S_V_HI], sq[S_V_LO], Vt, C, nullptr, nullptr, 0, Mpad, C, C,
+                                               4 /*BIAS_J*/, w[L_V_B], nullptr, nullptr, 0, os, SK, st)))
+                return rc;
+            {
+                GpProfScope prof(GP_PROF_ATTN, 4.0 * B * heads * 257.0 * 257.0 * 64.0, st);
+                hipLaunchKernelGGL(attention_planes_kernel, dim3(xcd_chunked_grid(B * heads * NKT)), dim3(64), 0, st, QK, Vt, Hhi, Hlo,
+                                   B, heads, C, Mpad, 0.125f);
+            }
+            GP_CHECK_LAUNCH("gp_vit_forward/attention_planes");
+            // x = x + ls1 * proj(attn)
+            if ((rc = gp_gemm_planes256_launch(sq[S_PROJ_HI], sq[S_PROJ_LO], Hhi, Hlo, X, Mpad, nullptr, nullptr, 0, C, Mpad, C,
+                                               3 /*BIAS_I_SCALE_RES*/, w[L_PROJ_B], w[L_LS1], X, Mpad, os, SK, st)))
+                return rc;
+            launch_layernorm_planes(X, Hhi, Hlo, w[L_LN2_G], w[L_LN2_B], C, Mpad, ln_eps, st);
+            GP_CHECK_LAUNCH("gp_vit_forward/layernorm_planes");
+            // gelu(fc1(.)) straight to planes [Mpad][mlp_dim]
+            if ((rc = gp_gemm_planes256_launch(sq[S_FC1_HI], sq[S_FC1_LO], Hhi, Hlo, nullptr, 0, Fhi, Flo, mlp_dim, mlp_dim, Mpad, C,
+                                               6 /*GELU -> planes*/, w[L_FC1_B], nullptr, nullptr, 0, os, SK, st)))
+                return rc;
+            // x = x + ls2 * fc2(.)
+            if ((rc = gp_gemm_planes256_launch(sq[S_FC2_HI], sq[S_FC2_LO], Fhi, Flo, X, Mpad, nullptr, nullptr, 0, C, Mpad, mlp_dim,
+                                               3 /*BIAS_I_SCALE_RES*/, w[L_FC2_B], w[L_LS2], X, Mpad, os, SK, st)))
+                return rc;
+        }
+    }
+    for (int l = planes ? nl : 0; l < nl; ++l) {
         const float* const* w = weights + W_HEADER + l * L_PER_LAYER;
         launch_layernorm(X, Hn, w[L_LN1_G], w[L_LN1_B], C, Mpad, ln_eps, st);
         GP_CHECK_LAUNCH("gp_vit_forward/layernorm");

@@ -180,13 +180,29 @@ int gp_gemm_split256(const float* act, int ld_act, const void* whi, const void* 
                      float* scratch, size_t scratch_bytes, void* stream);
 int gp_gemm_split256_error(const float* scratch, void* stream);
 
+/* Third generation (gp_split256.hip, gemm_planes256_kernel): BOTH operands as pre-split f16 planes, A [I][K] and
+ * B [J][K] (k contiguous; gp_split_planes makes them: hi = f16(scale x), lo = f16(scale x - hi); weights use scale 64,
+ * activations 8), the two wave groups of a workgroup running half a k-step apart (one issues MFMAs while the other
+ * stages).  D[i][j] = epi(out_scale * sum_k A[i][k] B[j][k]), out_scale = 1 / (scale_a * scale_b); epilogues 0-5 as
+ * gp_gemm_split (f32 D, ldd); 6 = bias along i + GELU, written as activation planes out_hi/out_lo[j][i] (x 8, row
+ * stride ldo) for the next GEMM.  Same shape rules, scratch and error word as gp_gemm_split256; results bit-identical
+ * to it. */
+int gp_split_planes(const float* X, size_t count, float scale, void* hi, void* lo, void* stream);
+int gp_gemm_planes256(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
+                      void* out_lo, int ldo, int I, int J, int K, int epilogue, const float* bias, const float* scale,
+                      const float* residual, int ldr, float out_scale, float* scratch, size_t scratch_bytes, void* stream);
+
 /* gp_vit_forward with the linear layers in split-f16 numerics: `split` = HOST array of n_split = 10*depth DEVICE
  * pointers, per layer: qk_hi, qk_lo (2dim, dim), v_hi, v_lo (dim, dim), proj_hi, proj_lo (dim, dim),
  * fc1_hi, fc1_lo (mlp, dim), fc2_hi, fc2_lo (dim, mlp) -- f16 planes of the PyTorch-native [out][in] weights,
  * w ~= hi + lo * 2^-11.  With n_split = 20*depth each layer carries ten more pointers: the same five weights as
  * gp_split256_weights planes; GEMMs whose shape fills the chip with 256 x 256 tiles then use gp_gemm_split256.
- * split == NULL: identical to gp_vit_forward.  (Patch embedding, LayerNorm, attention and
- * the feature epilogue are the same f32 kernels in both modes.) */
+ * When all five GEMMs of a layer do (ViT-L from B = 64), the activations between the kernels travel as token-major
+ * f16 planes written by LayerNorm, attention and fc1's GELU epilogue, and every GEMM is gp_gemm_planes256 (results
+ * bit-identical to the f32-activation kernels; gp_vit_set_planes(0) switches this off).
+ * split == NULL: identical to gp_vit_forward.  (Patch embedding, LayerNorm statistics, attention and the feature
+ * epilogue are the same f32 arithmetic in both modes.) */
+void gp_vit_set_planes(int on);
 int gp_vit_forward_split(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                          const float* const* weights, int n_weights, const void* const* split, int n_split,
                          float* workspace, size_t workspace_bytes, float* out_features, int normalize,

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 import torch
 
+from gigapose_amd import _lib
 from gigapose_amd import synthetic as syn
 from test_gpu_vit import hip_gemm, run_vit
 
@@ -287,3 +288,73 @@ def test_vit_large_split_uses_256_tiles_and_matches_chain():
     d = (chain - split).abs().max().item()
     print(f"ViT-L B=64 unit-norm features chain vs split (256-tile GEMMs): max |diff| {d:.2e}")
     assert d < 2e-6
+    # the default split forward at this size = activation planes + ping-pong plane x plane GEMMs; the f32-activation
+    # lock-step 256-tile kernels compute the same values in the same order: bit-identical features
+    lib = _lib.lib()
+    lib.gp_vit_set_planes(0)
+    try:
+        lockstep = vit.patch_features(x)
+    finally:
+        lib.gp_vit_set_planes(1)
+    assert torch.equal(split, lockstep), f"planes vs f32-activation split forward differ: {(split - lockstep).abs().max().item():.3e}"
+
+
+def planes256_gemm(A, Bm, epi, bias=None, scale=None, res=None, a_scale=64.0, b_scale=8.0):
+    """A [I][K], Bm [J][K] f32 -> D[i][j] through gp_split_planes + gp_gemm_planes256 (epi 6: returns the (hi, lo) planes O[j][i])."""
+    lib = _lib.lib()
+    lib.gp_gemm_split256_workspace_bytes.restype = ctypes.c_size_t
+    nb = lib.gp_gemm_split256_workspace_bytes()
+    ws = torch.zeros(nb // 4, device=DEV)
+
+    def planes(W, sc):
+        hi = torch.empty(W.shape, dtype=torch.float16, device=DEV)
+        lo = torch.empty_like(hi)
+        _lib.call("gp_split_planes", _lib.ptr(W), ctypes.c_size_t(W.numel()), _lib.f(sc), _lib.ptr(hi), _lib.ptr(lo), _lib.stream_ptr())
+        return hi, lo
+
+    (ahi, alo), (bhi, blo) = planes(A, a_scale), planes(Bm, b_scale)
+    I, J, K = A.shape[0], Bm.shape[0], A.shape[1]
+    D = res.clone() if res is not None else torch.zeros(I, J, device=DEV)
+    ohi = torch.zeros(J, I, dtype=torch.float16, device=DEV)
+    olo = torch.zeros_like(ohi)
+    _lib.call("gp_gemm_planes256", _lib.ptr(ahi), _lib.ptr(alo), _lib.ptr(bhi), _lib.ptr(blo), _lib.ptr(D), _lib.i(J), _lib.ptr(ohi),
+              _lib.ptr(olo), _lib.i(I), _lib.i(I), _lib.i(J), _lib.i(K), _lib.i(epi), _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(D),
+              _lib.i(J), _lib.f(1.0 / (a_scale * b_scale)), _lib.ptr(ws), ctypes.c_size_t(nb), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert lib.gp_gemm_split256_error(_lib.ptr(ws), _lib.stream_ptr()) == 0
+    return (ohi, olo) if epi == 6 else D
+
+
+@pytest.mark.parametrize("I,J,K", [(4096, 4096, 64), (2048, 8192, 96), (4352, 4096, 32)])
+def test_planes256_gemm_matches_f64(I, J, K):
+    """Ping-pong plane x plane GEMM (short k loops: 1-3 steps per segment, ragged stream-K ranges) vs f64."""
+    torch.manual_seed(I + K)
+    A = torch.randn(I, K, device=DEV) * 0.05
+    Bm = torch.randn(J, K, device=DEV)
+    D = planes256_gemm(A, Bm, 0)
+    ref = A.double() @ Bm.double().t()
+    mag = A.double().abs() @ Bm.double().abs().t()
+    e = ((D.double() - ref).abs() / mag).max().item()
+    assert e < 2e-6, e
+
+
+def test_planes256_gemm_epilogues():
+    torch.manual_seed(5)
+    I, J, K = 4096, 4096, 128
+    A = torch.randn(I, K, device=DEV) * 0.05
+    Bm = torch.randn(J, K, device=DEV)
+    bias = torch.randn(max(I, J), device=DEV)
+    scale = torch.randn(I, device=DEV)
+    res = torch.randn(I, J, device=DEV)
+    base = (A.double() @ Bm.double().t())
+    tol = dict(rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(planes256_gemm(A, Bm, 1, bias).cpu().double(), (base + bias[:I, None].double()).cpu(), **tol)
+    np.testing.assert_allclose(planes256_gemm(A, Bm, 4, bias).cpu().double(), (base + bias[None, :J].double()).cpu(), **tol)
+    np.testing.assert_allclose(planes256_gemm(A, Bm, 5, bias).cpu().double(), torch.relu(base + bias[:I, None].double()).cpu(), **tol)
+    gelu = torch.nn.functional.gelu(base + bias[:I, None].double())
+    np.testing.assert_allclose(planes256_gemm(A, Bm, 2, bias).cpu().double(), gelu.cpu(), **tol)
+    np.testing.assert_allclose(planes256_gemm(A, Bm, 3, bias, scale, res).cpu().double(),
+                               (res.double() + scale[:, None].double() * (base + bias[:I, None].double())).cpu(), **tol)
+    ohi, olo = planes256_gemm(A, Bm, 6, bias)   # GELU output as activation planes O[j][i] = 8 x, hi + lo
+    back = (ohi.double() + olo.double()) / 8.0
+    np.testing.assert_allclose(back.t().cpu(), gelu.cpu(), **tol)

@@ -342,7 +342,7 @@ unsigned g_epoch256 = 0;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 g16x4 __attribute__((ext_vector_type(4)));
 
-enum { PEPI_GELU_PLANES = 6 };  // bias along i, GELU, output as activation planes O[j][i] (x 8)
+enum { PEPI_GELU_PLANES = 6, PEPI_BIAS_I_PLANES = 7 };  // bias along i (6: + GELU), output as activation planes O[j][i] (x 8)
 
 struct ArgsP {
     const _Float16* ahi; const _Float16* alo;  // A planes [I][K]
@@ -565,14 +565,15 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const int j = j0 + 128 * wc + 32 * ni + l31;
-                    if (EPI == PEPI_GELU_PLANES) {
+                    if (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES) {
 #pragma unroll
                         for (int r4 = 0; r4 < 4; ++r4) {
                             const int i = i0 + 64 * wr + 32 * mi + frag_row(4 * r4, ln);
                             g16x4 oh, ol;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float v = gelu_x(acc[mi][ni][4 * r4 + e] * a.out_scale + a.bias[i + e]) * kActScale;
+                                const float x = acc[mi][ni][4 * r4 + e] * a.out_scale + a.bias[i + e];
+                                const float v = (EPI == PEPI_GELU_PLANES ? gelu_x(x) : x) * kActScale;
                                 const _Float16 hh = (_Float16)v;
                                 oh[e] = hh;
                                 ol[e] = (_Float16)(v - (float)hh);
@@ -612,7 +613,8 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
-    const float v = X[i] * scale;
+    float v = X[i] * scale;
+    asm volatile("" : "+v"(v));  // no v_fma_mixlo_f16 fold of multiply + conversion: hi and lo must see the same rounded v
     const _Float16 h = (_Float16)v;
     hi[i] = h;
     lo[i] = (_Float16)(v - (float)h);
@@ -672,7 +674,7 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
                    ((uintptr_t)bhi % 16 == 0) && ((uintptr_t)blo % 16 == 0) && ((uintptr_t)scratch % 16 == 0),
                "gp_gemm_planes256: null / misaligned operand");
     GP_REQUIRE((long long)I * K * 2 < (1ll << 31) && (long long)J * K * 2 < (1ll << 31), "gp_gemm_planes256: operand planes too large");
-    if (epilogue == PEPI_GELU_PLANES)
+    if (epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES)
         GP_REQUIRE(ohi && olo && ldo % 4 == 0 && ((uintptr_t)ohi % 8 == 0) && ((uintptr_t)olo % 8 == 0) && bias, "gp_gemm_planes256: bad plane output");
     else
         GP_REQUIRE(D && (long long)I * ldd < (1ll << 31) && (long long)I * (ldr > 0 ? ldr : 1) < (1ll << 31), "gp_gemm_planes256: bad f32 output");
@@ -690,6 +692,7 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
         case XEPI_BIAS_J: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_J>), dim3(kSlots), dim3(TNT), 0, st, a); break;
         case XEPI_BIAS_I_RELU: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_RELU>), dim3(kSlots), dim3(TNT), 0, st, a); break;
         case PEPI_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_GELU_PLANES>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        case PEPI_BIAS_I_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES>), dim3(kSlots), dim3(TNT), 0, st, a); break;
         default: GP_REQUIRE(false, "gp_gemm_planes256: unknown epilogue %d", epilogue);
     }
     GP_CHECK_LAUNCH("gp_gemm_planes256");

@@ -408,6 +408,209 @@ __global__ __launch_bounds__(64, 4) void attention_planes_kernel(const float* __
     attention_body<1, true>(Qp, Kp, Vp, nullptr, qb * 32, C, Mpad, scale, Ohi + o, Olo + o, tile);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Attention in split numerics.  Inputs: Q | K | V of every token as f16 planes [Mpad][3C] (x 8; written by the qk and v
+// GEMMs' plane epilogue), output: activation planes [Mpad][C] for proj.  One workgroup per (image, head), nine waves =
+// the nine 32-query tiles; K [288 keys][64] and V^T [64][288 keys] (both planes) are staged in LDS ONCE and shared by the
+// nine waves (the f32 kernel re-reads them from L2 per query tile).  Per wave the S^T trick of attention_body:
+//   S^T[key][query] = sum_d K[key][d] Q[query][d]   as  3 x v_mfma_f32_32x32x16_f16 per 16-d block (hi hi, hi lo, lo hi),
+// so a lane owns one query column, the softmax over keys is in-register, and its P registers 8m .. 8m+7 ARE the B
+// fragment of the P.V MFMA once the hardware k index (lane half, element e) is read as key 16m + 8 (e >> 2) + 4 half
+// + (e & 3) -- the A fragment (V^T row d) fetches the same keys as two 8-byte LDS reads.  P is split as 2^15 p = hi + lo
+// (the low half of a probability above 8e-6 stays a NORMAL f16: subnormal MFMA inputs are flushed).
+// All scalings are powers of two and undone exactly.  exp: exp2 on the hardware unit with the argument's rounding
+// error fed back (<= 2 ulp; libm's expf costs a third of the f32 kernel's time).
+constexpr int AKS = 72;   // K row stride (halfs): 64 + 8 -> rows 4 banks apart
+constexpr int AVS = 292;  // V^T row stride (halfs): 288 + 4 -> 8-byte aligned, rows 18 banks apart
+constexpr int AKEYS = 288;
+
+__device__ __forceinline__ float exp_neg(float x)  // x <= 0 (or -inf)
+{
+    x = fmaxf(x, -10000.0f);
+    const float t = x * 1.4426950216293335f;
+    float e = __builtin_fmaf(x, 1.4426950216293335f, -t);
+    e = __builtin_fmaf(x, 1.925963033500011e-08f, e);
+    const float r = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(r, e * 0.6931471824645996f, r);
+}
+
+__global__ __launch_bounds__(576) void attention_split_kernel(const _Float16* __restrict__ QKVhi, const _Float16* __restrict__ QKVlo,
+                                                               _Float16* __restrict__ Ohi, _Float16* __restrict__ Olo, int B, int H,
+                                                               int C, int Mpad)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 sm[2 * AKEYS * AKS + 2 * 64 * AVS];  // 157,696 bytes
+    _Float16* sKh = sm;
+    _Float16* sKl = sKh + AKEYS * AKS;
+    _Float16* sVh = sKl + AKEYS * AKS;
+    _Float16* sVl = sVh + 64 * AVS;
+    const int bh = xcd_chunked_tile(blockIdx.x, B * H);
+    if (bh < 0) return;
+    const int h = bh % H, b = bh / H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const size_t ld = 3 * (size_t)C, tok0 = (size_t)b * T_TOK;
+
+    // ---- stage K (rows = keys) and V^T (rows = channels); 8 lanes copy the 128 bytes of one key.  All loads first.
+    {
+        constexpr int NCH = 2 * T_TOK * 8, NIT = (NCH + 575) / 576;
+        v16x8 kv[NIT], vv[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int c = tid + 576 * i;
+            if (c < NCH) {
+                const int plane = c >= T_TOK * 8 ? 1 : 0, r = c - plane * T_TOK * 8, key = r >> 3, ch = r & 7;
+                const _Float16* src = (plane ? QKVlo : QKVhi) + (tok0 + key) * ld + C + h * 64 + 8 * ch;
+                kv[i] = *reinterpret_cast<const v16x8*>(src);
+                vv[i] = *reinterpret_cast<const v16x8*>(src + C);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int c = tid + 576 * i;
+            if (c < NCH) {
+                const int plane = c >= T_TOK * 8 ? 1 : 0, r = c - plane * T_TOK * 8, key = r >> 3, ch = r & 7;
+                *reinterpret_cast<v16x8*>((plane ? sKl : sKh) + key * AKS + 8 * ch) = kv[i];
+                _Float16* dst = (plane ? sVl : sVh) + (8 * ch) * AVS + key;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[e * AVS] = vv[i][e];
+            }
+        }
+    }
+    for (int c = tid; c < 2 * (AKEYS - T_TOK) * 8; c += 576) {  // keys 257..287: zero rows (masked below)
+        const int plane = c >= (AKEYS - T_TOK) * 8 ? 1 : 0, r = c - plane * (AKEYS - T_TOK) * 8;
+        v16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
+        *reinterpret_cast<v16x8*>((plane ? sKl : sKh) + (T_TOK + (r >> 3)) * AKS + 8 * (r & 7)) = z;
+    }
+    for (int c = tid; c < 2 * 64 * (AVS - T_TOK); c += 576) {   // V^T columns 257..291: zero (finite x p = 0)
+        const int plane = c >= 64 * (AVS - T_TOK) ? 1 : 0, r = c - plane * 64 * (AVS - T_TOK);
+        (plane ? sVl : sVh)[(r / (AVS - T_TOK)) * AVS + T_TOK + r % (AVS - T_TOK)] = (_Float16)0.f;
+    }
+
+    // ---- this wave's query tile: Q fragments (B operand: column = query, k = 8 half + e inside each 16-d block)
+    const int tq = wave * 32 + l31, tq_c = tq < T_TOK ? tq : T_TOK - 1;
+    const size_t qo = (tok0 + tq_c) * ld + h * 64 + 8 * half;
+    __syncthreads();
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_part = 0.f;
+    const float s_scale = 0.125f / 64.0f;  // softmax scale 64^-0.5, Q and K planes carry x 8 each
+
+#pragma unroll 1
+    for (int ch = 0; ch < 3; ++ch) {
+        f32x16 s[3];
+        v16x8 qh[4], ql[4];  // re-loaded per chunk (L1-hot): not live across the softmax / P.V phase
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            qh[kb] = *reinterpret_cast<const v16x8*>(QKVhi + qo + 16 * kb);
+            ql[kb] = *reinterpret_cast<const v16x8*>(QKVlo + qo + 16 * kb);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+            const int krow = (ch * 3 + t) * 32 + l31;
+            const _Float16* kph = sKh + krow * AKS + 8 * half;
+            const _Float16* kpl = sKl + krow * AKS + 8 * half;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const v16x8 kh = *reinterpret_cast<const v16x8*>(kph + 16 * kb);
+                const v16x8 kl = *reinterpret_cast<const v16x8*>(kpl + 16 * kb);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[kb], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[kb], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[kb], s[t], 0, 0, 0);
+            }
+        }
+        // online softmax over this chunk of 96 keys (same structure as attention_body)
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tk = (ch * 3 + t) * 32 + frag_row(r, lane);
+                const float v = (tk < T_TOK) ? s[t][r] * s_scale : -INFINITY;
+                s[t][r] = v;
+                cmax = fmaxf(cmax, v);
+            }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+        const float m_new = fmaxf(m_run, cmax);
+        const float alpha = exp_neg(m_run - m_new);  // first chunk: exp(-inf) = 0
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp_neg(s[t][r] - m_new);
+                s[t][r] = p;
+                psum += p;
+            }
+        l_part = l_part * alpha + psum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        m_run = m_new;
+        // O^T[d][query] += sum_key V^T[d][key] P^T[key][query], 16 keys per MFMA block (m)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                v16x8 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = s[t][8 * m + e] * 32768.0f;
+                    const _Float16 hh = (_Float16)pv;
+                    ph[e] = hh;
+                    pl[e] = (_Float16)(pv - (float)hh);
+                }
+                const int key0 = (ch * 3 + t) * 32 + 16 * m + 4 * half;
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh) {
+                    const int vo = (32 * dh + l31) * AVS + key0;
+                    const v16x4 a0 = *reinterpret_cast<const v16x4*>(sVh + vo), a1 = *reinterpret_cast<const v16x4*>(sVh + vo + 8);
+                    const v16x4 b0 = *reinterpret_cast<const v16x4*>(sVl + vo), b1 = *reinterpret_cast<const v16x4*>(sVl + vo + 8);
+                    v16x8 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vh[e] = a0[e]; vh[4 + e] = a1[e]; vl[e] = b0[e]; vl[4 + e] = b1[e]; }
+                    if (dh == 0) {
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o0, 0, 0, 0);
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o0, 0, 0, 0);
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o0, 0, 0, 0);
+                    } else {
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o1, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o1, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o1, 0, 0, 0);
+                    }
+                }
+            }
+    }
+    // planes out: 8 * O = acc * inv / 2^15  (acc carries 2^15 p x 8 v); lane = (query, half): 4 consecutive channels per r4
+    const float sc = (1.0f / (l_part + __shfl_xor(l_part, 32))) * (1.0f / 32768.0f);
+    if (tq < T_TOK) {
+        const size_t row = (tok0 + tq) * C + h * 64;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                v16x4 hv, lv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = (dh ? o1[4 * r4 + e] : o0[4 * r4 + e]) * sc;
+                    // keep the rounded f32 product: hipcc otherwise folds multiply + conversion into v_fma_mixlo_f16 (ONE
+                    // rounding of the exact product) for hi but subtracts from the f32-rounded product for lo -- at an f16 tie
+                    // the two disagree by one f16 ulp of hi (seen as sparse 2^-k errors)
+                    asm volatile("" : "+v"(v));
+                    const _Float16 hh = (_Float16)v;
+                    hv[e] = hh;
+                    lv[e] = (_Float16)(v - (float)hh);
+                }
+                const size_t o = row + 32 * dh + frag_row(4 * r4, lane);
+                *reinterpret_cast<v16x4*>(Ohi + o) = hv;
+                *reinterpret_cast<v16x4*>(Olo + o) = lv;
+            }
+    }
+}
+
 // K and V of one (image, head) staged in LDS ONCE and shared by the nine query-tile waves of the workgroup (the
 // register-resident kernel above re-reads them from L2 with one 4-byte load per MFMA, nine times per (image, head)).
 //   sK [64 d][288 keys] (keys >= 257 zero), sV [288 keys][64 d]: 147 KB -> one workgroup per CU, 9 waves.
@@ -511,10 +714,11 @@ __global__ __launch_bounds__(576, 1) void attention_lds_kernel(const float* __re
 // Measured on ViT-L, B=64 (tools/probe_attn.py, whole forward in split numerics): register-resident with one query tile
 // per wave 58.2 ms; two tiles per wave (operand loads shared, 226 VGPR -> 2 waves/SIMD) 60.4 ms; K/V through LDS (one
 // 147 KB workgroup per CU, staging not overlapped) 60.8 ms.  Occupancy wins: the default stays 1.
-// split numerics: activation planes + plane x plane GEMMs when every GEMM of a layer fits them (0: f32 activations and
-// the lock-step kernels, kept for A/B runs and the bit-identity test)
-static int g_vit_planes = 1;
-extern "C" void gp_vit_set_planes(int on) { g_vit_planes = on ? 1 : 0; }
+// split numerics: activation planes + plane x plane GEMMs when every GEMM of a layer fits them.  2 (default): attention in
+// split numerics too (Q | K | V as planes, attention_split_kernel); 1: f32 attention on f32 Q, K, V (bit-identical to 0);
+// 0: f32 activations and the lock-step kernels (kept for A/B runs and the bit-identity test)
+static int g_vit_planes = 2;
+extern "C" void gp_vit_set_planes(int mode) { g_vit_planes = (mode >= 0 && mode <= 2) ? mode : 2; }
 static int g_attn_nq = 1;  // 0: LDS-shared K/V kernel; 1 / 2: register-resident kernel with 1 / 2 query tiles per wave
 extern "C" void gp_attention_set_nq(int nq) { g_attn_nq = (nq >= 0 && nq <= 2) ? nq : 1; }
 
@@ -570,6 +774,17 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
                          const float* const* weights, int n_weights, const void* const* split, int n_split,
                          float* workspace, size_t workspace_bytes, float* out_features, int normalize,
                          int stop_after_layers, void* stream);
+
+int gp_attention_split(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
+                       void* stream)
+{
+    GP_REQUIRE(qkv_hi && qkv_lo && out_hi && out_lo && B > 0 && heads > 0 && dim == heads * 64 && Mpad >= B * T_TOK,
+               "gp_attention_split: bad arguments");
+    hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(576), 0, (hipStream_t)stream,
+                       (const _Float16*)qkv_hi, (const _Float16*)qkv_lo, (_Float16*)out_hi, (_Float16*)out_lo, B, heads, dim, Mpad);
+    GP_CHECK_LAUNCH("gp_attention_split");
+    return GP_OK;
+}
 
 int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                    const float* const* weights, int n_weights, float* workspace, size_t workspace_bytes,
@@ -646,6 +861,23 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
             const void* const* sq = split + l * sp_stride + S_PER_LAYER;  // x64 weight planes [out][in]
             launch_layernorm_planes(X, Hhi, Hlo, w[L_LN1_G], w[L_LN1_B], C, Mpad, ln_eps, st);
             GP_CHECK_LAUNCH("gp_vit_forward/layernorm_planes");
+            if (g_vit_planes == 2) {
+                // Q | K | V as planes [Mpad][3C] (aliasing the f32 QK + Vt buffers): W_qk / W_v (A) x tokens (B), plane epilogue
+                _Float16* Ahi = reinterpret_cast<_Float16*>(QK);
+                _Float16* Alo = Ahi + (size_t)3 * C * Mpad;
+                if ((rc = gp_gemm_planes256_launch(sq[S_QK_HI], sq[S_QK_LO], Hhi, Hlo, nullptr, 0, Ahi, Alo, 3 * C, 2 * C, Mpad, C,
+                                                   7 /*BIAS_I -> planes*/, w[L_QK_B], nullptr, nullptr, 0, os, SK, st)))
+                    return rc;
+                if ((rc = gp_gemm_planes256_launch(sq[S_V_HI], sq[S_V_LO], Hhi, Hlo, nullptr, 0, Ahi + 2 * C, Alo + 2 * C, 3 * C, C, Mpad, C,
+                                                   7 /*BIAS_I -> planes*/, w[L_V_B], nullptr, nullptr, 0, os, SK, st)))
+                    return rc;
+                {
+                    GpProfScope prof(GP_PROF_ATTN, 4.0 * B * heads * 257.0 * 257.0 * 64.0, st);
+                    hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(576), 0, st, Ahi, Alo, Hhi, Hlo, B,
+                                       heads, C, Mpad);
+                }
+                GP_CHECK_LAUNCH("gp_vit_forward/attention_split");
+            } else {
             // Q,K channel-major [2C][Mpad] = W_qk (A) x tokens (B)
             if ((rc = gp_gemm_planes256_launch(sq[S_QK_HI], sq[S_QK_LO], Hhi, Hlo, QK, Mpad, nullptr, nullptr, 0, 2 * C, Mpad, C,
                                                1 /*BIAS_I*/, w[L_QK_B], nullptr, nullptr, 0, os, SK, st)))
@@ -660,6 +892,7 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
                                    B, heads, C, Mpad, 0.125f);
             }
             GP_CHECK_LAUNCH("gp_vit_forward/attention_planes");
+            }
             // x = x + ls1 * proj(attn)
             if ((rc = gp_gemm_planes256_launch(sq[S_PROJ_HI], sq[S_PROJ_LO], Hhi, Hlo, X, Mpad, nullptr, nullptr, 0, C, Mpad, C,
                                                3 /*BIAS_I_SCALE_RES*/, w[L_PROJ_B], w[L_LS1], X, Mpad, os, SK, st)))

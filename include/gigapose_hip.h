@@ -184,8 +184,8 @@ int gp_gemm_split256_error(const float* scratch, void* stream);
  * B [J][K] (k contiguous; gp_split_planes makes them: hi = f16(scale x), lo = f16(scale x - hi); weights use scale 64,
  * activations 8), the two wave groups of a workgroup running half a k-step apart (one issues MFMAs while the other
  * stages).  D[i][j] = epi(out_scale * sum_k A[i][k] B[j][k]), out_scale = 1 / (scale_a * scale_b); epilogues 0-5 as
- * gp_gemm_split (f32 D, ldd); 6 = bias along i + GELU, written as activation planes out_hi/out_lo[j][i] (x 8, row
- * stride ldo) for the next GEMM.  Same shape rules, scratch and error word as gp_gemm_split256; results bit-identical
+ * gp_gemm_split (f32 D, ldd); 6 = bias along i + GELU, 7 = bias along i, both written as activation planes
+ * out_hi/out_lo[j][i] (x 8, row stride ldo) for the next kernel.  Same shape rules, scratch and error word as gp_gemm_split256; results bit-identical
  * to it. */
 int gp_split_planes(const float* X, size_t count, float scale, void* hi, void* lo, void* stream);
 int gp_gemm_planes256(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
@@ -202,7 +202,13 @@ int gp_gemm_planes256(const void* a_hi, const void* a_lo, const void* b_hi, cons
  * bit-identical to the f32-activation kernels; gp_vit_set_planes(0) switches this off).
  * split == NULL: identical to gp_vit_forward.  (Patch embedding, LayerNorm statistics, attention and the feature
  * epilogue are the same f32 arithmetic in both modes.) */
-void gp_vit_set_planes(int on);
+void gp_vit_set_planes(int mode); /* 2 (default) = planes + attention in split numerics, 1 = planes + f32 attention, 0 = off */
+
+/* softmax(q k^T / 8) v per (image, head) in split numerics (attention_split_kernel): qkv_hi/lo = f16 planes [Mpad][3 dim]
+ * of Q | K | V (x 8, token b*257 + t in row order), out_hi/lo = planes [Mpad][dim] (x 8) of the attention output;
+ * replaces HF modeling_dinov2.py:207-229 inside AENet.forward for the split mode. */
+int gp_attention_split(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
+                       void* stream);
 int gp_vit_forward_split(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                          const float* const* weights, int n_weights, const void* const* split, int n_split,
                          float* workspace, size_t workspace_bytes, float* out_features, int normalize,

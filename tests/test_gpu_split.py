@@ -288,15 +288,49 @@ def test_vit_large_split_uses_256_tiles_and_matches_chain():
     d = (chain - split).abs().max().item()
     print(f"ViT-L B=64 unit-norm features chain vs split (256-tile GEMMs): max |diff| {d:.2e}")
     assert d < 2e-6
-    # the default split forward at this size = activation planes + ping-pong plane x plane GEMMs; the f32-activation
-    # lock-step 256-tile kernels compute the same values in the same order: bit-identical features
+    # the default split forward at this size = activation planes + ping-pong plane x plane GEMMs + attention in split
+    # numerics (mode 2).  Mode 1 keeps the f32 attention: the same values in the same order as the f32-activation
+    # lock-step 256-tile kernels (mode 0) -> bit-identical features.
     lib = _lib.lib()
-    lib.gp_vit_set_planes(0)
     try:
+        lib.gp_vit_set_planes(0)
         lockstep = vit.patch_features(x)
-    finally:
         lib.gp_vit_set_planes(1)
-    assert torch.equal(split, lockstep), f"planes vs f32-activation split forward differ: {(split - lockstep).abs().max().item():.3e}"
+        planes_f32_attention = vit.patch_features(x)
+    finally:
+        lib.gp_vit_set_planes(2)
+    assert torch.equal(planes_f32_attention, lockstep), \
+        f"planes vs f32-activation split forward differ: {(planes_f32_attention - lockstep).abs().max().item():.3e}"
+    d2 = (split - lockstep).abs().max().item()
+    print(f"ViT-L B=64 split attention vs f32 attention (both split GEMMs): max |diff| {d2:.2e}")
+    assert d2 < 1e-6
+
+
+def test_attention_split_matches_f64():
+    """attention_split_kernel (Q | K | V planes -> output planes) vs float64 softmax attention on the same plane values."""
+    torch.manual_seed(11)
+    B, H = 3, 6
+    C = 64 * H
+    M = B * 257
+    Mpad = (M + 255) // 256 * 256
+    qkv = torch.zeros(Mpad, 3 * C, device=DEV)
+    qkv[:M] = torch.randn(M, 3 * C, device=DEV) * torch.tensor([1.5] * (2 * C) + [1.0] * C, device=DEV)
+    hi = torch.empty(Mpad, 3 * C, dtype=torch.float16, device=DEV)
+    lo = torch.empty_like(hi)
+    _lib.call("gp_split_planes", _lib.ptr(qkv), ctypes.c_size_t(qkv.numel()), _lib.f(8.0), _lib.ptr(hi), _lib.ptr(lo), _lib.stream_ptr())
+    ohi = torch.zeros(Mpad, C, dtype=torch.float16, device=DEV)
+    olo = torch.zeros_like(ohi)
+    _lib.call("gp_attention_split", _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(ohi), _lib.ptr(olo), _lib.i(B), _lib.i(H), _lib.i(C), _lib.i(Mpad),
+              _lib.stream_ptr())
+    torch.cuda.synchronize()
+    got = ((ohi.double() + olo.double()) / 8.0)[:M].view(B, 257, H, 64)
+    x = ((hi.double() + lo.double()) / 8.0)[:M].view(B, 257, 3, H, 64)
+    q, k, v = x[:, :, 0].permute(0, 2, 1, 3), x[:, :, 1].permute(0, 2, 1, 3), x[:, :, 2].permute(0, 2, 1, 3)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v).permute(0, 2, 1, 3)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    print(f"split attention vs f64: max |err| / max |ref| = {err:.2e}")
+    assert err < 2e-6, err
+    assert torch.count_nonzero(ohi[M:]) == 0  # pad rows untouched
 
 
 def planes256_gemm(A, Bm, epi, bias=None, scale=None, res=None, a_scale=64.0, b_scale=8.0):
@@ -322,7 +356,7 @@ def planes256_gemm(A, Bm, epi, bias=None, scale=None, res=None, a_scale=64.0, b_
               _lib.i(J), _lib.f(1.0 / (a_scale * b_scale)), _lib.ptr(ws), ctypes.c_size_t(nb), _lib.stream_ptr())
     torch.cuda.synchronize()
     assert lib.gp_gemm_split256_error(_lib.ptr(ws), _lib.stream_ptr()) == 0
-    return (ohi, olo) if epi == 6 else D
+    return (ohi, olo) if epi in (6, 7) else D
 
 
 @pytest.mark.parametrize("I,J,K", [(4096, 4096, 64), (2048, 8192, 96), (4352, 4096, 32)])
@@ -358,3 +392,6 @@ def test_planes256_gemm_epilogues():
     ohi, olo = planes256_gemm(A, Bm, 6, bias)   # GELU output as activation planes O[j][i] = 8 x, hi + lo
     back = (ohi.double() + olo.double()) / 8.0
     np.testing.assert_allclose(back.t().cpu(), gelu.cpu(), **tol)
+    ohi, olo = planes256_gemm(A, Bm, 7, bias)   # bias only, as planes (the Q | K | V producer)
+    back = (ohi.double() + olo.double()) / 8.0
+    np.testing.assert_allclose(back.t().cpu(), (base + bias[:I, None].double()).cpu(), **tol)

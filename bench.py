@@ -227,7 +227,7 @@ def main():
         "value": round(crops / dt, 2), "unit": "query-crops/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32 (linear layers + matcher: f32 operands split into f16 hi/lo, 3 x f16 MFMA per k-block, f32 accumulate -- "
+        "dtype": ("f32 (ViT linear layers + attention, matcher, IST convolutions: f32 operands split into f16 hi/lo, 3 x f16 MFMA per k-block, f32 accumulate -- "
                   "error vs f64 below the f32 fmaf chain's, tests/test_gpu_split.py; everything else f32)"
                   if args.numerics == "split" else "f32"),
         "data": "synthetic",

@@ -354,6 +354,7 @@ struct ArgsP {
     int tiles_i, tiles_j, group;
     int* flags; float* partial; int epoch;
     float out_scale;
+    int dp;
 };
 
 template <int EPI, bool TIMING = false>
@@ -372,13 +373,19 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
     const int T = a.tiles_i * a.tiles_j;
     const int t_lo = (int)((long long)T * x / 8), n_t = (int)((long long)T * (x + 1) / 8) - t_lo;
     const int nstep = a.K / TBK;
-    const long long U = (long long)n_t * nstep;
+    // Data-parallel rounds first: while the chunk holds two or more tiles per slot, round r gives slot n the whole tile
+    // r * slots_x + n -- the 32 slots of an XCD then sit on the same k-step of 32 neighbouring tiles (4 i-panels x 8
+    // j-panels) and share their operand slabs in that XCD's L2.  Only the last round + remainder is cut stream-K style
+    // (its slots run at staggered k offsets and get no L2 reuse: 1.9 GB fetched per fc1 launch when everything was).
+    const int rounds_dp = (a.dp && n_t / slots_x > 1) ? n_t / slots_x - 1 : 0;
+    const int n_dp = rounds_dp * slots_x;
+    const long long U = (long long)(n_t - n_dp) * nstep;
     const long long u0 = U * n / slots_x, u1 = U * (n + 1) / slots_x;
     const int ta = (int)(u0 / nstep), sa = (int)(u0 % nstep);
     const int tb = (int)(u1 / nstep), sb = (int)(u1 % nstep);
     const int n_head = sb > 0 ? 1 : 0, n_rest = sa > 0 ? 1 : 0;
     const int first_whole = ta + n_rest;
-    const int n_seg = n_head + (tb - first_whole) + n_rest;
+    const int n_seg = rounds_dp + n_head + (tb - first_whole) + n_rest;
 
     // staging: thread = (row tid >> 2 [+128], 16-byte k-chunk tid & 3) of each of the four planes
     const __amdgpu_buffer_rsrc_t r_ahi = __builtin_amdgcn_make_buffer_rsrc((void*)a.ahi, 0, a.tiles_i * TB * a.K * 2, 0x00020000);
@@ -396,9 +403,10 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
     const int bk0 = ((kh_ ^ ((br_ >> 2) & 3)) << 3), bk1 = (((kh_ + 2) ^ ((br_ >> 2) & 3)) << 3);
 
     for (int seg = 0; seg < n_seg; ++seg) {
-        const bool is_head = seg < n_head;
-        const bool is_rest = n_rest && seg == n_seg - 1;
-        const int t = is_head ? tb : (is_rest ? ta : first_whole + seg - n_head);
+        const bool is_dp = seg < rounds_dp;
+        const bool is_head = !is_dp && seg - rounds_dp < n_head;
+        const bool is_rest = !is_dp && n_rest && seg == n_seg - 1;
+        const int t = is_dp ? seg * slots_x + n : n_dp + (is_head ? tb : (is_rest ? ta : first_whole + seg - rounds_dp - n_head));
         const int s0 = is_rest ? sa : 0, s1 = is_head ? sb : nstep;
         const int q = t_lo + t;
         const int per_band = a.group * a.tiles_j;
@@ -664,6 +672,8 @@ int gp_gemm_split256_launch(const float* act, int ld_act, const void* whi, const
     return GP_OK;
 }
 
+static int g_planes_dp = 1;  // 1: data-parallel rounds before the stream-K remainder (0: everything stream-K; A/B hook)
+
 // internal entry (gp_vit.hip): D[i][j] = epi( out_scale * sum_k A[i][k] B[j][k] ), A / B = pre-split planes (see above)
 int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
                              void* olo, int ldo, int I, int J, int K, int epilogue, const float* bias, const float* scale,
@@ -680,7 +690,7 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
         GP_REQUIRE(D && (long long)I * ldd < (1ll << 31) && (long long)I * (ldr > 0 ? ldr : 1) < (1ll << 31), "gp_gemm_planes256: bad f32 output");
     ArgsP a{(const _Float16*)ahi, (const _Float16*)alo, (const _Float16*)bhi, (const _Float16*)blo, D, ldd, (_Float16*)ohi, (_Float16*)olo, ldo,
             K, bias, scale, res, ldr, I / TB, J / TB, 4, reinterpret_cast<int*>(scratch),
-            reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, out_scale};
+            reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, out_scale, g_planes_dp};
     g_epoch256 = (g_epoch256 + 1) & 0x3fffffff;
     a.epoch = (int)(0x40000000u | g_epoch256);
     GpProfScope prof(GP_PROF_GEMM_SPLIT, 2.0 * I * J * K, st);
@@ -768,13 +778,19 @@ int gp_gemm_planes256_timing(const void* a_hi, const void* a_lo, const void* b_h
     if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
     ArgsP a{(const _Float16*)a_hi, (const _Float16*)a_lo, (const _Float16*)b_hi, (const _Float16*)b_lo, D, ldd, nullptr, nullptr, 0,
             K, nullptr, nullptr, nullptr, 0, I / TB, J / TB, 4, reinterpret_cast<int*>(scratch),
-            reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, kOutScale};
+            reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, kOutScale, g_planes_dp};
     if (++g_epoch256 == 0) ++g_epoch256;
     a.epoch = (int)g_epoch256;
     hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_NONE, true>), dim3(kSlots), dim3(TNT), 0, (hipStream_t)stream, a);
     GP_CHECK_LAUNCH("gp_gemm_planes256_timing");
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
     return hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_t256), 8 * sizeof(unsigned long long)) == hipSuccess ? GP_OK : GP_ELAUNCH;
+}
+
+int gp_gemm_planes256_set_dp(int on)
+{
+    g_planes_dp = on ? 1 : 0;
+    return GP_OK;
 }
 
 int gp_gemm_split256_error(const float* scratch, void* stream)

@@ -186,8 +186,10 @@ class Dinov2ViT(nn.Module):
                         split += list(split_planes_x64(w))  # needs |activation| < 8190 -- GIGAPOSE_SPLIT_GEMM=128 keeps
                                                             # every GEMM on the two-accumulator kernel, range 65504)
             split_table = (ctypes.c_void_p * len(split))(*[t.data_ptr() for t in split])
-            if "GIGAPOSE_VIT_PLANES" in os.environ:  # A/B probes: 0 f32 activations, 1 default (csrc/gp_vit.hip)
+            if "GIGAPOSE_VIT_PLANES" in os.environ:  # A/B probes (csrc/gp_vit.hip): 0 f32 activations, 1 f32 attention, 2 default
                 _lib.lib().gp_vit_set_planes(int(os.environ["GIGAPOSE_VIT_PLANES"]))
+            if "GIGAPOSE_PLANES_DP" in os.environ:   # A/B probe: 0 = every plane-GEMM tile cut stream-K style
+                _lib.lib().gp_gemm_planes256_set_dp(int(os.environ["GIGAPOSE_PLANES_DP"]))
         self._packed = (device, tensors, table, split, split_table)
 
     def _workspace(self, B, device):

@@ -359,9 +359,10 @@ def planes256_gemm(A, Bm, epi, bias=None, scale=None, res=None, a_scale=64.0, b_
     return (ohi, olo) if epi in (6, 7) else D
 
 
-@pytest.mark.parametrize("I,J,K", [(4096, 4096, 64), (2048, 8192, 96), (4352, 4096, 32)])
+@pytest.mark.parametrize("I,J,K", [(4096, 4096, 64), (2048, 8192, 96), (4352, 4096, 32), (8192, 8448, 64)])
 def test_planes256_gemm_matches_f64(I, J, K):
-    """Ping-pong plane x plane GEMM (short k loops: 1-3 steps per segment, ragged stream-K ranges) vs f64."""
+    """Ping-pong plane x plane GEMM (short k loops: 1-3 steps per segment, ragged stream-K ranges; the last shape has 132 tiles
+    per XCD = 3 data-parallel rounds + a stream-K remainder) vs f64."""
     torch.manual_seed(I + K)
     A = torch.randn(I, K, device=DEV) * 0.05
     Bm = torch.randn(J, K, device=DEV)

@@ -331,7 +331,7 @@ unsigned g_epoch256 = 0;
 
 // ---------------------------------------------------------------------------------------------------------------
 // Third generation: BOTH operands arrive as pre-split f16 planes [n][K] (weights x 64 as above; activations x 8, written
-// token-major by their producers: gp_vit.hip's LayerNorm / attention kernels and this kernel's GELU epilogue), so the
+// token-major by their producers: gp_vit.hip's LayerNorm / attention kernels and this kernel's plane epilogues), so the
 // staging of a k-step is eight 16-byte copies per thread -- no conversion, one address register (buffer loads:
 // descriptor + per-thread voffset + scalar offset) -- and the two wave groups of the workgroup (waves 0-3 and 4-7, one
 // wave of each per SIMD) run half a step apart: while one group issues the 48 MFMAs of slab s (matrix phase C(s)) the
@@ -339,6 +339,7 @@ unsigned g_epoch256 = 0;
 // The lock-step kernel above idles the matrix pipe during every staging phase (60 % busy in-loop,
 // profiles/r01_probe_split256.txt).  Tile, LDS layout, single accumulator, stream-K hand-off and epilogues are those
 // of gemm_split256_kernel; the arithmetic (operand values, k order) is identical, so results are bit-identical to it.
+// Work distribution: data-parallel rounds of whole tiles first (L2 reuse), stream-K only for the last round + remainder.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 g16x4 __attribute__((ext_vector_type(4)));
 
@@ -348,7 +349,7 @@ struct ArgsP {
     const _Float16* ahi; const _Float16* alo;  // A planes [I][K]
     const _Float16* bhi; const _Float16* blo;  // B planes [J][K]
     float* D; int ldd;                         // f32 output D[i][j]
-    _Float16* ohi; _Float16* olo; int ldo;     // PEPI_GELU_PLANES: O[j][i]
+    _Float16* ohi; _Float16* olo; int ldo;     // PEPI_*_PLANES: O[j][i]
     int K;
     const float* bias; const float* scale; const float* res; int ldr;
     int tiles_i, tiles_j, group;

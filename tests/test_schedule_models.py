@@ -1,0 +1,110 @@
+"""Host-side models of two device schedules of gp_split256.hip's gemm_planes256_kernel, checked exhaustively on CPU:
+
+* the work plan of a launch (data-parallel rounds + stream-K remainder per XCD chunk): every (tile, k-step) unit is
+  computed exactly once, and every split tile's second part reads the fragment its first part publishes;
+* the half-step-offset k loop of the two wave groups (one barrier per k-step): LDS slabs are complete before they are
+  read and never overwritten while still being read.
+
+The arithmetic below restates the kernel's index computations line by line (same names); the GPU tests check the
+kernel itself against f64 and bit-for-bit against the lock-step kernel."""
+import pytest
+
+
+def launch_plan(T, nstep, dp=True, slots=256):
+    """-> {slot: [(tile, s0, s1, kind)]}, kind in {"dp", "head", "whole", "rest"}; tile is the global chunk-ordered index."""
+    plan = {}
+    for p in range(slots):
+        x, n, slots_x = p & 7, p >> 3, slots >> 3
+        t_lo = T * x // 8
+        n_t = T * (x + 1) // 8 - t_lo
+        rounds_dp = n_t // slots_x - 1 if (dp and n_t // slots_x > 1) else 0
+        n_dp = rounds_dp * slots_x
+        U = (n_t - n_dp) * nstep
+        u0, u1 = U * n // slots_x, U * (n + 1) // slots_x
+        ta, sa = divmod(u0, nstep)
+        tb, sb = divmod(u1, nstep)
+        n_head, n_rest = (1 if sb > 0 else 0), (1 if sa > 0 else 0)
+        first_whole = ta + n_rest
+        n_seg = rounds_dp + n_head + (tb - first_whole) + n_rest
+        segs = []
+        for seg in range(n_seg):
+            is_dp = seg < rounds_dp
+            is_head = (not is_dp) and seg - rounds_dp < n_head
+            is_rest = (not is_dp) and n_rest == 1 and seg == n_seg - 1
+            t = seg * slots_x + n if is_dp else n_dp + (tb if is_head else (ta if is_rest else first_whole + seg - rounds_dp - n_head))
+            assert 0 <= t < n_t and not (is_head and is_rest)
+            s0, s1 = (sa if is_rest else 0), (sb if is_head else nstep)
+            segs.append((t_lo + t, s0, s1, "dp" if is_dp else "head" if is_head else "rest" if is_rest else "whole"))
+        plan[p] = segs
+    return plan
+
+
+@pytest.mark.parametrize("T,nstep", [(1040, 32), (520, 32), (260, 32), (260, 128), (256, 2), (272, 1), (1056, 2), (2080, 4),
+                                      (300, 3), (4096, 1), (257, 7)])
+@pytest.mark.parametrize("dp", [True, False])
+def test_launch_plan_covers_every_unit_once_and_pairs_hand_offs(T, nstep, dp):
+    plan = launch_plan(T, nstep, dp)
+    seen = {}
+    for p, segs in plan.items():
+        kinds = [k for *_, k in segs]
+        # order inside a slot: data-parallel rounds, then the published head, whole tiles, the received rest last
+        assert kinds == sorted(kinds, key=["dp", "head", "whole", "rest"].index)
+        for tile, s0, s1, _ in segs:
+            assert s0 < s1
+            for s in range(s0, s1):
+                assert (tile, s) not in seen, (tile, s)
+                seen[(tile, s)] = p
+    assert len(seen) == T * nstep
+    heads = {p: (t, s1) for p, segs in plan.items() for t, s0, s1, k in segs if k == "head"}
+    for p, segs in plan.items():
+        for t, s0, s1, k in segs:
+            if k == "rest":  # continues the tile exactly where slot p - 8 (same XCD, previous slot) stopped
+                assert heads.get(p - 8) == (t, s0), (p, t, s0)
+            if k == "head":
+                assert s0 == 0   # the chain of a split tile starts at k = 0 in the publishing slot
+    if dp:  # the data-parallel part puts the 32 slots of an XCD on 32 consecutive tiles of its chunk
+        for p, segs in plan.items():
+            for r, (t, s0, s1, k) in enumerate(segs):
+                if k == "dp":
+                    x, n = p & 7, p >> 3
+                    assert t == T * x // 8 + r * 32 + n and (s0, s1) == (0, nstep)
+
+
+def group_events(grp, ns):
+    """The k loop of one wave group: C(s) = matrix phase on slab s, M(s) = stage slab s (+ load s+1), B = workgroup barrier."""
+    ev = []
+    if grp:
+        ev.append(("M", 1))
+    for s in range(ns):
+        ev.append(("C", s))
+        if grp and s + 1 < ns:
+            ev.append("B")
+        ev.append(("M", s + 1 + grp))
+        if (not grp) and s + 1 < ns:
+            ev.append("B")
+    return ev
+
+
+@pytest.mark.parametrize("ns", list(range(1, 12)) + [32, 128])
+def test_half_step_offset_loop_has_no_lds_hazard(ns):
+    ev = [group_events(0, ns), group_events(1, ns)]
+    assert ev[0].count("B") == ev[1].count("B") == ns - 1          # same barrier count: no deadlock
+    epoch = [{}, {}]                                               # (kind, slab) -> index of the barrier interval
+    for g in (0, 1):
+        k = 0
+        for e in ev[g]:
+            if e == "B":
+                k += 1
+            elif e[0] == "C" or e[1] < ns:                         # M of a slab >= ns stages nothing
+                epoch[g][e] = k
+    for slab in range(1, ns):
+        for g in (0, 1):
+            for gg in (0, 1):
+                # slab complete: every group's stage of it lies in an EARLIER barrier interval than any read of it
+                # (or the same interval of the same wave, which program order covers -- never the case here)
+                assert epoch[gg][("M", slab)] < epoch[g][("C", slab)], (ns, slab, g, gg)
+                # buffer reuse: slab (same buffer as slab - 2) is staged only after every read of slab - 2
+                if slab >= 2:
+                    assert epoch[g][("M", slab)] > epoch[gg][("C", slab - 2)], (ns, slab, g, gg)
+    # the offset: group 1 stages while group 0 computes, in the first half of every interval
+    assert ev[0][0] == ("C", 0) and ev[1][0] == ("M", 1)

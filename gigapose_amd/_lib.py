@@ -42,6 +42,35 @@ def lib():
     return _lib
 
 
+STATUS_BITS = {1: "a stream-K accumulator hand-over of the split GEMM timed out (features are garbage)",
+               2: "a stream-K accumulator hand-over of the f32 GEMM timed out (features are garbage)",
+               4: "split numerics: an activation left the range of the f16 planes (|x| >= 8190) or is not finite -- "
+                  "use numerics 'chain' or GIGAPOSE_SPLIT_GEMM=128 for this checkpoint",
+               8: "a detection label / template id lies outside the onboarded bank (the reference raises IndexError)"}
+_status = None
+
+
+def status_word(device=None):
+    """The device int32 the kernels OR their guard-rail bits into (include/gigapose_hip.h: gp_set_status_buffer).
+    Created on first use (the library then holds its address) -- one GPU per process, as everywhere in this package."""
+    global _status
+    if _status is None:
+        _status = torch.zeros(1, dtype=torch.int32, device=device or "cuda")
+        call("gp_set_status_buffer", ctypes.c_void_p(_status.data_ptr()))
+    return _status
+
+
+def check_status():
+    """Read + clear the status word (a host synchronisation: call where one happens anyway) and raise if a bit is set."""
+    if _status is None:
+        return
+    bits = int(_status.item())
+    if bits:
+        _status.zero_()
+        msgs = [m for b, m in STATUS_BITS.items() if bits & b]
+        raise GigaPoseHipError("device status 0x%x: %s" % (bits, "; ".join(msgs)))
+
+
 def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -6,6 +6,8 @@
 #include "gp_common.h"
 
 static thread_local char g_err[512] = "";
+static int* g_status = nullptr;  // device int32 owned by the caller (gp_set_status_buffer)
+int* gp_status_buffer() { return g_status; }
 
 void gp_set_error(const char* fmt, ...)
 {
@@ -69,5 +71,10 @@ int gp_prof_end(int max_kinds, double* ms, double* work, long long* launches)
 }
 const char* gp_prof_kind_name(int kind) { return (kind >= 0 && kind < GP_PROF_KINDS) ? kKindNames[kind] : ""; }
 const char* gp_last_error(void) { return g_err; }
+int gp_set_status_buffer(int* device_word)
+{
+    g_status = device_word;
+    return GP_OK;
+}
 int gp_abi_version(void) { return 1; }
 }

@@ -18,6 +18,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GP_P 256  // patches per crop (16x16)
 #define GP_G 16
 
+// Device-side status word (guard rails): kernels OR a bit into *gp_status_buffer() when something that must not pass
+// silently happens; the host reads it at its next synchronisation point (gigapose_amd/_lib.py: check_status) and raises.
+// The buffer is the caller's (gp_set_status_buffer, one int32 on the device); NULL = reporting off.
+enum { GP_ST_HANDOFF_SPLIT = 1,   // a stream-K accumulator hand-over of the split GEMMs timed out: that tile is garbage
+       GP_ST_HANDOFF_CHAIN = 2,   // same, f32 (chain) GEMM
+       GP_ST_SPLIT_RANGE = 4,     // an activation left the range of the single-accumulator split planes (|x| >= 8190) or is not finite
+       GP_ST_LABEL_RANGE = 8 };   // a detection label / template id outside the onboarded bank
+int* gp_status_buffer();
+__device__ __forceinline__ void gp_raise(int* status, int bit)
+{
+    if (status) atomicOr(status, bit);
+}
+constexpr float kSplitPlaneLimit = 65504.0f;  // largest finite f16: |8 x| beyond it would store inf in the hi plane
+
 // set by every entry point on failure; read through gp_last_error()
 void gp_set_error(const char* fmt, ...);
 

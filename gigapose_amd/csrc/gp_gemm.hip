@@ -48,6 +48,7 @@ struct GemmArgs {
     int* flags;      // stream-K only
     float* partial;  // stream-K only
     int epoch;       // stream-K only: value a published flag carries in this launch (never 0)
+    int* status;     // guard rails (gp_common.h)
 };
 
 // tile list position q -> tile origin.  The ~128 tiles an XCD runs concurrently form a compact
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(GM::NT, 8) void gemm_streamk_kernel(const GemmArgs 
                     __builtin_amdgcn_s_sleep(16);
                     if (++spins > kSpinLimit) {
                         __hip_atomic_store(a.flags + kMaxSlots, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gp_raise(a.status, GP_ST_HANDOFF_CHAIN);
                         break;
                     }
                 }
@@ -216,7 +218,7 @@ template <int EPI>
 int launch(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J, int K,
            const float* bias, const float* scale, const float* res, int ldr, float* sk_ws, hipStream_t st)
 {
-    GemmArgs a{A, lda, B, ldb, D, ldd, K, bias, scale, res, ldr, I / GM::BM, J / GM::BN, g_group, nullptr, nullptr, 0};
+    GemmArgs a{A, lda, B, ldb, D, ldd, K, bias, scale, res, ldr, I / GM::BM, J / GM::BN, g_group, nullptr, nullptr, 0, gp_status_buffer()};
     const int T = a.tiles_i * a.tiles_j;
     // Measured on ViT-L at B=64 (tools/probe_vit.py): with fewer than 4 tiles per slot the balanced split wins
     // (fc2 1.32 -> 1.13 ms, V 0.34 -> 0.30, QK 0.60 -> 0.58, proj 0.35 -> 0.34); from 4 tiles per slot on, the

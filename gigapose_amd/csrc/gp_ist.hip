@@ -22,9 +22,16 @@ __global__ __launch_bounds__(256) void ist_gather_kernel(
     const float* __restrict__ src_bank,  // (O, N, D, 256)
     const int* __restrict__ labels, const long long* __restrict__ id_src,  // (B), (B,k)
     const long long* __restrict__ tar_pts, const long long* __restrict__ src_pts,  // (B,k,256,2)
-    int N, int k, int D, size_t R, float* __restrict__ X)
+    int O, int N, int k, int D, size_t R, float* __restrict__ X, int* __restrict__ status)
 {
     const int bk = blockIdx.x, b = bk / k, t = threadIdx.x;
+    int lab = labels[b];
+    long long view = id_src[bk];
+    if ((unsigned)lab >= (unsigned)O || (unsigned long long)view >= (unsigned long long)N) {  // the reference's index would raise
+        if (t == 0) gp_raise(status, GP_ST_LABEL_RANGE);
+        lab = 0;
+        view = 0;
+    }
     const size_t r = (size_t)bk * GP_P + t;
     const long long tx = tar_pts[2 * r], ty = tar_pts[2 * r + 1];
     const long long sx = src_pts[2 * r], sy = src_pts[2 * r + 1];
@@ -32,7 +39,7 @@ __global__ __launch_bounds__(256) void ist_gather_kernel(
     const int ti = valid ? (int)(ty * GP_G + tx) : 0;  // index = y * W + x   (batch.py:63)
     const int si = valid ? (int)(sy * GP_G + sx) : 0;
     const float* tf = tar_feat + (size_t)b * D * GP_P + ti;
-    const float* sf = src_bank + (((size_t)labels[b] * N + (size_t)id_src[bk]) * D) * GP_P + si;
+    const float* sf = src_bank + (((size_t)lab * N + (size_t)view) * D) * GP_P + si;
     for (int c = 0; c < D; ++c) X[(size_t)c * R + r] = tf[(size_t)c * GP_P];
     for (int c = 0; c < D; ++c) X[(size_t)(D + c) * R + r] = sf[(size_t)c * GP_P];
 }
@@ -99,7 +106,7 @@ int gp_ist_regress(const float* tar_feat, const float* src_bank, const int* labe
     float* H1 = X + (size_t)2 * D * R;
     float* H2 = H1 + (size_t)2 * H * R;
     hipLaunchKernelGGL(ist_gather_kernel, dim3(B * k), dim3(256), 0, st, tar_feat, src_bank, labels, id_src,
-                       tar_pts, src_pts, N, k, D, R, X);
+                       tar_pts, src_pts, O, N, k, D, R, X, gp_status_buffer());
     GP_CHECK_LAUNCH("gp_ist_regress/gather");
     int rc;
     for (int head = 0; head < 2; ++head) {  // 0: scale_predictor, 1: inplane_predictor (ist_net.py:140-155)

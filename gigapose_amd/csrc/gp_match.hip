@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void match_tiles_kernel(
     const float* __restrict__ qmask,  // (B, 256)
     const float* __restrict__ bmask,  // (O, N, 256)
     const int* __restrict__ labels,   // (B) 0-based object index
-    int B, int N, int C, float thr, float patch_thr,
+    int B, int O, int N, int C, float thr, float patch_thr, int* __restrict__ status,
     uint8_t* __restrict__ idx_t2s,    // (B, N, 256)
     float* __restrict__ score_t2s,    // (B, N, 256)
     float* __restrict__ mask_all,     // (B, N, 256)
@@ -207,7 +207,12 @@ __global__ __launch_bounds__(512, 2) void match_tiles_kernel(
     const int gsz = min(8, B - band * 8);
     const int b = band * 8 + r8 % gsz, n = r8 / gsz;
     const int tid = threadIdx.x;
-    const size_t on = (size_t)labels[b] * N + n;
+    int lab = labels[b];
+    if ((unsigned)lab >= (unsigned)O) {  // the reference raises IndexError at ae_features[label - 1] (gigaPose.py:520)
+        if (tid == 0) gp_raise(status, GP_ST_LABEL_RANGE);
+        lab = 0;
+    }
+    const size_t on = (size_t)lab * N + n;
     const float* A = query + (size_t)b * C * GP_P;
     const float* Bm = bank + on * (size_t)C * GP_P;
 
@@ -250,9 +255,9 @@ struct MatchSplitSmem {
 __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo,  // (B, 256, C)
     const _Float16* __restrict__ b_hi, const _Float16* __restrict__ b_lo,  // (O*N, 256, C)
-    const float* __restrict__ qmask, const float* __restrict__ bmask, const int* __restrict__ labels, int B, int N, int C,
-    float thr, float patch_thr, uint8_t* __restrict__ idx_t2s, float* __restrict__ score_t2s, float* __restrict__ mask_all,
-    float* __restrict__ sim_avg)
+    const float* __restrict__ qmask, const float* __restrict__ bmask, const int* __restrict__ labels, int B, int O, int N, int C,
+    float thr, float patch_thr, int* __restrict__ status, uint8_t* __restrict__ idx_t2s, float* __restrict__ score_t2s,
+    float* __restrict__ mask_all, float* __restrict__ sim_avg)
 {
     __shared__ MatchSplitSmem sm;
     const int q = xcd_chunked_tile(blockIdx.x, B * N);
@@ -262,7 +267,12 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     const int b = band * 8 + r8 % gsz, n = r8 / gsz;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const size_t on = (size_t)labels[b] * N + n;
+    int lab = labels[b];
+    if ((unsigned)lab >= (unsigned)O) {
+        if (tid == 0) gp_raise(status, GP_ST_LABEL_RANGE);
+        lab = 0;
+    }
+    const size_t on = (size_t)lab * N + n;
     if (tid < GP_P) sm.qmask[tid] = qmask[(size_t)b * GP_P + tid];
     else sm.smask[tid - GP_P] = bmask[on * GP_P + (tid - GP_P)];
 
@@ -467,8 +477,8 @@ int gp_match_tiles(const float* query, const float* bank, const float* qmask, co
                "gp_match_tiles: null pointer");
     GpProfScope prof(GP_PROF_MATCH, 2.0 * B * N * 256.0 * 256.0 * C, (hipStream_t)stream);
     hipLaunchKernelGGL(match_tiles_kernel, dim3(xcd_chunked_grid(B * N)), dim3(512), 0,
-                       (hipStream_t)stream, query, bank, qmask, bmask, labels, B, N, C, sim_threshold,
-                       patch_threshold, idx_t2s, score_t2s, mask_all, sim_avg);
+                       (hipStream_t)stream, query, bank, qmask, bmask, labels, B, O, N, C, sim_threshold,
+                       patch_threshold, gp_status_buffer(), idx_t2s, score_t2s, mask_all, sim_avg);
     GP_CHECK_LAUNCH("gp_match_tiles");
     return GP_OK;
 }
@@ -497,7 +507,7 @@ int gp_match_tiles_split(const void* q_hi, const void* q_lo, const void* b_hi, c
     GpProfScope prof(GP_PROF_MATCH_SPLIT, 2.0 * B * N * 256.0 * 256.0 * C, (hipStream_t)stream);
     hipLaunchKernelGGL(match_tiles_split_kernel, dim3(xcd_chunked_grid(B * N)), dim3(512), 0, (hipStream_t)stream,
                        (const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)b_hi, (const _Float16*)b_lo, qmask,
-                       bmask, labels, B, N, C, sim_threshold, patch_threshold, idx_t2s, score_t2s, mask_all, sim_avg);
+                       bmask, labels, B, O, N, C, sim_threshold, patch_threshold, gp_status_buffer(), idx_t2s, score_t2s, mask_all, sim_avg);
     GP_CHECK_LAUNCH("gp_match_tiles_split");
     return GP_OK;
 }

@@ -171,16 +171,23 @@ __global__ __launch_bounds__(64) void recover_kernel(
     const int* __restrict__ labels, const float* __restrict__ tar_K, const float* __restrict__ tar_M,  // (B), (B,3,3) x2
     const long long* __restrict__ id_src, const float* __restrict__ pred_M,                           // (B,k), (B,k,3,3)
     const float* __restrict__ tmpl_K, const float* __restrict__ tmpl_M, const float* __restrict__ tmpl_pose,  // (O,3,3) (O,N,3,3) (O,N,4,4)
-    int B, int N, int k, float* __restrict__ out /*(B,k,4,4)*/, int* __restrict__ bad_crop_M)
+    int B, int O, int N, int k, float* __restrict__ out /*(B,k,4,4)*/, int* __restrict__ bad_crop_M, int* __restrict__ status)
 {
     const int bk = blockIdx.x * 64 + threadIdx.x;
     if (bk >= B * k) return;
     const int b = bk / k;
-    const size_t on = (size_t)labels[b] * N + (size_t)id_src[bk];
+    int lab = labels[b];
+    long long view = id_src[bk];
+    if ((unsigned)lab >= (unsigned)O || (unsigned long long)view >= (unsigned long long)N) {
+        gp_raise(status, GP_ST_LABEL_RANGE);
+        lab = 0;
+        view = 0;
+    }
+    const size_t on = (size_t)lab * N + (size_t)view;
     const float* qM = tar_M + (size_t)b * 9;
     const float* qK = tar_K + (size_t)b * 9;
     const float* M = pred_M + (size_t)bk * 9;
-    const float* tK = tmpl_K + (size_t)labels[b] * 9;
+    const float* tK = tmpl_K + (size_t)lab * 9;
     const float* tM = tmpl_M + on * 9;
     const float* tP = tmpl_pose + on * 16;
     // the reference asserts the crop transform is isotropic scale + translation (lib3d/torch.py:54-55)
@@ -250,7 +257,7 @@ int gp_recover_poses(const int* labels, const float* tar_K, const float* tar_M, 
     GP_REQUIRE(labels && tar_K && tar_M && id_src && pred_M && tmpl_K && tmpl_M && tmpl_pose && poses && bad_crop_M,
                "gp_recover_poses: null pointer");
     hipLaunchKernelGGL(recover_kernel, dim3((B * k + 63) / 64), dim3(64), 0, (hipStream_t)stream, labels, tar_K,
-                       tar_M, id_src, pred_M, tmpl_K, tmpl_M, tmpl_pose, B, N, k, poses, bad_crop_M);
+                       tar_M, id_src, pred_M, tmpl_K, tmpl_M, tmpl_pose, B, O, N, k, poses, bad_crop_M, gp_status_buffer());
     GP_CHECK_LAUNCH("gp_recover_poses");
     return GP_OK;
 }

@@ -22,6 +22,8 @@
 
 typedef _Float16 g16x8 __attribute__((ext_vector_type(8)));
 typedef float g32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 g16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -30,6 +32,7 @@ constexpr int TB = 256, TBK = 32, TNT = 512;
 constexpr int TROW = 32, TPLANE = TB * TROW;  // halfs
 constexpr int TBUF = 4 * TPLANE;              // A hi, A lo, B hi, B lo
 constexpr int kSlots = 256;
+constexpr int kErrWord = 1025;  // scratch header word: beyond gp_gemm.hip's 1024 slot flags + its own error word (shared scratch)
 constexpr size_t kHeaderBytes = 8192;
 constexpr size_t kFragFloats = (size_t)TB * TB;
 constexpr int kSpin = 400000;
@@ -43,6 +46,7 @@ struct Args256 {
     const float* bias; const float* scale; const float* res; int ldr;
     int tiles_i, tiles_j, group;
     int* flags; float* partial; int epoch;
+    int* status;
 };
 
 __device__ __forceinline__ int toff(int row, int kc) { return row * TROW + ((kc ^ ((row >> 2) & 3)) << 3); }
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_split256_kernel(const Args256 a)
     const int ng = tid & 127, kg = tid >> 7;
     g32x2 ract[8];
     g16x8 rw[4];
+    int bad = 0;  // range guard: some |8 x| this thread converted is beyond f16 or not finite
     // fragment addressing
     const int ar_ = 64 * wr + (lane & 31), br_ = 128 * wc + (lane & 31), kh_ = lane >> 5;
     const int arow = ar_ * TROW, brow = br_ * TROW;
@@ -139,7 +144,8 @@ __global__ __launch_bounds__(TNT, 2) void gemm_split256_kernel(const Args256 a)
                 while (__hip_atomic_load(a.flags + (p - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
                     __builtin_amdgcn_s_sleep(16);
                     if (++spins > kSpin) {
-                        __hip_atomic_store(a.flags + kSlots, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(a.flags + kErrWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gp_raise(a.status, GP_ST_HANDOFF_SPLIT);
                         break;
                     }
                 }
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_split256_kernel(const Args256 a)
                     const _Float16 hh = (_Float16)v;
                     h[r] = hh;
                     l[r] = (_Float16)(v - (float)hh);
+                    bad |= !(fabsf(v) <= kSplitPlaneLimit);  // !(<=): NaN counts
                 }
                 const int off = toff(ng * 2 + c, kg);
                 *reinterpret_cast<g16x8*>(L + act_hi + off) = h;
@@ -321,6 +328,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_split256_kernel(const Args256 a)
             __syncthreads();  // LDS buffer 0 is re-staged by the next segment's prologue
         }
     }
+    if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE);
     if (TIMING && blockIdx.x == 100 && tid == 0)
         for (int i = 0; i < 6; ++i) g_t256[i] = tc[i];
 }
@@ -340,9 +348,6 @@ unsigned g_epoch256 = 0;
 // profiles/r01_probe_split256.txt).  Tile, LDS layout, single accumulator, stream-K hand-off and epilogues are those
 // of gemm_split256_kernel; the arithmetic (operand values, k order) is identical, so results are bit-identical to it.
 // Work distribution: data-parallel rounds of whole tiles first (L2 reuse), stream-K only for the last round + remainder.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 g16x4 __attribute__((ext_vector_type(4)));
-
 enum { PEPI_GELU_PLANES = 6, PEPI_BIAS_I_PLANES = 7 };  // bias along i (6: + GELU), output as activation planes O[j][i] (x 8)
 
 struct ArgsP {
@@ -356,7 +361,124 @@ struct ArgsP {
     int* flags; float* partial; int epoch;
     float out_scale;
     int dp;
+    unsigned long long* trace;  // TIMING builds: per-block segment time stamps (100 MHz ticks), else null
+    int* status;                // guard rails (gp_common.h)
 };
+
+__device__ __forceinline__ float lane_bcast(float v, int lane)  // value held by `lane` (compile-time constant) -> SGPR
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// ---- Epilogues through LDS.  The accumulator fragment of v_mfma_f32_32x32x16_f16 gives a lane ONE column j and rows
+// i in groups of four, so direct stores are 4-byte (f32 D[i][j]) or 8-byte (planes O[j][i]) pieces: 512 vector-memory
+// instructions per lane and tile for the residual epilogue, each touching 2 (f32) or 32 (planes) cache lines -- the
+// per-slot timeline showed the epilogues costing 40-90 us per tile against 73 us for the k loop of a K = 1024 tile.
+// After the k loop the 128 KiB of operand buffers are free: each wave owns 16 KiB of them and turns its 64 x 128 tile
+// in two rounds, so that every global access is 16 bytes per lane over full 128-byte lines (64 instead of 512
+// instructions per lane for the residual epilogue).  Wave-private: no workgroup barrier between the rounds (LDS
+// operations of one wave execute in order).  Same arithmetic per element as before: results are bit-identical.
+template <int EPI>
+__device__ __forceinline__ void epilogue_f32_lds(const ArgsP& a, f32x16 (&acc)[2][4], float* __restrict__ wl, int i_base, int j_base, int ln)
+{
+    const int l31 = ln & 31, half = ln >> 5;
+    constexpr bool kBiasI = EPI == XEPI_BIAS_I || EPI == XEPI_BIAS_I_GELU || EPI == XEPI_BIAS_I_SCALE_RES || EPI == XEPI_BIAS_I_RELU;
+    float bias_l = 0.f, scale_l = 0.f;  // lane l holds the value of row i_base + l
+    if (kBiasI) bias_l = a.bias[i_base + ln];
+    if (EPI == XEPI_BIAS_I_SCALE_RES) scale_l = a.scale[i_base + ln];
+    f32x4 bias_j = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == XEPI_BIAS_J) bias_j = *reinterpret_cast<const f32x4*>(a.bias + j_base + 4 * l31);
+    const unsigned j = (unsigned)(j_base + 4 * l31);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        // round mi: rows 32 mi .. 32 mi + 31 of the wave tile as wl[32][128] (writes: a lane group covers 32 consecutive
+        // words of a row; reads: 16 bytes per lane, a wave covers two whole rows -- both conflict-free without padding)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wl[frag_row(r, ln) * 128 + 32 * ni + l31] = acc[mi][ni][r];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = 2 * it + half;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(wl + row * 128 + 4 * l31);
+            const unsigned i = (unsigned)(i_base + 32 * mi + row);
+            float b = 0.f, sc = 0.f;
+            if (kBiasI) {
+                const float b0 = lane_bcast(bias_l, 32 * mi + 2 * it), b1 = lane_bcast(bias_l, 32 * mi + 2 * it + 1);
+                b = half ? b1 : b0;
+            }
+            f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+            if (EPI == XEPI_BIAS_I_SCALE_RES) {
+                const float s0 = lane_bcast(scale_l, 32 * mi + 2 * it), s1 = lane_bcast(scale_l, 32 * mi + 2 * it + 1);
+                sc = half ? s1 : s0;
+                rs = *reinterpret_cast<const f32x4*>(a.res + i * (unsigned)a.ldr + j);
+            }
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = t[e] * a.out_scale;
+                if (kBiasI) v = v + b;
+                if (EPI == XEPI_BIAS_J) v = v + bias_j[e];
+                if (EPI == XEPI_BIAS_I_GELU) v = gelu_x(v);
+                if (EPI == XEPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
+                if (EPI == XEPI_BIAS_I_SCALE_RES) v = rs[e] + sc * v;
+                o[e] = v;
+            }
+            *reinterpret_cast<f32x4*>(a.D + i * (unsigned)a.ldd + j) = o;
+        }
+    }
+}
+
+// planes O[j][i] (x 8, hi + lo): round h = columns 64 h .. 64 h + 63 of the wave tile, all 64 rows: per plane 64 token
+// rows of 128 bytes, the 8-byte pieces a lane produces XOR-placed by the token (2-way on the writes, the 16-byte reads
+// conflict-free), then 16 bytes per lane: 8 lanes cover the 128 contiguous bytes a token row gets from this wave.
+template <int EPI>
+__device__ __forceinline__ void epilogue_planes_lds(const ArgsP& a, f32x16 (&acc)[2][4], char* __restrict__ wl, int i_base, int j_base, int ln)
+{
+    const int l31 = ln & 31, half = ln >> 5;
+    const float bias_l = a.bias[i_base + ln];
+    int bad = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+            const int ni = 2 * h + nn, jl = 32 * nn + l31;
+            char* wrow = wl + jl * 128;
+            const int sw = (jl & 7) << 1;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    g16x4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float b0 = lane_bcast(bias_l, 32 * mi + 8 * r4 + e), b1 = lane_bcast(bias_l, 32 * mi + 8 * r4 + 4 + e);
+                        const float x = acc[mi][ni][4 * r4 + e] * a.out_scale + (half ? b1 : b0);
+                        const float v = (EPI == PEPI_GELU_PLANES ? gelu_x(x) : x) * kActScale;
+                        const _Float16 hh = (_Float16)v;
+                        oh[e] = hh;
+                        ol[e] = (_Float16)(v - (float)hh);
+                        bad |= !(fabsf(v) <= kSplitPlaneLimit);  // !(<=): NaN counts
+                    }
+                    const int c8 = 8 * mi + 2 * r4 + half;  // 8-byte piece of the 128-byte row: rows 4 c8 .. 4 c8 + 3
+                    *reinterpret_cast<g16x4*>(wrow + ((c8 ^ sw) << 3)) = oh;
+                    *reinterpret_cast<g16x4*>(wrow + 8192 + ((c8 ^ sw) << 3)) = ol;
+                }
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            _Float16* O = pl ? a.olo : a.ohi;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int jl = 8 * it + (ln >> 3), c16 = ln & 7;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(wl + pl * 8192 + jl * 128 + ((c16 ^ (jl & 7)) << 4));
+                const size_t o = (size_t)(unsigned)(j_base + 64 * h + jl) * (unsigned)a.ldo + (unsigned)(i_base + 8 * c16);
+                *reinterpret_cast<u32x4*>(O + o) = v;
+            }
+        }
+    }
+    if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE);
+}
 
 template <int EPI, bool TIMING = false>
 __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
@@ -378,7 +500,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
     // r * slots_x + n -- the 32 slots of an XCD then sit on the same k-step of 32 neighbouring tiles (4 i-panels x 8
     // j-panels) and share their operand slabs in that XCD's L2.  Only the last round + remainder is cut stream-K style
     // (its slots run at staggered k offsets and get no L2 reuse: 1.9 GB fetched per fc1 launch when everything was).
-    const int rounds_dp = (a.dp && n_t / slots_x > 1) ? n_t / slots_x - 1 : 0;
+    const int rounds_dp = ((a.dp & 1) && n_t / slots_x > 1) ? n_t / slots_x - 1 : 0;
     const int n_dp = rounds_dp * slots_x;
     const long long U = (long long)(n_t - n_dp) * nstep;
     const long long u0 = U * n / slots_x, u1 = U * (n + 1) / slots_x;
@@ -403,6 +525,10 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
     const int ak0 = ((kh_ ^ ((ar_ >> 2) & 3)) << 3), ak1 = (((kh_ + 2) ^ ((ar_ >> 2) & 3)) << 3);
     const int bk0 = ((kh_ ^ ((br_ >> 2) & 3)) << 3), bk1 = (((kh_ + 2) ^ ((br_ >> 2) & 3)) << 3);
 
+    if (TIMING && a.trace && tid == 0) {
+        a.trace[(size_t)p * 32 + 0] = wall_clock64();
+        a.trace[(size_t)p * 32 + 1] = (unsigned long long)n_seg;
+    }
     for (int seg = 0; seg < n_seg; ++seg) {
         const bool is_dp = seg < rounds_dp;
         const bool is_head = !is_dp && seg - rounds_dp < n_head;
@@ -423,7 +549,8 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
                 while (__hip_atomic_load(a.flags + (p - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
                     __builtin_amdgcn_s_sleep(16);
                     if (++spins > kSpin) {
-                        __hip_atomic_store(a.flags + kSlots, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(a.flags + kErrWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gp_raise(a.status, GP_ST_HANDOFF_SPLIT);
                         break;
                     }
                 }
@@ -452,6 +579,10 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
 
         // ---- k loop over steps [s0, s1)
         const int ns = s1 - s0;
+        if (TIMING && a.trace && tid == 0 && seg < 7) {  // kind (0 whole tile, 1 head = publishes, 2 rest = continues), steps, start
+            a.trace[(size_t)p * 32 + 2 + 4 * seg] = ((unsigned long long)(is_head ? 1 : (is_rest ? 2 : 0)) << 32) | (unsigned)ns;
+            a.trace[(size_t)p * 32 + 3 + 4 * seg] = wall_clock64();
+        }
         const unsigned sA0 = ((unsigned)i0 * (unsigned)a.K + (unsigned)s0 * TBK) * 2u;  // scalar byte offsets of slab s0
         const unsigned sB0 = ((unsigned)j0 * (unsigned)a.K + (unsigned)s0 * TBK) * 2u;
         auto gload = [&](int slab) {
@@ -544,6 +675,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
             if (TIMING) { t1 = __builtin_readcyclecounter(); tc[3] += t1 - t0; }
         }
 #undef X_MFMA
+        if (TIMING && a.trace && tid == 0 && seg < 7) a.trace[(size_t)p * 32 + 4 + 4 * seg] = wall_clock64();
 
         if (is_head) {  // publish the fragment for slot n+1 (agent-scope release by one lane)
             f32x4* w = reinterpret_cast<f32x4*>(a.partial + (size_t)p * kFragFloats) + tid * 32;
@@ -563,51 +695,21 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(a.flags + p, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(a.dp & 2))  // test hook (gp_gemm_planes256_set_dp(.. | 2)): a LOST hand-off -> the waiter must time out and flag it
+                    __hip_atomic_store(a.flags + p, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
             int tid_ = threadIdx.x;
             asm volatile("" : "+v"(tid_));  // keep the epilogue's address arithmetic inside the segment loop
-            const int ln = tid_ & 63, l31 = ln & 31;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const int j = j0 + 128 * wc + 32 * ni + l31;
-                    if (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES) {
-#pragma unroll
-                        for (int r4 = 0; r4 < 4; ++r4) {
-                            const int i = i0 + 64 * wr + 32 * mi + frag_row(4 * r4, ln);
-                            g16x4 oh, ol;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float x = acc[mi][ni][4 * r4 + e] * a.out_scale + a.bias[i + e];
-                                const float v = (EPI == PEPI_GELU_PLANES ? gelu_x(x) : x) * kActScale;
-                                const _Float16 hh = (_Float16)v;
-                                oh[e] = hh;
-                                ol[e] = (_Float16)(v - (float)hh);
-                            }
-                            const size_t o = (size_t)(unsigned)j * (unsigned)a.ldo + (unsigned)i;
-                            *reinterpret_cast<g16x4*>(a.ohi + o) = oh;
-                            *reinterpret_cast<g16x4*>(a.olo + o) = ol;
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int i = i0 + 64 * wr + 32 * mi + frag_row(r, ln);
-                            float v = acc[mi][ni][r] * a.out_scale;
-                            if (EPI == XEPI_BIAS_I || EPI == XEPI_BIAS_I_GELU || EPI == XEPI_BIAS_I_SCALE_RES || EPI == XEPI_BIAS_I_RELU)
-                                v = v + a.bias[i];
-                            if (EPI == XEPI_BIAS_J) v = v + a.bias[j];
-                            if (EPI == XEPI_BIAS_I_GELU) v = gelu_x(v);
-                            if (EPI == XEPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
-                            if (EPI == XEPI_BIAS_I_SCALE_RES) v = a.res[(unsigned)i * (unsigned)a.ldr + (unsigned)j] + a.scale[i] * v;
-                            a.D[(unsigned)i * (unsigned)a.ldd + (unsigned)j] = v;
-                        }
-                    }
-                }
+            __syncthreads();                // every wave has read its last operand fragments: the buffers are free
+            char* wl = reinterpret_cast<char*>(lds) + (tid_ >> 6) * 16384;
+            if (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES)
+                epilogue_planes_lds<EPI>(a, acc, wl, i0 + 64 * wr, j0 + 128 * wc, tid_ & 63);
+            else
+                epilogue_f32_lds<EPI>(a, acc, reinterpret_cast<float*>(wl), i0 + 64 * wr, j0 + 128 * wc, tid_ & 63);
             __syncthreads();  // LDS buffer 0 is re-staged by the next segment's prologue
         }
+        if (TIMING && a.trace && tid == 0 && seg < 7) a.trace[(size_t)p * 32 + 5 + 4 * seg] = wall_clock64();
     }
     if (TIMING && blockIdx.x == 100 && tid == 0) {
         for (int i = 0; i < 6; ++i) g_t256[i] = tc[i];
@@ -656,7 +758,7 @@ int gp_gemm_split256_launch(const float* act, int ld_act, const void* whi, const
                "gp_gemm_split256: null / misaligned operand");
     GP_REQUIRE((long long)I * ldd < (1ll << 31) && (long long)I * (ldr > 0 ? ldr : 1) < (1ll << 31), "gp_gemm_split256: output too large");
     Args256 a{act, ld_act, (const _Float16*)whi, (const _Float16*)wlo, D, ldd, K, bias, scale, res, ldr, I / TB, J / TB, 4,
-              reinterpret_cast<int*>(scratch), reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0};
+              reinterpret_cast<int*>(scratch), reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, gp_status_buffer()};
     g_epoch256 = (g_epoch256 + 1) & 0x3fffffff;  // bit 30 marks this kernel's epochs: it may share a scratch (and its
     a.epoch = (int)(0x40000000u | g_epoch256);    // flags) with gp_gemm.hip's stream-K inside one forward
     GpProfScope prof(GP_PROF_GEMM_SPLIT, 2.0 * I * J * K, st);
@@ -688,10 +790,14 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
     if (epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES)
         GP_REQUIRE(ohi && olo && ldo % 4 == 0 && ((uintptr_t)ohi % 8 == 0) && ((uintptr_t)olo % 8 == 0) && bias, "gp_gemm_planes256: bad plane output");
     else
-        GP_REQUIRE(D && (long long)I * ldd < (1ll << 31) && (long long)I * (ldr > 0 ? ldr : 1) < (1ll << 31), "gp_gemm_planes256: bad f32 output");
+        GP_REQUIRE(D && (long long)I * ldd < (1ll << 31) && (long long)I * (ldr > 0 ? ldr : 1) < (1ll << 31) && ldd % 4 == 0 && ldr % 4 == 0 &&
+                       ((uintptr_t)D % 16 == 0) && ((uintptr_t)res % 16 == 0) && (epilogue != XEPI_BIAS_J || (uintptr_t)bias % 16 == 0),
+                   "gp_gemm_planes256: bad f32 output (16-byte rows)");
+    if (epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES)
+        GP_REQUIRE(ldo % 8 == 0 && ((uintptr_t)ohi % 16 == 0) && ((uintptr_t)olo % 16 == 0), "gp_gemm_planes256: plane output rows must be 16-byte aligned");
     ArgsP a{(const _Float16*)ahi, (const _Float16*)alo, (const _Float16*)bhi, (const _Float16*)blo, D, ldd, (_Float16*)ohi, (_Float16*)olo, ldo,
             K, bias, scale, res, ldr, I / TB, J / TB, 4, reinterpret_cast<int*>(scratch),
-            reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, out_scale, g_planes_dp};
+            reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, out_scale, g_planes_dp, nullptr, gp_status_buffer()};
     g_epoch256 = (g_epoch256 + 1) & 0x3fffffff;
     a.epoch = (int)(0x40000000u | g_epoch256);
     GpProfScope prof(GP_PROF_GEMM_SPLIT, 2.0 * I * J * K, st);
@@ -788,16 +894,42 @@ int gp_gemm_planes256_timing(const void* a_hi, const void* a_lo, const void* b_h
     return hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_t256), 8 * sizeof(unsigned long long)) == hipSuccess ? GP_OK : GP_ELAUNCH;
 }
 
-int gp_gemm_planes256_set_dp(int on)
+/* probe: the launch of gp_gemm_planes256 (epilogues 0, 3, 6, 7) from a build with time stamps: trace (device,
+ * 256 x 32 u64) receives per slot: [0] start, [1] segments, then per segment (first 7): kind << 32 | k-steps, start of its
+ * k loop (after the accumulator hand-over wait, if any), end of the k loop, end of its epilogue / publish -- 100 MHz ticks */
+int gp_gemm_planes256_trace(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
+                            void* out_lo, int ldo, int I, int J, int K, int epilogue, const float* bias, const float* scale,
+                            const float* residual, int ldr, float out_scale, float* scratch, unsigned long long* trace, void* stream)
 {
-    g_planes_dp = on ? 1 : 0;
+    GP_REQUIRE(gp_gemm_split256_usable(I, J, K) && trace && scratch, "gp_gemm_planes256_trace: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(scratch, 0, kHeaderBytes, st) != hipSuccess) return GP_ELAUNCH;
+    ArgsP a{(const _Float16*)a_hi, (const _Float16*)a_lo, (const _Float16*)b_hi, (const _Float16*)b_lo, D, ldd, (_Float16*)out_hi,
+            (_Float16*)out_lo, ldo, K, bias, scale, residual, ldr, I / TB, J / TB, 4, reinterpret_cast<int*>(scratch),
+            reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, out_scale, g_planes_dp, trace, gp_status_buffer()};
+    g_epoch256 = (g_epoch256 + 1) & 0x3fffffff;
+    a.epoch = (int)(0x40000000u | g_epoch256);
+    switch (epilogue) {
+        case XEPI_NONE: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_NONE, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        case XEPI_BIAS_I_SCALE_RES: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        case PEPI_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_GELU_PLANES, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        case PEPI_BIAS_I_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        default: GP_REQUIRE(false, "gp_gemm_planes256_trace: epilogue %d has no traced build", epilogue);
+    }
+    GP_CHECK_LAUNCH("gp_gemm_planes256_trace");
+    return GP_OK;
+}
+
+int gp_gemm_planes256_set_dp(int mode)  // bit 0: data-parallel rounds (default on); bit 1: test hook, head fragments are never published
+{
+    g_planes_dp = mode & 3;
     return GP_OK;
 }
 
 int gp_gemm_split256_error(const float* scratch, void* stream)
 {
     int e = -1;
-    if (hipMemcpyAsync(&e, reinterpret_cast<const int*>(scratch) + kSlots, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) !=
+    if (hipMemcpyAsync(&e, reinterpret_cast<const int*>(scratch) + kErrWord, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) !=
             hipSuccess ||
         hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
         return -1;

@@ -146,12 +146,14 @@ constexpr float kPlaneScale = 8.0f;  // == kActScale of gp_split256.hip
 
 __global__ __launch_bounds__(1024) void layernorm_planes_kernel(const float* __restrict__ X, _Float16* __restrict__ Yhi,
                                                                  _Float16* __restrict__ Ylo, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, int C, int Mpad, float eps)
+                                                                 const float* __restrict__ beta, int C, int Mpad, float eps,
+                                                                 int* __restrict__ status)
 {
     __shared__ float red[16][64];
     const int tok = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int per = C >> 4, c0 = sl * per;
     const float* x = X + (size_t)c0 * Mpad + (size_t)blockIdx.x * 64 + tok;
+    int bad = 0;  // range guard of the x 8 planes (gp_common.h: GP_ST_SPLIT_RANGE)
     float s = 0.f;
 #pragma unroll 8
     for (int i = 0; i < per; ++i) s += x[(size_t)i * Mpad];
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(1024) void layernorm_planes_kernel(const float* __r
             const float v = y * kPlaneScale;
             const _Float16 hh = (_Float16)v;
             const _Float16 ll = (_Float16)(v - (float)hh);
+            bad |= !(fabsf(v) <= kSplitPlaneLimit);  // !(<=): a NaN / inf residual stream counts
             T[cl * 65 + tok] = (unsigned int)__builtin_bit_cast(unsigned short, hh) |
                                ((unsigned int)__builtin_bit_cast(unsigned short, ll) << 16);
         }
@@ -207,13 +210,14 @@ __global__ __launch_bounds__(1024) void layernorm_planes_kernel(const float* __r
         *reinterpret_cast<v16x8*>(Yhi + row + 128 * k) = h;
         *reinterpret_cast<v16x8*>(Ylo + row + 128 * k) = l;
     }
+    if (bad) gp_raise(status, GP_ST_SPLIT_RANGE);
 }
 
 int launch_layernorm_planes(const float* X, _Float16* hi, _Float16* lo, const float* g, const float* b, int C, int Mpad, float eps,
                             hipStream_t st)
 {
     GpProfScope prof(GP_PROF_LN, 8.0 * C * Mpad, st);
-    hipLaunchKernelGGL(layernorm_planes_kernel, dim3(Mpad / 64), dim3(1024), 0, st, X, hi, lo, g, b, C, Mpad, eps);
+    hipLaunchKernelGGL(layernorm_planes_kernel, dim3(Mpad / 64), dim3(1024), 0, st, X, hi, lo, g, b, C, Mpad, eps, gp_status_buffer());
     return 0;
 }
 

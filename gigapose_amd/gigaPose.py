@@ -19,6 +19,7 @@ import pandas as pd
 import torch
 from torch import nn
 
+from . import _lib
 from .matching import MatchBank
 from .poses import ObjectPoseRecovery
 from .tensor_collection import PandasTensorCollection
@@ -96,6 +97,8 @@ class GigaPose(_Base):
         t0 = time.time()
         template_dataset = self.template_datasets[dataset_name]
         dev = self.device
+        if torch.device(dev).type == "cuda":
+            _lib.status_word(dev)
         cols = {n: [] for n in ["mask", "K", "M", "poses", "ae_features", "ist_features"]}
         lo, hi = 0, None
         if self.template_shard is not None:
@@ -121,6 +124,7 @@ class GigaPose(_Base):
         self.pose_recovery[dataset_name] = ObjectPoseRecovery(template_K=data["K"], template_Ms=data["M"],
                                                               template_poses=data["poses"])
         torch.cuda.synchronize()
+        _lib.check_status()
         self.onboarding_time = (time.time() - t0) / max(1, len(template_dataset))
 
     # ------------------------------------------------------------------ the hot loop
@@ -132,6 +136,11 @@ class GigaPose(_Base):
         ransac_*, scores (B,k), pred_poses (B,k,4,4)."""
         bank = self.match_banks[dataset_name]
         template_data = self.template_datas[dataset_name]
+        n_obj = template_data.ist_features.shape[0]
+        if not labels.is_cuda and labels.numel() and (int(labels.min()) < 1 or int(labels.max()) > n_obj):
+            raise IndexError(f"detection label outside 1..{n_obj} (the reference indexes ae_features[label - 1], gigaPose.py:520)")
+        if tar_img.is_cuda:
+            _lib.status_word(tar_img.device)  # device labels / hand-offs / split range are checked by the kernels (check_status)
         labels0 = (labels.to(tar_img.device) - 1).to(torch.int32).contiguous()
         side = None
         if self.overlap_ist and tar_img.is_cuda:
@@ -182,6 +191,7 @@ class GigaPose(_Base):
                                    sort_pred_by_inliers)
         predictions.infos = batch.infos
         torch.cuda.synchronize()
+        _lib.check_status()  # guard rails: lost hand-off / split range / label range -> GigaPoseHipError, never silent garbage
         total_time = time.time() - t0
         self.last_predictions = predictions
         save_path = osp.join(self.log_dir, "predictions", f"{idx_batch}.npz")

@@ -68,6 +68,20 @@ class ResNet(nn.Module):
         self.numerics = mode
         return self
 
+    def invalidate(self):
+        """Drop the packed (folded-BN / split-plane) weight copies; they are rebuilt at the next forward."""
+        self._packed = None
+        self._split = None
+
+    def _load_from_state_dict(self, *a, **k):
+        # nn.Module.load_state_dict on ANY ancestor (GigaPose, a Lightning checkpoint load) recurses through here
+        self.invalidate()
+        return super()._load_from_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):   # .to() / .float() / .cuda(): the packed copies follow the parameters
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
     # ------------------------------------------------------------------ torch fp32 reference
     def reference_forward(self, x):
         """Plain PyTorch statement of resnet.py:364-381 -- the fp32 reference the HIP path is tested
@@ -248,11 +262,13 @@ class ISTNet(nn.Module):
         self._packed = None
         self._ws = None
 
-    def load_state_dict(self, *a, **k):
+    def _load_from_state_dict(self, *a, **k):
+        self._packed = None   # regressor weight table; reached from a parent module's load_state_dict too
+        return super()._load_from_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
         self._packed = None
-        self.backbone._packed = None
-        self.backbone._split = None
-        return super().load_state_dict(*a, **k)
+        return super()._apply(fn, *a, **k)
 
     @torch.no_grad()
     def forward_by_chunk(self, processed_rgbs):

@@ -207,6 +207,27 @@ def fill_state_dict(module, seed):
     return module
 
 
+def condition_ist(module):
+    """Rescale a random-init ISTNet (reference or mirror; keyed by state-dict names) into the regime a TRAINED one
+    works in: the Kaiming-initialised net emits |features| ~ 23, scales of 5 +- 15 (negative ones included) and fully
+    saturated tanh outputs, so two correct f32 evaluations of it differ by ~3e-4 relative and RANSAC's 14-px test is
+    decided by rounding.  Exact power-of-two rescalings of three weight tensors + fixed output biases give features
+    of O(1), relScale = 1.2 +- 0.02 and (cos, sin) ~ (cos 0.3, sin 0.3) +- 0.03: |1 - s e^{i theta}| ~ 0.38, so the
+    re-projection error of a correspondence d patches away from the proposing one is ~ 5.4 d px -- the integer
+    lattice distances next to the 14-px boundary are sqrt(5) (12.0 px, inlier) and sqrt(8) (15.2 px, outlier)."""
+    import torch
+
+    sd = module.state_dict()
+    with torch.no_grad():
+        sd["backbone.layer4_outconv.weight"].mul_(1.0 / 32.0)
+        sd["regressor.scale_predictor.4.weight"].mul_(1.0 / 32.0)
+        sd["regressor.scale_predictor.4.bias"].fill_(1.2)
+        sd["regressor.inplane_predictor.4.weight"].mul_(1.0 / 32.0)
+        sd["regressor.inplane_predictor.4.bias"].copy_(torch.tensor([1.886, 0.3046]))
+    module.load_state_dict(sd)
+    return module
+
+
 def many_to_one_case(seed, R):
     """RANSAC stress case: neighbouring query patches matched to the SAME template patch, so many
     errors are exactly 14 px in exact arithmetic and the `<= 14` test is decided by rounding (see

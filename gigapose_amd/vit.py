@@ -132,18 +132,43 @@ class Dinov2ViT(nn.Module):
         m.load_state_dict(out)
         return m.eval()
 
+    # How a 1 + M*M position table (hub checkpoints: M = 37, trained at 518 x 518) becomes the 1 + 16*16 one used at
+    # 224 x 224.  The hub model does this at run time in `interpolate_pos_encoding` (facebookresearch/dinov2,
+    # vision_transformer.py; reached from the reference through `forward_features`, ae_net.py:44-47): bicubic
+    # F.interpolate of the (M, M) grid with scale_factor = (16 + interpolate_offset) / M and the released models'
+    # interpolate_offset = 0.1, interpolate_antialias = False -- the OUTPUT size is floor(M * scale) = 16 but the
+    # sampling positions follow 1/scale_factor = M / 16.1, not M / 16 (~0.2 source pixels apart at the grid edge).
+    # interpolate_offset = 0.0 is the hub code's other branch (plain `size=(16, 16)`).  Done once on the host at load
+    # time: weight preparation, not hot-path arithmetic.  Restated and tested in oracle/vit_numpy.py / tests/test_oracle_vit.py.
+    interpolate_offset = 0.1
+    interpolate_antialias = False
+
+    def resample_pos_embed(self, pe):
+        """(1, 1 + M*M, C) -> (1, 257, C), as the hub model's interpolate_pos_encoding does for a 224 x 224 input."""
+        pe = pe.float()
+        n = int(round(math.sqrt(pe.shape[1] - 1)))
+        if n * n != pe.shape[1] - 1:
+            raise ValueError(f"pos_embed with {pe.shape[1]} entries is not 1 + a square grid")
+        grid = pe[:, 1:].reshape(1, n, n, -1).permute(0, 3, 1, 2)
+        if self.interpolate_offset:
+            sf = float(16 + self.interpolate_offset) / n
+            grid = nn.functional.interpolate(grid, scale_factor=(sf, sf), mode="bicubic", antialias=self.interpolate_antialias)
+        else:
+            grid = nn.functional.interpolate(grid, size=(16, 16), mode="bicubic", antialias=self.interpolate_antialias)
+        if tuple(grid.shape[-2:]) != (16, 16):
+            raise ValueError(f"pos_embed resampling produced {tuple(grid.shape[-2:])}, expected (16, 16)")
+        return torch.cat([pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, 256, -1)], dim=1)
+
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
-        """Checkpoints trained at 518x518 carry a 1+37*37 position table; resample it once on the
-        host to the 16x16 grid used at 224x224 (DINOv2 does this bicubically at run time)."""
         key = prefix + "pos_embed"
         if key in state_dict and state_dict[key].shape[1] != self.pos_embed.shape[1]:
-            pe = state_dict[key].float()
-            n = int(round(math.sqrt(pe.shape[1] - 1)))
-            grid = pe[:, 1:].reshape(1, n, n, -1).permute(0, 3, 1, 2)
-            grid = nn.functional.interpolate(grid, size=(16, 16), mode="bicubic", align_corners=False)
-            state_dict[key] = torch.cat([pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, 256, -1)], dim=1)
+            state_dict[key] = self.resample_pos_embed(state_dict[key])
         self._packed = None
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def _apply(self, fn, *a, **k):   # .to() / .float(): packed weight copies follow the parameters
+        self._packed = None
+        return super()._apply(fn, *a, **k)
 
     # ---------------------------------------------------------------- weight packing
     def invalidate(self):

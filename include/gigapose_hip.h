@@ -23,6 +23,17 @@ extern "C" {
 int gp_abi_version(void);
 const char* gp_last_error(void);
 
+/* Guard rails: conditions that the reference turns into Python exceptions (IndexError at `ae_features[label - 1]`,
+ * gigaPose.py:520) or that have no counterpart there (a lost stream-K accumulator hand-over; an activation outside the
+ * range of the split-f16 planes, |x| >= 8190 or non-finite) are OR-ed by the kernels into ONE device int32 owned by the
+ * caller.  The host reads it at its next synchronisation point (gigapose_amd/_lib.py: check_status) and raises.
+ * device_word == NULL switches the reporting off.  Bits: */
+#define GP_STATUS_HANDOFF_SPLIT 1 /* split GEMM: a hand-over timed out, the tile it fed is garbage */
+#define GP_STATUS_HANDOFF_CHAIN 2 /* f32 (chain) GEMM: same */
+#define GP_STATUS_SPLIT_RANGE 4   /* split numerics: plane value out of range / NaN (use numerics "chain" or GIGAPOSE_SPLIT_GEMM=128) */
+#define GP_STATUS_LABEL_RANGE 8   /* label >= O or template id >= N (clamped to 0 so nothing reads out of bounds) */
+int gp_set_status_buffer(int* device_word);
+
 /* Optional timing of kernel families with HIP events on the launch stream (used by bench.py for the
  * roofline figure; not part of the reference interface).  gp_prof_begin() starts recording;
  * gp_prof_end() stops, synchronises and returns per-kind totals: ms[k], work[k] (flops, or bytes for
@@ -202,6 +213,12 @@ int gp_gemm_planes256(const void* a_hi, const void* a_lo, const void* b_hi, cons
  * bit-identical to the f32-activation kernels; gp_vit_set_planes(0) switches this off).
  * split == NULL: identical to gp_vit_forward.  (Patch embedding, LayerNorm statistics, attention and the feature
  * epilogue are the same f32 arithmetic in both modes.) */
+int gp_gemm_planes256_set_dp(int mode); /* bit 0 (default 1): data-parallel rounds before the stream-K remainder; bit 1: TEST hook,
+                                           head fragments are never published (every waiter times out -> GP_STATUS_HANDOFF_SPLIT) */
+/* probe build of gp_gemm_planes256 (epilogues 0, 3, 6, 7) with per-slot time stamps, see gp_split256.hip */
+int gp_gemm_planes256_trace(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
+                            void* out_lo, int ldo, int I, int J, int K, int epilogue, const float* bias, const float* scale,
+                            const float* residual, int ldr, float out_scale, float* scratch, unsigned long long* trace, void* stream);
 void gp_vit_set_planes(int mode); /* 2 (default) = planes + attention in split numerics, 1 = planes + f32 attention, 0 = off */
 
 /* softmax(q k^T / 8) v per (image, head) in split numerics (attention_split_kernel): qkv_hi/lo = f16 planes [Mpad][3 dim]

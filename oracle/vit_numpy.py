@@ -69,3 +69,60 @@ def patch_features(sd, images, depth, heads, normalize=True, stop_after_layers=N
         from . import cpu
         f = cpu.l2norm_cp(f)
     return f.reshape(B, C, 16, 16)
+
+
+# ---- position-table resampling: facebookresearch/dinov2 vision_transformer.py `interpolate_pos_encoding` ------------
+# (un-vendored; the reference reaches it through forward_features, ae_net.py:44-47).  Restated from the published
+# code: F.interpolate(grid (1,C,M,M), mode="bicubic", antialias=<interpolate_antialias>, scale_factor=(16+offset)/M)
+# for interpolate_offset != 0 (released models: 0.1), or size=(16,16) for offset 0.  ATen semantics restated:
+#   * output size = floor(M * scale_factor); the coordinate scale is 1/scale_factor when a scale factor is given
+#     (recompute_scale_factor unset), M/out otherwise; align_corners=False: src = scale * (dst + 0.5) - 0.5;
+#   * bicubic (UpSampleBicubic2d): Keys kernel A = -0.75 on taps floor(src)-1..+2, indices clamped to the border;
+#   * antialias (UpSampleKernel.cpp, _compute_indices_min_size_weights_aa): Keys kernel a = -0.5 stretched by the scale
+#     over support 2*scale around center = scale * (dst + 0.5), weights normalised to sum 1.
+def _cubic(x, a):
+    x = abs(x)
+    if x <= 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0
+    if x < 2.0:
+        return (((x - 5.0) * x + 8.0) * x - 4.0) * a
+    return 0.0
+
+
+def _resample_matrix(n_in, n_out, scale, antialias):
+    """(n_out, n_in) float64 matrix of one separable pass."""
+    W = np.zeros((n_out, n_in))
+    for i in range(n_out):
+        if not antialias:
+            # ATen evaluates the source coordinate in f32 (area_pixel_compute_source_index<float>, scale =
+            # float(1 / scale_factor)): with 37 / 16.1 that rounding moves values by ~1e-5, so it is restated too
+            src = np.float32(np.float32(scale) * np.float32(i + 0.5) - np.float32(0.5))
+            i0 = math.floor(src)
+            t = float(np.float32(src - np.float32(i0)))
+            for k in range(-1, 3):
+                W[i, min(max(i0 + k, 0), n_in - 1)] += _cubic(k - t, -0.75)
+        else:
+            support = 2.0 * scale if scale >= 1.0 else 2.0
+            inv = 1.0 / scale if scale >= 1.0 else 1.0
+            center = scale * (i + 0.5)
+            lo = max(int(center - support + 0.5), 0)
+            hi = min(int(center + support + 0.5), n_in)
+            w = np.array([_cubic((j - center + 0.5) * inv, -0.5) for j in range(lo, hi)])
+            W[i, lo:hi] = w / w.sum()
+    return W
+
+
+def interpolate_pos_encoding(pos_embed, interpolate_offset=0.1, antialias=False, n_out=16):
+    """pos_embed (1, 1 + M*M, C) -> (1, 1 + n_out*n_out, C), float64 arithmetic, returned as f32."""
+    pe = np.asarray(pos_embed, np.float64)
+    m = int(round(math.sqrt(pe.shape[1] - 1)))
+    grid = pe[0, 1:].reshape(m, m, -1)
+    if interpolate_offset:
+        sf = float(n_out + interpolate_offset) / m
+        assert math.floor(m * sf) == n_out
+        scale = 1.0 / sf
+    else:
+        scale = m / n_out
+    W = _resample_matrix(m, n_out, scale, antialias)
+    out = np.einsum("ia,jb,abc->ijc", W, W, grid)
+    return np.concatenate([pe[:, :1], out.reshape(1, n_out * n_out, -1)], axis=1).astype(np.float32)

@@ -1,0 +1,123 @@
+"""GPU guard rails: nothing on the product path may turn into silent garbage.
+
+  * split numerics: an activation outside the f16 planes' range (|x| >= 8190) or a non-finite one raises at the next
+    host synchronisation; large-but-legal activations (a token x 500) stay accurate;
+  * a LOST stream-K accumulator hand-over (forced through the test hook) raises instead of returning a wrong tile;
+  * labels outside the onboarded bank raise (host labels: IndexError as in the reference, gigaPose.py:520; device labels:
+    the kernels clamp + flag, no out-of-bounds read).
+"""
+import numpy as np
+import pytest
+import torch
+
+from gigapose_amd import _lib, factory
+from gigapose_amd import synthetic as syn
+from gigapose_amd.vit import Dinov2ViT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def small_vitl(seed=7, depth=2):
+    """ViT-L width, two blocks: at B = 64 every GEMM takes the plane kernels (the benchmark path), in seconds."""
+    return syn.fill_state_dict(Dinov2ViT(1024, depth, 16), seed).eval().to(DEV)
+
+
+def images(B=64, seed=3):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal((B, 3, 224, 224)).astype(np.float32)).to(DEV)
+
+
+@pytest.fixture(autouse=True)
+def clean_status():
+    _lib.status_word(DEV).zero_()
+    yield
+    _lib.lib().gp_gemm_planes256_set_dp(1)
+    torch.cuda.synchronize()
+    _lib.status_word(DEV).zero_()
+
+
+def test_one_channel_1e4_trips_the_range_guard():
+    vit = small_vitl().set_numerics("split")
+    x = images()
+    vit.patch_features(x)
+    torch.cuda.synchronize()
+    _lib.check_status()                                   # clean weights: nothing flagged
+    with torch.no_grad():
+        vit.blocks[0].mlp.fc1.bias[7] = 1.0e4             # GELU(1e4) = 1e4 -> 8e4 in the x 8 planes: beyond f16
+    vit.invalidate()
+    vit.patch_features(x)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.GigaPoseHipError, match="range of the f16 planes"):
+        _lib.check_status()
+    _lib.check_status()                                   # reading clears the word
+    # the chain mode has no such limit: same weights, finite features, no flag
+    vit.set_numerics("chain")
+    f = vit.patch_features(x)
+    torch.cuda.synchronize()
+    _lib.check_status()
+    assert torch.isfinite(f).all()
+
+
+def test_nan_input_trips_the_range_guard():
+    vit = small_vitl().set_numerics("split")
+    x = images()
+    x[5, 1, 100, 100] = float("nan")
+    vit.patch_features(x)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.GigaPoseHipError, match="not finite"):
+        _lib.check_status()
+
+
+def test_token_x500_stays_legal_and_accurate():
+    """A massive-but-representable activation (one crop scaled by 500: patch-embedding outputs and the residual stream
+    of ALL its tokens grow 500-fold) is inside the planes' range; split must still agree with chain."""
+    x = images()
+    x[9] *= 500.0
+    vit = small_vitl()
+    fc = vit.set_numerics("chain").patch_features(x).clone()
+    fs = vit.set_numerics("split").patch_features(x)
+    torch.cuda.synchronize()
+    _lib.check_status()
+    err = (fs - fc).abs().max().item()
+    print("unit-norm features, crop 9 scaled x 500: max |split - chain| = %.2e (crop 9 alone %.2e)" % (err, (fs[9] - fc[9]).abs().max().item()))
+    assert err < 2e-6
+
+
+def test_lost_handoff_raises():
+    vit = small_vitl(depth=1).set_numerics("split")
+    x = images()
+    ref = vit.patch_features(x).clone()
+    torch.cuda.synchronize()
+    _lib.check_status()
+    _lib.lib().gp_gemm_planes256_set_dp(1 | 2)            # test hook: head fragments are never published
+    vit.patch_features(x)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.GigaPoseHipError, match="hand-over"):
+        _lib.check_status()
+    _lib.lib().gp_gemm_planes256_set_dp(1)
+    again = vit.patch_features(x)
+    torch.cuda.synchronize()
+    _lib.check_status()
+    assert torch.equal(again, ref)                        # and the next forward is clean again
+
+
+def test_labels_outside_the_bank():
+    model = factory.build_model("dinov2_vits14", k=3, device=DEV, seed=2)
+    tset = factory.TemplateSet(2, 5, seed=70)
+    model.template_datasets = {"syn": tset}
+    model.set_template_data("syn")
+    q = tset.crops(71, 4, DEV)
+    good = model.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
+    torch.cuda.synchronize()
+    _lib.check_status()
+    for bad in (0, 3):
+        labels = q["labels"].clone()
+        labels[1] = bad
+        with pytest.raises(IndexError):                   # host labels: checked before anything is launched
+            model.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], labels, "syn")
+        out = model.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], labels.to(DEV), "syn")  # device labels
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.GigaPoseHipError, match="outside the onboarded bank"):
+            _lib.check_status()
+        keep = [0, 2, 3]                                  # the other detections are untouched
+        assert torch.equal(out.id_src[keep], good.id_src[keep]) and torch.equal(out.pred_poses[keep], good.pred_poses[keep])

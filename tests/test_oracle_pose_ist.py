@@ -14,11 +14,13 @@ IST_CFG = dict(n_heads=0, input_dim=3, input_size=256, initial_dim=128, block_di
                descriptor_size=256)
 
 
-def build_ist(seed):
+def build_ist(seed, conditioned=False):
+    """conditioned: synthetic.condition_ist's rescaling (what the e2e goldens use, oracle/make_goldens.py: build_ref_ist)."""
     from gigapose_amd.ist_net import ISTNet, Regressor, ResNet
 
     net = ISTNet("resnet", ResNet(dict(IST_CFG)), Regressor(256, 256, True, True), 64).eval()
-    return syn.fill_state_dict(net, seed)
+    syn.fill_state_dict(net, seed)
+    return syn.condition_ist(net) if conditioned else net
 
 
 def mlp_weights(net):

@@ -1,0 +1,62 @@
+"""GPU probe: per-slot timeline of the plane GEMM (gp_gemm_planes256_trace) for the five ViT-L GEMM shapes at B = 64:
+where a slot's time goes -- accumulator hand-over waits, k loop, epilogue / publish -- next to the event-timed launch."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from gigapose_amd import _lib
+dev = "cuda"
+lib = _lib.lib()
+lib.gp_gemm_split256_workspace_bytes.restype = ctypes.c_size_t
+NB = lib.gp_gemm_split256_workspace_bytes()
+ws = torch.zeros(NB // 4, device=dev)
+def planes(W, scale):
+    hi = torch.empty(W.shape, dtype=torch.float16, device=dev); lo = torch.empty_like(hi)
+    _lib.call("gp_split_planes", _lib.ptr(W), ctypes.c_size_t(W.numel()), _lib.f(scale), _lib.ptr(hi), _lib.ptr(lo), _lib.stream_ptr())
+    return hi, lo
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+torch.manual_seed(0)
+M = int(os.environ.get("MTOK", 16640))
+for (nw, K, name, epi) in [(2048, 1024, "qk", 7), (1024, 1024, "v", 7), (1024, 1024, "proj", 3), (4096, 1024, "fc1", 6), (1024, 4096, "fc2", 3)]:
+    W = torch.randn(nw, K, device=dev) * 0.03
+    Xt = torch.randn(M, K, device=dev) * 1.5
+    whi, wlo = planes(W, 64.0); xhi, xlo = planes(Xt, 8.0)
+    I, J = nw, M
+    bias = torch.randn(I, device=dev); sc = torch.randn(I, device=dev)
+    D = torch.randn(I, J, device=dev)
+    ohi = torch.zeros(M, nw, dtype=torch.float16, device=dev); olo = torch.zeros_like(ohi)
+    trace = torch.zeros(256 * 32, dtype=torch.int64, device=dev)
+    args = (_lib.ptr(whi), _lib.ptr(wlo), _lib.ptr(xhi), _lib.ptr(xlo), _lib.ptr(D), _lib.i(J), _lib.ptr(ohi), _lib.ptr(olo), _lib.i(nw),
+            _lib.i(I), _lib.i(J), _lib.i(K), _lib.i(epi), _lib.ptr(bias), _lib.ptr(sc), _lib.ptr(D), _lib.i(J), _lib.f(1.0 / 512.0), _lib.ptr(ws))
+    def plain(): _lib.call("gp_gemm_planes256", *args, ctypes.c_size_t(NB), _lib.stream_ptr())
+    def traced(): _lib.call("gp_gemm_planes256_trace", *args, _lib.ptr(trace), _lib.stream_ptr())
+    t_plain = timeit(plain)
+    for _ in range(20): plain()          # sustained clocks
+    traced(); torch.cuda.synchronize()
+    t = trace.cpu().numpy().reshape(256, 32).astype(np.int64)
+    start, nseg = t[:, 0], t[:, 1]
+    t0 = start.min()
+    ends, kl, ep, wait, steps, pub = [], [], [], [], [], []
+    for p in range(256):
+        prev = start[p]
+        for s in range(min(int(nseg[p]), 7)):
+            kind, ns = int(t[p, 2 + 4 * s] >> 32), int(t[p, 2 + 4 * s] & 0xffffffff)
+            a, b, c = t[p, 3 + 4 * s], t[p, 4 + 4 * s], t[p, 5 + 4 * s]
+            wait.append((a - prev) / 100.0); kl.append((b - a) / 100.0); steps.append(ns)
+            (pub if kind == 1 else ep).append((c - b) / 100.0)
+            prev = c
+        ends.append((prev - t0) / 100.0)
+    kl, steps = np.array(kl), np.array(steps)
+    fl = 2.0 * I * J * K
+    print(f"{name:5s} I={I} J={J} K={K} epi {epi}: event-timed {t_plain:6.1f} us = {fl / t_plain / 1e6:5.0f} TF-eq | traced slots: start spread "
+          f"{(start.max() - t0) / 100.0:5.1f} us, lifetime min/mean/max {min(ends):6.1f}/{np.mean(ends):6.1f}/{max(ends):6.1f} us | per slot: segments "
+          f"{nseg.mean():.2f}, k loop {kl.sum() / 256:6.1f} us ({kl.sum() / steps.sum():.3f} us/step, {steps.sum() / 256:.1f} steps), "
+          f"epilogues {np.sum(ep) / 256:5.1f} us ({np.mean(ep) if ep else 0:5.1f} each x {len(ep) / 256:.2f}), publishes {np.sum(pub) / 256:5.1f} us "
+          f"({np.mean(pub) if pub else 0:5.1f} each), waits + prologue {np.sum(wait) / 256:5.1f} us (max single {np.max(wait):5.1f})", flush=True)

@@ -23,6 +23,7 @@ from oracle import cpu as oracle
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 _cases = {}
+_oracle_tiles = {}
 
 
 def big_case(golden_dir, name):
@@ -70,9 +71,11 @@ def test_matcher_config2_all_tiles_vs_oracle(golden_dir, numerics):
     _, (idx, sc, ma, avg) = run_bank(case, int(g["k"]), numerics)
     B, C = case["tar_feat"].shape[:2]
     O, N = case["src_feats"].shape[:2]
-    qn = oracle.l2norm_cp(case["tar_feat"].reshape(B, C, 256))
-    bn = oracle.l2norm_cp(case["src_feats"].reshape(O, N, C, 256))
-    oi, osc, oma, oavg = oracle.match(qn, bn, oracle.patch_mask(case["tar_mask"]), oracle.patch_mask(case["src_masks"]), case["labels"])
+    if "cfg2" not in _oracle_tiles:   # ~1 min of host cores: once for both numerics
+        qn = oracle.l2norm_cp(case["tar_feat"].reshape(B, C, 256))
+        bn = oracle.l2norm_cp(case["src_feats"].reshape(O, N, C, 256))
+        _oracle_tiles["cfg2"] = oracle.match(qn, bn, oracle.patch_mask(case["tar_mask"]), oracle.patch_mask(case["src_masks"]), case["labels"])
+    oi, osc, oma, oavg = _oracle_tiles["cfg2"]
     n_idx, n_mask = int((idx != oi).sum()), int((ma != oma).sum())
     print(f"config 2, all {B * N} tiles [{numerics}] vs oracle: idx differ {n_idx}/{oi.size}, mask bits differ {n_mask}/{oma.size}; "
           f"score max err {np.abs(sc - osc).max():.2e}, sim_avg max err {np.abs(avg - oavg).max():.2e}")

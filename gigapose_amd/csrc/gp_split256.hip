@@ -363,6 +363,7 @@ struct ArgsP {
     int dp;
     unsigned long long* trace;  // TIMING builds: per-block segment time stamps (100 MHz ticks), else null
     int* status;                // guard rails (gp_common.h)
+    int strip_j0, strip_fj;     // ragged J: rows [strip_j0, strip_j0 + 32 strip_fj) of B are not tiled, see strip_phase
 };
 
 __device__ __forceinline__ float lane_bcast(float v, int lane)  // value held by `lane` (compile-time constant) -> SGPR
@@ -478,6 +479,114 @@ __device__ __forceinline__ void epilogue_planes_lds(const ArgsP& a, f32x16 (&acc
         }
     }
     if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE);
+}
+
+// ---- The ragged edge of J.  257 tokens per crop: J = 257 B is never a multiple of 256, and at B = 64 the 65th column of
+// tiles (64 valid rows of 256) turned a 256-tile problem -- one whole tile per CU, no hand-over at all -- into 260 tiles
+// on 256 slots: half the chip split tiles, published and re-read 256 KB accumulator fragments and finished 40 % later
+// than the other half (per-slot time stamps, profiles/r02_planes_timeline.txt).  Now the tiles cover
+// floor(J_valid / 256) * 256 rows and the remaining rows (< 256) are computed here as 32 x 32 fragments: the eight
+// waves of a slot split K of ONE fragment (operands straight from global memory into the MFMA operand registers, up
+// to 32 loads in flight per wave -- a single wave walking all of K needs K / 64 dependent memory round trips: 21 us at
+// K = 1024, 78 us at K = 4096, measured), the partial accumulators are summed in wave order through LDS (fixed order:
+// deterministic) and wave 0 applies the epilogue.  Same three products per k16 block; only the summation order over K
+// differs from the tile path (strip outputs agree with tiled ones to f32 round-off, not bit for bit).
+template <int EPI>
+__device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ red, int slot, int nslots, int tid)
+{
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5, wave = tid >> 6;
+    const int nfi = a.tiles_i * (TB / 32), nfrag = nfi * a.strip_fj;
+    const int nkb = a.K >> 4;                                        // k16 blocks
+    const int kb0 = nkb * wave / 8, kb1 = nkb * (wave + 1) / 8;      // this wave's share of K
+    for (int f = slot; f < nfrag; f += nslots) {                     // uniform over the workgroup (barriers inside)
+        const int i0 = (f % nfi) * 32, j0 = a.strip_j0 + (f / nfi) * 32;
+        const _Float16* pah = a.ahi + (size_t)(i0 + l31) * a.K + 8 * half;
+        const _Float16* pal = a.alo + (size_t)(i0 + l31) * a.K + 8 * half;
+        const _Float16* pbh = a.bhi + (size_t)(j0 + l31) * a.K + 8 * half;
+        const _Float16* pbl = a.blo + (size_t)(j0 + l31) * a.K + 8 * half;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        int kb = kb0;
+        for (; kb + 8 <= kb1; kb += 8) {  // 32 unconditional 16-byte loads in flight, then 24 MFMAs (a guard per load would make
+            g16x8 ah[8], al[8], bh[8], bl[8];  // hipcc branch around each one and wait for it: 32 dependent round trips)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ah[u] = *reinterpret_cast<const g16x8*>(pah + 16 * (kb + u));
+                al[u] = *reinterpret_cast<const g16x8*>(pal + 16 * (kb + u));
+                bh[u] = *reinterpret_cast<const g16x8*>(pbh + 16 * (kb + u));
+                bl[u] = *reinterpret_cast<const g16x8*>(pbl + 16 * (kb + u));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], bh[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], bl[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[u], bh[u], acc, 0, 0, 0);
+            }
+        }
+        for (; kb < kb1; ++kb) {  // K / 16 not a multiple of 64: the odd blocks one at a time
+            const g16x8 ah = *reinterpret_cast<const g16x8*>(pah + 16 * kb), al = *reinterpret_cast<const g16x8*>(pal + 16 * kb);
+            const g16x8 bh = *reinterpret_cast<const g16x8*>(pbh + 16 * kb), bl = *reinterpret_cast<const g16x8*>(pbl + 16 * kb);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            f32x4 v;
+            v[0] = acc[4 * r4 + 0]; v[1] = acc[4 * r4 + 1]; v[2] = acc[4 * r4 + 2]; v[3] = acc[4 * r4 + 3];
+            *reinterpret_cast<f32x4*>(red + ((wave * 4 + r4) * 64 + lane) * 4) = v;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(red + (r4 * 64 + lane) * 4);
+#pragma unroll
+                for (int w = 1; w < 8; ++w) {
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(red + ((w * 4 + r4) * 64 + lane) * 4);
+                    t[0] = t[0] + u[0]; t[1] = t[1] + u[1]; t[2] = t[2] + u[2]; t[3] = t[3] + u[3];
+                }
+                acc[4 * r4 + 0] = t[0]; acc[4 * r4 + 1] = t[1]; acc[4 * r4 + 2] = t[2]; acc[4 * r4 + 3] = t[3];
+            }
+            // per-element arithmetic of the tile epilogues, direct stores (a few KB per launch)
+            const int j = j0 + l31;
+            int bad = 0;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int i = i0 + frag_row(4 * r4, lane);
+                if (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES) {
+                    g16x4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = acc[4 * r4 + e] * a.out_scale + a.bias[i + e];
+                        const float v = (EPI == PEPI_GELU_PLANES ? gelu_x(x) : x) * kActScale;
+                        const _Float16 hh = (_Float16)v;
+                        oh[e] = hh;
+                        ol[e] = (_Float16)(v - (float)hh);
+                        bad |= !(fabsf(v) <= kSplitPlaneLimit);
+                    }
+                    const size_t o = (size_t)(unsigned)j * (unsigned)a.ldo + (unsigned)i;
+                    *reinterpret_cast<g16x4*>(a.ohi + o) = oh;
+                    *reinterpret_cast<g16x4*>(a.olo + o) = ol;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[4 * r4 + e] * a.out_scale;
+                        if (EPI == XEPI_BIAS_I || EPI == XEPI_BIAS_I_GELU || EPI == XEPI_BIAS_I_SCALE_RES || EPI == XEPI_BIAS_I_RELU)
+                            v = v + a.bias[i + e];
+                        if (EPI == XEPI_BIAS_J) v = v + a.bias[j];
+                        if (EPI == XEPI_BIAS_I_GELU) v = gelu_x(v);
+                        if (EPI == XEPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
+                        if (EPI == XEPI_BIAS_I_SCALE_RES) v = a.res[(unsigned)(i + e) * (unsigned)a.ldr + (unsigned)j] + a.scale[i + e] * v;
+                        a.D[(unsigned)(i + e) * (unsigned)a.ldd + (unsigned)j] = v;
+                    }
+                }
+            }
+            if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE);
+        }
+        __syncthreads();  // `red` is rewritten by the next fragment
+    }
 }
 
 template <int EPI, bool TIMING = false>
@@ -711,6 +820,8 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
         }
         if (TIMING && a.trace && tid == 0 && seg < 7) a.trace[(size_t)p * 32 + 5 + 4 * seg] = wall_clock64();
     }
+    if (a.strip_fj > 0) strip_phase<EPI>(a, reinterpret_cast<float*>(lds), p, gridDim.x, threadIdx.x);
+    if (TIMING && a.trace && tid == 0) a.trace[(size_t)p * 32 + 31] = wall_clock64();
     if (TIMING && blockIdx.x == 100 && tid == 0) {
         for (int i = 0; i < 6; ++i) g_t256[i] = tc[i];
         g_t256[6] = __builtin_readcyclecounter() - k_c0;  // whole kernel, shader cycles
@@ -778,11 +889,28 @@ int gp_gemm_split256_launch(const float* act, int ld_act, const void* whi, const
 static int g_planes_dp = 1;  // 1: data-parallel rounds before the stream-K remainder (0: everything stream-K; A/B hook)
 
 // internal entry (gp_vit.hip): D[i][j] = epi( out_scale * sum_k A[i][k] B[j][k] ), A / B = pre-split planes (see above)
-int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
-                             void* olo, int ldo, int I, int J, int K, int epilogue, const float* bias, const float* scale,
-                             const float* res, int ldr, float out_scale, float* scratch, hipStream_t st)
+// J_valid <= J: rows of B that carry data (J itself stays a multiple of 256: the buffers are padded).  Tiles cover
+// floor(J_valid / 256) * 256 rows, strip_phase the rest (rows beyond round_up(J_valid, 32) are neither read nor written).
+static void planes_ragged(int J, int J_valid, int& J_main, int& strip_fj)
 {
-    GP_REQUIRE(gp_gemm_split256_usable(I, J, K), "gp_gemm_planes256: I=%d, J=%d must be multiples of 256 with >= 256 tiles, K=%d of 32", I, J, K);
+    J_main = (J_valid >= J || J_valid <= 0) ? J : (J_valid / TB) * TB;
+    strip_fj = (J_main == J) ? 0 : (J_valid - J_main + 31) / 32;
+}
+bool gp_gemm_planes256_usable(int I, int J, int J_valid, int K)
+{
+    int J_main, fj;
+    planes_ragged(J, J_valid, J_main, fj);
+    return J % TB == 0 && J_valid <= J && gp_gemm_split256_usable(I, J_main, K);
+}
+
+int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
+                             void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
+                             const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace)
+{
+    GP_REQUIRE(gp_gemm_planes256_usable(I, J, J_valid, K),
+               "gp_gemm_planes256: I=%d, J=%d must be multiples of 256 with >= 256 tiles below J_valid=%d, K=%d of 32", I, J, J_valid, K);
+    int J_main, strip_fj;
+    planes_ragged(J, J_valid, J_main, strip_fj);
     GP_REQUIRE(ahi && alo && bhi && blo && scratch && ((uintptr_t)ahi % 16 == 0) && ((uintptr_t)alo % 16 == 0) &&
                    ((uintptr_t)bhi % 16 == 0) && ((uintptr_t)blo % 16 == 0) && ((uintptr_t)scratch % 16 == 0),
                "gp_gemm_planes256: null / misaligned operand");
@@ -796,11 +924,23 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
     if (epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES)
         GP_REQUIRE(ldo % 8 == 0 && ((uintptr_t)ohi % 16 == 0) && ((uintptr_t)olo % 16 == 0), "gp_gemm_planes256: plane output rows must be 16-byte aligned");
     ArgsP a{(const _Float16*)ahi, (const _Float16*)alo, (const _Float16*)bhi, (const _Float16*)blo, D, ldd, (_Float16*)ohi, (_Float16*)olo, ldo,
-            K, bias, scale, res, ldr, I / TB, J / TB, 4, reinterpret_cast<int*>(scratch),
-            reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, out_scale, g_planes_dp, nullptr, gp_status_buffer()};
+            K, bias, scale, res, ldr, I / TB, J_main / TB, 4, reinterpret_cast<int*>(scratch),
+            reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, out_scale, g_planes_dp, trace, gp_status_buffer(),
+            J_main, strip_fj};
     g_epoch256 = (g_epoch256 + 1) & 0x3fffffff;
     a.epoch = (int)(0x40000000u | g_epoch256);
-    GpProfScope prof(GP_PROF_GEMM_SPLIT, 2.0 * I * J * K, st);
+    GpProfScope prof(GP_PROF_GEMM_SPLIT, 2.0 * I * (J_valid > 0 && J_valid < J ? J_valid : J) * K, st);
+    if (trace) {  // probe build with per-slot time stamps
+        switch (epilogue) {
+            case XEPI_NONE: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_NONE, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case XEPI_BIAS_I_SCALE_RES: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case PEPI_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_GELU_PLANES, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case PEPI_BIAS_I_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            default: GP_REQUIRE(false, "gp_gemm_planes256_trace: epilogue %d has no traced build", epilogue);
+        }
+        GP_CHECK_LAUNCH("gp_gemm_planes256_trace");
+        return GP_OK;
+    }
     switch (epilogue) {
         case XEPI_NONE: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_NONE>), dim3(kSlots), dim3(TNT), 0, st, a); break;
         case XEPI_BIAS_I: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I>), dim3(kSlots), dim3(TNT), 0, st, a); break;
@@ -817,6 +957,10 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
 }
 
 extern "C" {
+
+int gp_gemm_planes256_ragged(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
+                             void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
+                             const float* residual, int ldr, float out_scale, float* scratch, size_t scratch_bytes, void* stream);
 
 size_t gp_gemm_split256_workspace_bytes(void) { return gp_gemm_split256_scratch_bytes(); }
 
@@ -870,10 +1014,18 @@ int gp_gemm_planes256(const void* a_hi, const void* a_lo, const void* b_hi, cons
                       void* out_lo, int ldo, int I, int J, int K, int epilogue, const float* bias, const float* scale,
                       const float* residual, int ldr, float out_scale, float* scratch, size_t scratch_bytes, void* stream)
 {
+    return gp_gemm_planes256_ragged(a_hi, a_lo, b_hi, b_lo, D, ldd, out_hi, out_lo, ldo, I, J, J, K, epilogue, bias, scale, residual, ldr,
+                                    out_scale, scratch, scratch_bytes, stream);
+}
+
+int gp_gemm_planes256_ragged(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
+                             void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
+                             const float* residual, int ldr, float out_scale, float* scratch, size_t scratch_bytes, void* stream)
+{
     GP_REQUIRE(scratch && scratch_bytes >= gp_gemm_split256_scratch_bytes(), "gp_gemm_planes256: scratch too small");
     if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
-    return gp_gemm_planes256_launch(a_hi, a_lo, b_hi, b_lo, D, ldd, out_hi, out_lo, ldo, I, J, K, epilogue, bias, scale, residual, ldr,
-                                    out_scale, scratch, (hipStream_t)stream);
+    return gp_gemm_planes256_launch(a_hi, a_lo, b_hi, b_lo, D, ldd, out_hi, out_lo, ldo, I, J, J_valid, K, epilogue, bias, scale, residual, ldr,
+                                    out_scale, scratch, (hipStream_t)stream, nullptr);
 }
 
 /* probe: no-epilogue launch with per-phase cycle counters of wave 0 of block 100; out6 (host, 8 entries): matrix phase,
@@ -898,26 +1050,13 @@ int gp_gemm_planes256_timing(const void* a_hi, const void* a_lo, const void* b_h
  * 256 x 32 u64) receives per slot: [0] start, [1] segments, then per segment (first 7): kind << 32 | k-steps, start of its
  * k loop (after the accumulator hand-over wait, if any), end of the k loop, end of its epilogue / publish -- 100 MHz ticks */
 int gp_gemm_planes256_trace(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
-                            void* out_lo, int ldo, int I, int J, int K, int epilogue, const float* bias, const float* scale,
+                            void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
                             const float* residual, int ldr, float out_scale, float* scratch, unsigned long long* trace, void* stream)
 {
-    GP_REQUIRE(gp_gemm_split256_usable(I, J, K) && trace && scratch, "gp_gemm_planes256_trace: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(scratch, 0, kHeaderBytes, st) != hipSuccess) return GP_ELAUNCH;
-    ArgsP a{(const _Float16*)a_hi, (const _Float16*)a_lo, (const _Float16*)b_hi, (const _Float16*)b_lo, D, ldd, (_Float16*)out_hi,
-            (_Float16*)out_lo, ldo, K, bias, scale, residual, ldr, I / TB, J / TB, 4, reinterpret_cast<int*>(scratch),
-            reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, out_scale, g_planes_dp, trace, gp_status_buffer()};
-    g_epoch256 = (g_epoch256 + 1) & 0x3fffffff;
-    a.epoch = (int)(0x40000000u | g_epoch256);
-    switch (epilogue) {
-        case XEPI_NONE: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_NONE, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-        case XEPI_BIAS_I_SCALE_RES: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-        case PEPI_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_GELU_PLANES, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-        case PEPI_BIAS_I_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-        default: GP_REQUIRE(false, "gp_gemm_planes256_trace: epilogue %d has no traced build", epilogue);
-    }
-    GP_CHECK_LAUNCH("gp_gemm_planes256_trace");
-    return GP_OK;
+    GP_REQUIRE(trace && scratch, "gp_gemm_planes256_trace: bad arguments");
+    if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
+    return gp_gemm_planes256_launch(a_hi, a_lo, b_hi, b_lo, D, ldd, out_hi, out_lo, ldo, I, J, J_valid, K, epilogue, bias, scale, residual, ldr,
+                                    out_scale, scratch, (hipStream_t)stream, trace);
 }
 
 int gp_gemm_planes256_set_dp(int mode)  // bit 0: data-parallel rounds (default on); bit 1: test hook, head fragments are never published

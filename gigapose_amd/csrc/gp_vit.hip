@@ -24,9 +24,10 @@ int gp_gemm_split256_launch(const float* act, int ld_act, const void* whi, const
 size_t gp_gemm_streamk_bytes();
 int gp_gemm_streamk_reset_launch(float* sk_ws, hipStream_t st);
 bool gp_gemm_split256_usable(int I, int J, int K);
+bool gp_gemm_planes256_usable(int I, int J, int J_valid, int K);
 int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
-                             void* olo, int ldo, int I, int J, int K, int epilogue, const float* bias, const float* scale,
-                             const float* res, int ldr, float out_scale, float* scratch, hipStream_t st);
+                             void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
+                             const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace = nullptr);
 
 namespace {
 
@@ -851,9 +852,10 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
     // epilogue; the f32 residual stream X, Q/K and V stay as they are) and every GEMM is gemm_planes256_kernel.  The
     // planes alias the f32 buffers they replace (2 planes x 2 bytes = 4 bytes per element).  Bit-identical to the
     // f32-activation kernels (same values, same split, same k order).
-    const bool planes = split && sp_stride == 2 * S_PER_LAYER && g_vit_planes && gp_gemm_split256_usable(2 * C, Mpad, C) &&
-                        gp_gemm_split256_usable(Mpad, C, C) && gp_gemm_split256_usable(C, Mpad, C) &&
-                        gp_gemm_split256_usable(mlp_dim, Mpad, C) && gp_gemm_split256_usable(C, Mpad, mlp_dim);
+    const int Mtok = B * T_TOK;  // rows that carry tokens: the plane GEMMs tile floor(Mtok / 256) * 256 of them + a strip
+    const bool planes = split && sp_stride == 2 * S_PER_LAYER && g_vit_planes && gp_gemm_planes256_usable(2 * C, Mpad, Mtok, C) &&
+                        gp_gemm_planes256_usable(C, Mpad, Mtok, C) && gp_gemm_planes256_usable(mlp_dim, Mpad, Mtok, C) &&
+                        gp_gemm_planes256_usable(C, Mpad, Mtok, mlp_dim) && (g_vit_planes == 2 || gp_gemm_split256_usable(Mpad, C, C));
     if (planes) {
         _Float16* Hhi = reinterpret_cast<_Float16*>(Hn);
         _Float16* Hlo = Hhi + (size_t)C * Mpad;
@@ -869,10 +871,10 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
                 // Q | K | V as planes [Mpad][3C] (aliasing the f32 QK + Vt buffers): W_qk / W_v (A) x tokens (B), plane epilogue
                 _Float16* Ahi = reinterpret_cast<_Float16*>(QK);
                 _Float16* Alo = Ahi + (size_t)3 * C * Mpad;
-                if ((rc = gp_gemm_planes256_launch(sq[S_QK_HI], sq[S_QK_LO], Hhi, Hlo, nullptr, 0, Ahi, Alo, 3 * C, 2 * C, Mpad, C,
+                if ((rc = gp_gemm_planes256_launch(sq[S_QK_HI], sq[S_QK_LO], Hhi, Hlo, nullptr, 0, Ahi, Alo, 3 * C, 2 * C, Mpad, Mtok, C,
                                                    7 /*BIAS_I -> planes*/, w[L_QK_B], nullptr, nullptr, 0, os, SK, st)))
                     return rc;
-                if ((rc = gp_gemm_planes256_launch(sq[S_V_HI], sq[S_V_LO], Hhi, Hlo, nullptr, 0, Ahi + 2 * C, Alo + 2 * C, 3 * C, C, Mpad, C,
+                if ((rc = gp_gemm_planes256_launch(sq[S_V_HI], sq[S_V_LO], Hhi, Hlo, nullptr, 0, Ahi + 2 * C, Alo + 2 * C, 3 * C, C, Mpad, Mtok, C,
                                                    7 /*BIAS_I -> planes*/, w[L_V_B], nullptr, nullptr, 0, os, SK, st)))
                     return rc;
                 {
@@ -883,11 +885,11 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
                 GP_CHECK_LAUNCH("gp_vit_forward/attention_split");
             } else {
             // Q,K channel-major [2C][Mpad] = W_qk (A) x tokens (B)
-            if ((rc = gp_gemm_planes256_launch(sq[S_QK_HI], sq[S_QK_LO], Hhi, Hlo, QK, Mpad, nullptr, nullptr, 0, 2 * C, Mpad, C,
+            if ((rc = gp_gemm_planes256_launch(sq[S_QK_HI], sq[S_QK_LO], Hhi, Hlo, QK, Mpad, nullptr, nullptr, 0, 2 * C, Mpad, Mtok, C,
                                                1 /*BIAS_I*/, w[L_QK_B], nullptr, nullptr, 0, os, SK, st)))
                 return rc;
             // V token-major [Mpad][C] = tokens (A) x W_v (B), bias along j
-            if ((rc = gp_gemm_planes256_launch(Hhi, Hlo, sq[S_V_HI], sq[S_V_LO], Vt, C, nullptr, nullptr, 0, Mpad, C, C,
+            if ((rc = gp_gemm_planes256_launch(Hhi, Hlo, sq[S_V_HI], sq[S_V_LO], Vt, C, nullptr, nullptr, 0, Mpad, C, C, C,
                                                4 /*BIAS_J*/, w[L_V_B], nullptr, nullptr, 0, os, SK, st)))
                 return rc;
             {
@@ -898,17 +900,17 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
             GP_CHECK_LAUNCH("gp_vit_forward/attention_planes");
             }
             // x = x + ls1 * proj(attn)
-            if ((rc = gp_gemm_planes256_launch(sq[S_PROJ_HI], sq[S_PROJ_LO], Hhi, Hlo, X, Mpad, nullptr, nullptr, 0, C, Mpad, C,
+            if ((rc = gp_gemm_planes256_launch(sq[S_PROJ_HI], sq[S_PROJ_LO], Hhi, Hlo, X, Mpad, nullptr, nullptr, 0, C, Mpad, Mtok, C,
                                                3 /*BIAS_I_SCALE_RES*/, w[L_PROJ_B], w[L_LS1], X, Mpad, os, SK, st)))
                 return rc;
             launch_layernorm_planes(X, Hhi, Hlo, w[L_LN2_G], w[L_LN2_B], C, Mpad, ln_eps, st);
             GP_CHECK_LAUNCH("gp_vit_forward/layernorm_planes");
             // gelu(fc1(.)) straight to planes [Mpad][mlp_dim]
-            if ((rc = gp_gemm_planes256_launch(sq[S_FC1_HI], sq[S_FC1_LO], Hhi, Hlo, nullptr, 0, Fhi, Flo, mlp_dim, mlp_dim, Mpad, C,
+            if ((rc = gp_gemm_planes256_launch(sq[S_FC1_HI], sq[S_FC1_LO], Hhi, Hlo, nullptr, 0, Fhi, Flo, mlp_dim, mlp_dim, Mpad, Mtok, C,
                                                6 /*GELU -> planes*/, w[L_FC1_B], nullptr, nullptr, 0, os, SK, st)))
                 return rc;
             // x = x + ls2 * fc2(.)
-            if ((rc = gp_gemm_planes256_launch(sq[S_FC2_HI], sq[S_FC2_LO], Fhi, Flo, X, Mpad, nullptr, nullptr, 0, C, Mpad, mlp_dim,
+            if ((rc = gp_gemm_planes256_launch(sq[S_FC2_HI], sq[S_FC2_LO], Fhi, Flo, X, Mpad, nullptr, nullptr, 0, C, Mpad, Mtok, mlp_dim,
                                                3 /*BIAS_I_SCALE_RES*/, w[L_FC2_B], w[L_LS2], X, Mpad, os, SK, st)))
                 return rc;
         }

@@ -70,7 +70,10 @@ class GigaPose(_Base):
         self.test_dataset_name = None
         self.last_predictions = None  # full (unfiltered) predictions of the last eval_retrieval call
         self.template_shard = None    # (rank, world, group) when the template bank is sharded
-        self.overlap_ist = True       # run the IST backbone on a side stream, concurrently with ViT + matching
+        # IST backbone on a side stream, concurrently with ViT + matching?  Measured (BENCH_r01, profiles/r02_*): both chains are
+        # matrix-core / power bound, so the overlap only stretches every kernel (attention 3.4 -> 7.7 ms, GEMMs 30.6 -> 36.4 ms per
+        # step inside the two-stream region) for a 0-1 % gain in step time -- off by default, kept as a switch.
+        self.overlap_ist = False
         self._side_stream = None
 
     def set_numerics(self, mode):

@@ -215,9 +215,17 @@ int gp_gemm_planes256(const void* a_hi, const void* a_lo, const void* b_hi, cons
  * epilogue are the same f32 arithmetic in both modes.) */
 int gp_gemm_planes256_set_dp(int mode); /* bit 0 (default 1): data-parallel rounds before the stream-K remainder; bit 1: TEST hook,
                                            head fragments are never published (every waiter times out -> GP_STATUS_HANDOFF_SPLIT) */
-/* probe build of gp_gemm_planes256 (epilogues 0, 3, 6, 7) with per-slot time stamps, see gp_split256.hip */
+/* Ragged J (257 tokens per crop are never a multiple of 256): only rows < J_valid of B carry data (J, the padded row
+ * count of the buffers, stays a multiple of 256).  The 256 x 256 tiles cover floor(J_valid / 256) * 256 rows -- at
+ * B = 64 crops exactly one / two / four whole tiles per CU, no stream-K hand-over -- and the remaining < 256 rows are
+ * computed as 32 x 32 fragments with the same per-accumulator instruction sequence (bit-identical to tiled results).
+ * Rows >= round_up(J_valid, 32) of the outputs are not written.  Needs (I / 256) * (J_valid / 256) >= 256. */
+int gp_gemm_planes256_ragged(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
+                             void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
+                             const float* residual, int ldr, float out_scale, float* scratch, size_t scratch_bytes, void* stream);
+/* probe build of gp_gemm_planes256_ragged (epilogues 0, 3, 6, 7) with per-slot time stamps, see gp_split256.hip */
 int gp_gemm_planes256_trace(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
-                            void* out_lo, int ldo, int I, int J, int K, int epilogue, const float* bias, const float* scale,
+                            void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
                             const float* residual, int ldr, float out_scale, float* scratch, unsigned long long* trace, void* stream);
 void gp_vit_set_planes(int mode); /* 2 (default) = planes + attention in split numerics, 1 = planes + f32 attention, 0 = off */
 

@@ -226,9 +226,11 @@ E2E_CONFIGS = {
 E2E = E2E_CONFIGS["e2e"]
 
 
-def gen_e2e(which="e2e"):
-    """Whole GigaPose.eval_retrieval (gigaPose.py:481-633) of the unmodified reference: HF DINOv2 stand-in
-    backbone, reference ISTNet/LocalSimilarity/ObjectPoseRecovery, CPU."""
+def run_ref_e2e(which, double=False, dets_per_forward=4, model=None):
+    """Whole GigaPose.eval_retrieval (gigaPose.py:481-633) of the unmodified reference: HF DINOv2 stand-in backbone,
+    reference ISTNet/LocalSimilarity/ObjectPoseRecovery, CPU.  double: the SAME code with every module and input cast to
+    float64 (the reference's arithmetic without its f32 rounding).  dets_per_forward: configs/test.yaml:21's
+    max_num_dets_per_forward (a memory knob; changes the shapes of the reference's own GEMMs).  Returns (model, arrays)."""
     import tempfile
 
     import pandas as pd
@@ -241,19 +243,28 @@ def gen_e2e(which="e2e"):
 
     cfg = E2E_CONFIGS[which]
     dim, depth, heads = cfg["vit"]
-    backbone = ref_shim.HFDinov2Backbone.build(dim, depth, heads, seed=0)
-    syn.fill_state_dict(backbone.m, 302)
-    ae = AENet(cfg["name"], backbone, dim, 64)
-    ist = build_ref_ist(seed=303, conditioned=True)
-    metric = LocalSimilarity(k=cfg["k"], sim_threshold=0.5, patch_threshold=3)
+    dt = torch.float64 if double else torch.float32
     tmp = tempfile.mkdtemp()
-    model = GigaPose("large", ae, ist, None, metric, None, 1000, tmp, max_num_dets_per_forward=4).eval()
+    if model is None:
+        backbone = ref_shim.HFDinov2Backbone.build(dim, depth, heads, seed=0)
+        syn.fill_state_dict(backbone.m, 302)
+        ae = AENet(cfg["name"], backbone, dim, 64)
+        ist = build_ref_ist(seed=303, conditioned=True)
+        metric = LocalSimilarity(k=cfg["k"], sim_threshold=0.5, patch_threshold=3)
+        model = GigaPose("large", ae, ist, None, metric, None, 1000, tmp, max_num_dets_per_forward=dets_per_forward).eval().to(dt)
+    else:
+        model.log_dir = tmp
+        os.makedirs(os.path.join(tmp, "predictions"), exist_ok=True)
+    model.max_num_dets_per_forward = dets_per_forward
     items, q = e2e_inputs(cfg["seed"], cfg["O"], cfg["N"], cfg["B"])
+    for it in items:
+        for n in ["rgb", "mask", "K", "M", "poses"]:
+            setattr(it, n, getattr(it, n).to(dt))
     model.template_datasets = {"syn": _FakeTemplates(items)}
     infos = pd.DataFrame(dict(label=[str(l) for l in q["labels"]], scene_id=[1] * cfg["B"], view_id=[7] * cfg["B"]))
-    batch = PandasTensorCollection(infos=infos, tar_img=torch.from_numpy(q["tar_img"]),
-                                   tar_mask=torch.from_numpy(q["tar_mask"]), tar_K=torch.from_numpy(q["tar_K"]),
-                                   tar_M=torch.from_numpy(q["tar_M"]))
+    batch = PandasTensorCollection(infos=infos, tar_img=torch.from_numpy(q["tar_img"]).to(dt),
+                                   tar_mask=torch.from_numpy(q["tar_mask"]).to(dt), tar_K=torch.from_numpy(q["tar_K"]).to(dt),
+                                   tar_M=torch.from_numpy(q["tar_M"]).to(dt))
     objs = sorted(set(int(l) for l in q["labels"]))
     batch.test_list = PandasTensorCollection(infos=pd.DataFrame(dict(
         im_id=[7] * len(objs), scene_id=[1] * len(objs), obj_id=objs,
@@ -262,30 +273,68 @@ def gen_e2e(which="e2e"):
     orig_argsort = torch.argsort
     torch.argsort = lambda x, dim=-1, descending=False, stable=False: orig_argsort(x, dim=dim, descending=descending, stable=True)
     captured = {}
-    orig_fs = model.filter_and_save
+    orig_fs = GigaPose.filter_and_save.__get__(model)
 
     def spy(predictions, **kw):
         captured["pred"] = predictions.clone()
         return orig_fs(predictions, **kw)
 
     model.filter_and_save = spy
+    if double:  # the reference creates its temporaries with torch's default dtype (matching.py:275, ransac.py:139)
+        torch.set_default_dtype(torch.float64)
     try:
         with torch.no_grad():
             model.eval_retrieval(batch, 0, "syn")
     finally:
         torch.argsort = orig_argsort
+        torch.set_default_dtype(torch.float32)
+        del model.filter_and_save
     out = np.load(os.path.join(tmp, "predictions", "0.npz"))
     p = captured["pred"]
     td = model.template_datas["syn"]
-    np.savez_compressed(os.path.join(GOLD, which + ".npz"), poses=out["poses"], scores=out["scores"],
-                        object_id=out["object_id"], id_src=p.id_src.numpy().astype(np.int16), score_src=p.score_src.numpy(),
-                        score_pts=p.score_pts.numpy(),
-                        all_scores=p.scores.numpy(), all_poses=p.pred_poses.numpy(), M=p.M.numpy(),
-                        relScale=p.relScale.numpy(), relInplane=p.relInplane.numpy(), idx_failed=p.idx_failed.numpy(),
-                        src_pts=p.src_pts.numpy().astype(np.int8), tar_pts=p.tar_pts.numpy().astype(np.int8),
-                        tmpl_ae_feat_sample=td.ae_features[0, 0].numpy(), ist_conditioned=True)
-    print(which, ": id_src", p.id_src[:4].tolist(), "scores", np.round(p.scores[:4].numpy(), 4).tolist())
+    arrays = dict(poses=out["poses"], scores=out["scores"],
+                  object_id=out["object_id"], id_src=p.id_src.numpy().astype(np.int16), score_src=p.score_src.numpy(),
+                  score_pts=p.score_pts.numpy(),
+                  all_scores=p.scores.numpy(), all_poses=p.pred_poses.numpy(), M=p.M.numpy(),
+                  relScale=p.relScale.numpy(), relInplane=p.relInplane.numpy(), idx_failed=p.idx_failed.numpy(),
+                  src_pts=p.src_pts.numpy().astype(np.int8), tar_pts=p.tar_pts.numpy().astype(np.int8),
+                  tmpl_ae_feat_sample=td.ae_features[0, 0].numpy(), ist_conditioned=True)
+    print(which, "double" if double else "f32", "dets/forward", dets_per_forward, ": id_src", p.id_src[:4].tolist(), "scores",
+          np.round(p.scores[:4].numpy(), 4).tolist())
     print("     valid corr", (p.src_pts[..., 0] >= 0).sum(-1)[:8].tolist(), "failed", int(p.idx_failed.sum()), flush=True)
+    return model, arrays
+
+
+def gen_e2e(which="e2e"):
+    _, arrays = run_ref_e2e(which)
+    np.savez_compressed(os.path.join(GOLD, which + ".npz"), **arrays)
+
+
+def disagreement(a, b):
+    """Counts used by tests/test_gpu_parity_big.py: detections whose top-k template SET / ORDER differ, differing
+    correspondence entries, hypotheses with a different inlier count."""
+    ida, idb = a["id_src"].astype(np.int64), b["id_src"].astype(np.int64)
+    return dict(set=int((np.sort(ida, 1) != np.sort(idb, 1)).any(1).sum()), order=int((ida != idb).any(1).sum()),
+                src_pts=int((a["src_pts"] != b["src_pts"]).sum()), tar_pts=int((a["tar_pts"] != b["tar_pts"]).sum()),
+                inliers=int((a["all_scores"] != b["all_scores"]).sum()))
+
+
+def gen_e2e_f64(which="e2e_cfg2"):
+    """The reference's own code in float64 (`model.double()`, double inputs): what the f32 runs -- the reference's and
+    ours -- are approximations of.  Written to <which>_f64.npz (index / count fields + poses).  Also measured here: how
+    far the reference's f32 golden is from it, and how far the reference is from ITSELF when only
+    max_num_dets_per_forward (configs/test.yaml:21) changes from 4 to 8 -- the yardsticks for the GPU parity bar."""
+    g32 = dict(np.load(os.path.join(GOLD, which + ".npz")))
+    model, a8 = run_ref_e2e(which, dets_per_forward=8)
+    d_self = disagreement(a8, g32)
+    print(which, "reference f32, max_num_dets_per_forward 8 vs 4 (the golden):", d_self, flush=True)
+    del model
+    _, a64 = run_ref_e2e(which, double=True)
+    d_64 = disagreement(g32, a64)
+    print(which, "reference f32 golden vs reference in float64:", d_64, flush=True)
+    keep = ["id_src", "src_pts", "tar_pts", "all_scores", "idx_failed", "score_src"]
+    np.savez_compressed(os.path.join(GOLD, which + "_f64.npz"), **{k: a64[k] for k in keep}, all_poses=a64["all_poses"].astype(np.float64),
+                        M=a64["M"].astype(np.float64), ref_f32_vs_f64=repr(d_64), ref_f32_dets8_vs_dets4=repr(d_self))
 
 
 CLIP_MEAN = [0.48145466, 0.4578275, 0.40821073]   # reference configs/data/transform.yaml:6-7
@@ -337,7 +386,8 @@ def gen_bop_csv():
 
 
 STAGES = {"bop_csv": gen_bop_csv, "val": gen_val, "matcher": gen_matcher, "ist": gen_ist, "pose": gen_pose, "e2e": gen_e2e, "crop": gen_crop,
-          "matcher_big": gen_matcher_big, "e2e_cfg2": lambda: gen_e2e("e2e_cfg2"), "e2e_cfg3": lambda: gen_e2e("e2e_cfg3")}
+          "matcher_big": gen_matcher_big, "e2e_cfg2": lambda: gen_e2e("e2e_cfg2"), "e2e_cfg3": lambda: gen_e2e("e2e_cfg3"),
+          "e2e_cfg2_f64": lambda: gen_e2e_f64("e2e_cfg2"), "e2e_cfg3_f64": lambda: gen_e2e_f64("e2e_cfg3"), "e2e_f64": lambda: gen_e2e_f64("e2e")}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

@@ -66,7 +66,7 @@ def test_matcher_at_benchmark_size_vs_reference_golden(golden_dir, name, numeric
 @pytest.mark.parametrize("numerics", ["chain", "split"])
 def test_matcher_config2_all_tiles_vs_oracle(golden_dir, numerics):
     """Every one of the 10 368 tiles: idx_tar2src, mask_all, score_tar2src, sim_avg.  chain: bit-exact incl. float bits
-    (same fmaf chain).  split: a different f32-class arithmetic -- indices and masks must still be EQUAL; floats 2e-6."""
+    (same fmaf chain).  split: a different f32-class arithmetic -- indices and masks must still be EQUAL; floats 4e-6."""
     g, case = big_case(golden_dir, "match_cfg2")
     _, (idx, sc, ma, avg) = run_bank(case, int(g["k"]), numerics)
     B, C = case["tar_feat"].shape[:2]
@@ -84,7 +84,7 @@ def test_matcher_config2_all_tiles_vs_oracle(golden_dir, numerics):
         np.testing.assert_array_equal(sc.view(np.uint32), osc.view(np.uint32))
         np.testing.assert_array_equal(avg.view(np.uint32), oavg.view(np.uint32))
     else:
-        assert np.abs(sc - osc).max() <= 2e-6 and np.abs(avg - oavg).max() <= 2e-6
+        assert np.abs(sc - osc).max() <= 4e-6 and np.abs(avg - oavg).max() <= 1e-6
 
 
 # ---------------------------------------------------------------------------------------------------------------- e2e

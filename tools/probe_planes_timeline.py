@@ -23,7 +23,8 @@ def timeit(fn, iters=10, warm=3):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 torch.manual_seed(0)
-M = int(os.environ.get("MTOK", 16640))
+M = int(os.environ.get("MPAD", 16640))           # padded rows of the token dimension (ViT-L at B = 64)
+MV = int(os.environ.get("MTOK", 16448))          # rows that carry tokens (64 x 257); MTOK=16640 probes the fully tiled launch
 for (nw, K, name, epi) in [(2048, 1024, "qk", 7), (1024, 1024, "v", 7), (1024, 1024, "proj", 3), (4096, 1024, "fc1", 6), (1024, 4096, "fc2", 3)]:
     W = torch.randn(nw, K, device=dev) * 0.03
     Xt = torch.randn(M, K, device=dev) * 1.5
@@ -34,8 +35,8 @@ for (nw, K, name, epi) in [(2048, 1024, "qk", 7), (1024, 1024, "v", 7), (1024, 1
     ohi = torch.zeros(M, nw, dtype=torch.float16, device=dev); olo = torch.zeros_like(ohi)
     trace = torch.zeros(256 * 32, dtype=torch.int64, device=dev)
     args = (_lib.ptr(whi), _lib.ptr(wlo), _lib.ptr(xhi), _lib.ptr(xlo), _lib.ptr(D), _lib.i(J), _lib.ptr(ohi), _lib.ptr(olo), _lib.i(nw),
-            _lib.i(I), _lib.i(J), _lib.i(K), _lib.i(epi), _lib.ptr(bias), _lib.ptr(sc), _lib.ptr(D), _lib.i(J), _lib.f(1.0 / 512.0), _lib.ptr(ws))
-    def plain(): _lib.call("gp_gemm_planes256", *args, ctypes.c_size_t(NB), _lib.stream_ptr())
+            _lib.i(I), _lib.i(J), _lib.i(MV), _lib.i(K), _lib.i(epi), _lib.ptr(bias), _lib.ptr(sc), _lib.ptr(D), _lib.i(J), _lib.f(1.0 / 512.0), _lib.ptr(ws))
+    def plain(): _lib.call("gp_gemm_planes256_ragged", *args, ctypes.c_size_t(NB), _lib.stream_ptr())
     def traced(): _lib.call("gp_gemm_planes256_trace", *args, _lib.ptr(trace), _lib.stream_ptr())
     t_plain = timeit(plain)
     for _ in range(20): plain()          # sustained clocks
@@ -43,7 +44,7 @@ for (nw, K, name, epi) in [(2048, 1024, "qk", 7), (1024, 1024, "v", 7), (1024, 1
     t = trace.cpu().numpy().reshape(256, 32).astype(np.int64)
     start, nseg = t[:, 0], t[:, 1]
     t0 = start.min()
-    ends, kl, ep, wait, steps, pub = [], [], [], [], [], []
+    ends, kl, ep, wait, steps, pub, strip = [], [], [], [], [], [], []
     for p in range(256):
         prev = start[p]
         for s in range(min(int(nseg[p]), 7)):
@@ -52,11 +53,13 @@ for (nw, K, name, epi) in [(2048, 1024, "qk", 7), (1024, 1024, "v", 7), (1024, 1
             wait.append((a - prev) / 100.0); kl.append((b - a) / 100.0); steps.append(ns)
             (pub if kind == 1 else ep).append((c - b) / 100.0)
             prev = c
-        ends.append((prev - t0) / 100.0)
+        strip.append((t[p, 31] - prev) / 100.0)
+        ends.append((t[p, 31] - t0) / 100.0)
     kl, steps = np.array(kl), np.array(steps)
-    fl = 2.0 * I * J * K
+    fl = 2.0 * I * MV * K
     print(f"{name:5s} I={I} J={J} K={K} epi {epi}: event-timed {t_plain:6.1f} us = {fl / t_plain / 1e6:5.0f} TF-eq | traced slots: start spread "
           f"{(start.max() - t0) / 100.0:5.1f} us, lifetime min/mean/max {min(ends):6.1f}/{np.mean(ends):6.1f}/{max(ends):6.1f} us | per slot: segments "
           f"{nseg.mean():.2f}, k loop {kl.sum() / 256:6.1f} us ({kl.sum() / steps.sum():.3f} us/step, {steps.sum() / 256:.1f} steps), "
           f"epilogues {np.sum(ep) / 256:5.1f} us ({np.mean(ep) if ep else 0:5.1f} each x {len(ep) / 256:.2f}), publishes {np.sum(pub) / 256:5.1f} us "
-          f"({np.mean(pub) if pub else 0:5.1f} each), waits + prologue {np.sum(wait) / 256:5.1f} us (max single {np.max(wait):5.1f})", flush=True)
+          f"({np.mean(pub) if pub else 0:5.1f} each), waits + prologue {np.sum(wait) / 256:5.1f} us (max single {np.max(wait):5.1f}), "
+          f"strip mean {np.mean(strip):4.1f} max {np.max(strip):4.1f} us", flush=True)

@@ -76,10 +76,12 @@ def save_bank(model, dataset_name, path):
               "ist_features": td.ist_features.cpu().numpy(), "K": td.K.cpu().numpy(), "M": td.M.cpu().numpy(),
               "poses": td.poses.cpu().numpy()}
     if bank.numerics == "split":
-        arrays["match_hi"], arrays["match_lo"] = bank.hi.cpu().numpy(), bank.lo.cpu().numpy()
+        arrays["match_hi"] = bank.hi.cpu().numpy()
+        if bank.lo is not None:            # bank_dtype "f16": the file holds the hi plane only (half the bytes)
+            arrays["match_lo"] = bank.lo.cpu().numpy()
     else:
         arrays["match_f32"] = bank.features.cpu().numpy()
-    return write_sections(path, dict(numerics=bank.numerics, O=bank.O, N=bank.N, C=bank.C), arrays)
+    return write_sections(path, dict(numerics=bank.numerics, bank_dtype=getattr(bank, "bank_dtype", "f32"), O=bank.O, N=bank.N, C=bank.C), arrays)
 
 
 @torch.no_grad()
@@ -102,8 +104,10 @@ def load_bank(model, dataset_name, path, shard=None, group=None):
     bank = MatchBank.__new__(MatchBank)
     bank.numerics, bank.O, bank.N, bank.C = h["numerics"], O, hi - lo, h["C"]
     bank.features = bank.hi = bank.lo = None
+    bank.bank_dtype = h.get("bank_dtype", "f32")
     if h["numerics"] == "split":
-        bank.hi, bank.lo = up("match_hi", slice(lo, hi)), up("match_lo", slice(lo, hi))
+        bank.hi = up("match_hi", slice(lo, hi))
+        bank.lo = up("match_lo", slice(lo, hi)) if "match_lo" in h["sections"] else None
     else:
         bank.features = up("match_f32", slice(lo, hi))
     bank.masks = up("masks", slice(lo, hi))

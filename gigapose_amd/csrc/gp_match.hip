@@ -252,6 +252,15 @@ struct MatchSplitSmem {
     float maskv[GP_P];
 };
 
+// Main loop = gemm_planes256_kernel's (gp_split256.hip): the two wave groups of the workgroup (waves 0-3 / 4-7, one of each
+// per SIMD) run half a k-step apart -- one issues its 48 MFMAs from LDS buffer s while the other writes its share of slab
+// s + 1 and loads slab s + 2 -- with ONE barrier per step; per accumulator the products keep the order hi*hi, hi*lo, lo*hi
+// per k16 block, k ascending: results are bit-identical to the lock-step loop this replaces (60 % -> 84 % matrix-busy in
+// the k loop).  BANK_LO = false: the bank holds only its f16 hi plane (BASELINE config 5's "fp16 feature bank": half the
+// bytes, 2 of the 3 products; the query keeps both planes) -- f16-rounded template features, measured flip rate in DESIGN.md.
+typedef unsigned int mu32x4 __attribute__((ext_vector_type(4)));
+
+template <bool BANK_LO>
 __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo,  // (B, 256, C)
     const _Float16* __restrict__ b_hi, const _Float16* __restrict__ b_lo,  // (O*N, 256, C)
@@ -265,8 +274,9 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     const int band = q / (8 * N), r8 = q - band * (8 * N);
     const int gsz = min(8, B - band * 8);
     const int b = band * 8 + r8 % gsz, n = r8 / gsz;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, grp = wave >> 2;
     int lab = labels[b];
     if ((unsigned)lab >= (unsigned)O) {
         if (tid == 0) gp_raise(status, GP_ST_LABEL_RANGE);
@@ -276,21 +286,41 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     if (tid < GP_P) sm.qmask[tid] = qmask[(size_t)b * GP_P + tid];
     else sm.smask[tid - GP_P] = bmask[on * GP_P + (tid - GP_P)];
 
-    // staging: chunk c = tid + 512 u (u < 8): plane c >> 10 (q_hi, q_lo, b_hi, b_lo), row (c & 1023) >> 2, k-chunk c & 3
-    const _Float16* src[4] = {q_hi + (size_t)b * GP_P * C, q_lo + (size_t)b * GP_P * C, b_hi + on * GP_P * C, b_lo + on * GP_P * C};
-    h16x8 rg[8];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = tid + 512 * u, row = (c & 1023) >> 2, kc = c & 3;
-            rg[u] = *reinterpret_cast<const h16x8*>(src[u >> 1] + (size_t)row * C + k0 + kc * 8);
+    // staging: thread = (row tid >> 2 [+128], 16-byte k-chunk tid & 3) of each plane; one descriptor per plane of THIS tile
+    const unsigned plane_bytes = (unsigned)GP_P * (unsigned)C * 2u;
+    const __amdgpu_buffer_rsrc_t r_qh = __builtin_amdgcn_make_buffer_rsrc((void*)(q_hi + (size_t)b * GP_P * C), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_ql = __builtin_amdgcn_make_buffer_rsrc((void*)(q_lo + (size_t)b * GP_P * C), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_bh = __builtin_amdgcn_make_buffer_rsrc((void*)(b_hi + on * GP_P * C), 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_bl = __builtin_amdgcn_make_buffer_rsrc((void*)((BANK_LO ? b_lo : b_hi) + on * GP_P * C), 0, plane_bytes, 0x00020000);
+    const unsigned voff = (unsigned)(tid >> 2) * (unsigned)C * 2u + (unsigned)(tid & 3) * 16u;
+    const unsigned half_rows = 128u * (unsigned)C * 2u;
+    const int wofs = (tid >> 2) * MS_BK + (((tid & 3) ^ (((tid >> 2) >> 2) & 3)) << 3);
+    constexpr int P_AHI = 0, P_ALO = MS_PLANE, P_BHI = 2 * MS_PLANE, P_BLO = 3 * MS_PLANE, MS_BUF = 4 * MS_PLANE;
+    mu32x4 rg[8];
+    auto gload = [&](int slab) {
+        const unsigned so = (unsigned)slab * (MS_BK * 2u);
+        rg[0] = __builtin_amdgcn_raw_buffer_load_b128(r_qh, voff, so, 0);
+        rg[1] = __builtin_amdgcn_raw_buffer_load_b128(r_qh, voff, so + half_rows, 0);
+        rg[2] = __builtin_amdgcn_raw_buffer_load_b128(r_ql, voff, so, 0);
+        rg[3] = __builtin_amdgcn_raw_buffer_load_b128(r_ql, voff, so + half_rows, 0);
+        rg[4] = __builtin_amdgcn_raw_buffer_load_b128(r_bh, voff, so, 0);
+        rg[5] = __builtin_amdgcn_raw_buffer_load_b128(r_bh, voff, so + half_rows, 0);
+        if (BANK_LO) {
+            rg[6] = __builtin_amdgcn_raw_buffer_load_b128(r_bl, voff, so, 0);
+            rg[7] = __builtin_amdgcn_raw_buffer_load_b128(r_bl, voff, so + half_rows, 0);
         }
     };
     auto stage = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = tid + 512 * u, row = (c & 1023) >> 2, kc = c & 3;
-            *reinterpret_cast<h16x8*>(sm.stage + (buf * 4 + (u >> 1)) * MS_PLANE + row * MS_BK + ((kc ^ ((row >> 2) & 3)) * 8)) = rg[u];
+        _Float16* L = sm.stage + buf * MS_BUF + wofs;
+        *reinterpret_cast<mu32x4*>(L + P_AHI) = rg[0];
+        *reinterpret_cast<mu32x4*>(L + P_AHI + 128 * MS_BK) = rg[1];
+        *reinterpret_cast<mu32x4*>(L + P_ALO) = rg[2];
+        *reinterpret_cast<mu32x4*>(L + P_ALO + 128 * MS_BK) = rg[3];
+        *reinterpret_cast<mu32x4*>(L + P_BHI) = rg[4];
+        *reinterpret_cast<mu32x4*>(L + P_BHI + 128 * MS_BK) = rg[5];
+        if (BANK_LO) {
+            *reinterpret_cast<mu32x4*>(L + P_BLO) = rg[6];
+            *reinterpret_cast<mu32x4*>(L + P_BLO + 128 * MS_BK) = rg[7];
         }
     };
 
@@ -302,43 +332,77 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const int nstep = C / MS_BK;
+    // fragment addressing (rows of the wave tile 64 x 128, XOR-swizzled 16-byte chunks)
+    const int ar_ = 64 * wr + (lane & 31), br_ = 128 * wc + (lane & 31), kh_ = lane >> 5;
+    const int arow = ar_ * MS_BK, brow = br_ * MS_BK;
+    const int ak0 = ((kh_ ^ ((ar_ >> 2) & 3)) << 3), ak1 = (((kh_ + 2) ^ ((ar_ >> 2) & 3)) << 3);
+    const int bk0 = ((kh_ ^ ((br_ >> 2) & 3)) << 3), bk1 = (((kh_ + 2) ^ ((br_ >> 2) & 3)) << 3);
+    const int ns = C / MS_BK;
     gload(0);
     stage(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ns > 1) gload(1);
     __syncthreads();
-    const int l31 = lane & 31, kh = lane >> 5;
-    for (int s = 0; s < nstep; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nstep) gload((s + 1) * MS_BK);
-        const _Float16* L = sm.stage + buf * 4 * MS_PLANE;
+
+#define M_MFMA(A_, B_, mi, ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[mi], B_[ni], acc[mi][ni], 0, 0, 0)
+    auto c_phase = [&](int s) __attribute__((always_inline)) {
+        const _Float16* L = sm.stage + (s & 1) * MS_BUF;
+        __builtin_amdgcn_s_setprio(1);  // before the fragment reads: they must not queue behind the other group's staging
+        h16x8 ah[2], al[2], bh[4], bl[4], ch[2], cl[2], dh[4], dl[4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int kc = 2 * ks + kh;  // this lane's 8-k chunk inside the 32-k slab
-            h16x8 ah[2], al[2];
+        for (int mi = 0; mi < 2; ++mi) ah[mi] = *reinterpret_cast<const h16x8*>(L + P_AHI + arow + mi * 32 * MS_BK + ak0);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int row = 64 * wr + 32 * mi + l31;
-                const int off = row * MS_BK + ((kc ^ ((row >> 2) & 3)) * 8);
-                ah[mi] = *reinterpret_cast<const h16x8*>(L + 0 * MS_PLANE + off);
-                al[mi] = *reinterpret_cast<const h16x8*>(L + 1 * MS_PLANE + off);
-            }
+        for (int ni = 0; ni < 4; ++ni) bh[ni] = *reinterpret_cast<const h16x8*>(L + P_BHI + brow + ni * 32 * MS_BK + bk0);
+        if (BANK_LO) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int row = 128 * wc + 32 * ni + l31;
-                const int off = row * MS_BK + ((kc ^ ((row >> 2) & 3)) * 8);
-                const h16x8 bh = *reinterpret_cast<const h16x8*>(L + 2 * MS_PLANE + off);
-                const h16x8 bl = *reinterpret_cast<const h16x8*>(L + 3 * MS_PLANE + off);
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh, acc[mi][ni], 0, 0, 0);
-                }
-            }
+            for (int ni = 0; ni < 4; ++ni) bl[ni] = *reinterpret_cast<const h16x8*>(L + P_BLO + brow + ni * 32 * MS_BK + bk0);
         }
-        if (s + 1 < nstep) stage(buf ^ 1);
-        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) al[mi] = *reinterpret_cast<const h16x8*>(L + P_ALO + arow + mi * 32 * MS_BK + ak0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) { M_MFMA(ah, bh, 0, ni); M_MFMA(ah, bh, 1, ni); }
+        if (BANK_LO) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) { M_MFMA(ah, bl, 0, ni); M_MFMA(ah, bl, 1, ni); }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) ch[mi] = *reinterpret_cast<const h16x8*>(L + P_AHI + arow + mi * 32 * MS_BK + ak1);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) dh[ni] = *reinterpret_cast<const h16x8*>(L + P_BHI + brow + ni * 32 * MS_BK + bk1);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) { M_MFMA(al, bh, 0, ni); M_MFMA(al, bh, 1, ni); }
+        if (BANK_LO) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) dl[ni] = *reinterpret_cast<const h16x8*>(L + P_BLO + brow + ni * 32 * MS_BK + bk1);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) cl[mi] = *reinterpret_cast<const h16x8*>(L + P_ALO + arow + mi * 32 * MS_BK + ak1);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) { M_MFMA(ch, dh, 0, ni); M_MFMA(ch, dh, 1, ni); }
+        if (BANK_LO) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) { M_MFMA(ch, dl, 0, ni); M_MFMA(ch, dl, 1, ni); }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) { M_MFMA(cl, dh, 0, ni); M_MFMA(cl, dh, 1, ni); }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto m_phase = [&](int slab) __attribute__((always_inline)) {  // stages `slab`, loads slab + 1
+        if (slab < ns) stage(slab & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        gload(min(slab + 1, ns - 1));  // unconditional (the last ones re-load an L2-hot slab, unused)
+    };
+    //     waves 0-3:  C0 M1 | C1 M2 | ...          waves 4-7:  M1 C0 | M2 C1 | ...        (| = the one barrier per k-step)
+    if (grp) m_phase(1);
+    for (int s = 0; s < ns; ++s) {
+        c_phase(s);
+        if (grp && s + 1 < ns) __syncthreads();
+        m_phase(s + 1 + grp);
+        if (!grp && s + 1 < ns) __syncthreads();
     }
+#undef M_MFMA
+    __syncthreads();  // the epilogue reuses nothing of `stage`, but its first LDS writes must follow every wave's mask reads
+
     constexpr float inv = 1.0f / (kFeatScale * kFeatScale);  // exact power of two
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -502,12 +566,18 @@ int gp_match_tiles_split(const void* q_hi, const void* q_lo, const void* b_hi, c
     GP_REQUIRE(B >= 0 && O > 0 && N > 0, "gp_match_tiles_split: bad sizes B=%d O=%d N=%d", B, O, N);
     GP_REQUIRE(C > 0 && C % 32 == 0, "gp_match_tiles_split: C=%d must be a positive multiple of 32", C);
     if (B == 0) return GP_OK;
-    GP_REQUIRE(q_hi && q_lo && b_hi && b_lo && qmask && bmask && labels && idx_t2s && score_t2s && mask_all && sim_avg,
+    GP_REQUIRE(q_hi && q_lo && b_hi && qmask && bmask && labels && idx_t2s && score_t2s && mask_all && sim_avg,
                "gp_match_tiles_split: null pointer");
+    GP_REQUIRE((long long)GP_P * C * 2 < (1ll << 31), "gp_match_tiles_split: C too large");
     GpProfScope prof(GP_PROF_MATCH_SPLIT, 2.0 * B * N * 256.0 * 256.0 * C, (hipStream_t)stream);
-    hipLaunchKernelGGL(match_tiles_split_kernel, dim3(xcd_chunked_grid(B * N)), dim3(512), 0, (hipStream_t)stream,
-                       (const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)b_hi, (const _Float16*)b_lo, qmask,
-                       bmask, labels, B, O, N, C, sim_threshold, patch_threshold, gp_status_buffer(), idx_t2s, score_t2s, mask_all, sim_avg);
+    if (b_lo)
+        hipLaunchKernelGGL(match_tiles_split_kernel<true>, dim3(xcd_chunked_grid(B * N)), dim3(512), 0, (hipStream_t)stream,
+                           (const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)b_hi, (const _Float16*)b_lo, qmask,
+                           bmask, labels, B, O, N, C, sim_threshold, patch_threshold, gp_status_buffer(), idx_t2s, score_t2s, mask_all, sim_avg);
+    else  // fp16 bank: hi plane only
+        hipLaunchKernelGGL(match_tiles_split_kernel<false>, dim3(xcd_chunked_grid(B * N)), dim3(512), 0, (hipStream_t)stream,
+                           (const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)b_hi, (const _Float16*)nullptr, qmask,
+                           bmask, labels, B, O, N, C, sim_threshold, patch_threshold, gp_status_buffer(), idx_t2s, score_t2s, mask_all, sim_avg);
     GP_CHECK_LAUNCH("gp_match_tiles_split");
     return GP_OK;
 }

@@ -120,9 +120,11 @@ class GigaPose(_Base):
         data = {n: torch.stack(v, dim=0) for n, v in cols.items()}
         self.template_datas[dataset_name] = PandasTensorCollection(infos=pd.DataFrame(), **data)
         if self.template_shard is None:
-            self.match_banks[dataset_name] = MatchBank(data["ae_features"], data["mask"], self.testing_metric.numerics)
+            self.match_banks[dataset_name] = MatchBank(data["ae_features"], data["mask"], self.testing_metric.numerics,
+                                                       self.testing_metric.bank_dtype)
         else:  # the matcher bank holds only this rank's slice of every object's templates
-            shard = MatchBank(data["ae_features"], data["mask"][:, lo:hi].contiguous(), self.testing_metric.numerics)
+            shard = MatchBank(data["ae_features"], data["mask"][:, lo:hi].contiguous(), self.testing_metric.numerics,
+                              self.testing_metric.bank_dtype)
             self.match_banks[dataset_name] = ShardedMatcher(self.testing_metric, shard, lo, group)
         self.pose_recovery[dataset_name] = ObjectPoseRecovery(template_K=data["K"], template_Ms=data["M"],
                                                               template_poses=data["poses"])

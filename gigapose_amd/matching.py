@@ -51,14 +51,22 @@ class MatchBank:
     matcher's own, matching.py:229) and patch masks (O,N,256).  numerics "chain": features (O,N,C,256) f32;
     "split": f16 planes hi / lo (O,N,256,C) of the same normalised values x 32 (same bytes per template)."""
 
-    def __init__(self, ae_features, masks224, numerics=None):
+    def __init__(self, ae_features, masks224, numerics=None, bank_dtype=None):
+        """bank_dtype "f16" (split numerics only; env GIGAPOSE_BANK_DTYPE): keep only the f16 hi plane of the templates --
+        BASELINE config 5's "fp16 feature bank resident in HBM": half the bytes (0.5 MB per template at C = 1024) and two of
+        the three MFMA products; the template features are then f16-rounded (11 bits), which moves near-tied patch argmaxes
+        (measured rate: DESIGN.md section 2).  The query keeps both planes."""
         self.numerics = numerics or default_numerics()
+        self.bank_dtype = bank_dtype or os.environ.get("GIGAPOSE_BANK_DTYPE", "f32")
+        if self.bank_dtype not in ("f32", "f16") or (self.bank_dtype == "f16" and self.numerics != "split"):
+            raise ValueError("bank_dtype must be 'f32' or 'f16' ('f16' needs numerics='split')")
         O, N, C = ae_features.shape[:3]
         feats = ae_features.reshape(O * N, C, P).contiguous().float()
         self.features = self.hi = self.lo = None
         if self.numerics == "split":
             hi, lo = normalize_split(feats)
-            self.hi, self.lo = hi.view(O, N, P, -1), lo.view(O, N, P, -1)
+            self.hi = hi.view(O, N, P, -1)
+            self.lo = lo.view(O, N, P, -1) if self.bank_dtype == "f32" else None
         else:
             self.features = torch.empty_like(feats)
             _lib.call("gp_l2norm_cp", _lib.ptr(feats), _lib.ptr(self.features), _lib.i(O * N), _lib.i(C),
@@ -81,6 +89,7 @@ class LocalSimilarity(torch.nn.Module):
         self.search_direction = search_direction
         self.num_patches = image_size // patch_size
         self.numerics = default_numerics()
+        self.bank_dtype = None  # None: MatchBank's default (env GIGAPOSE_BANK_DTYPE or "f32"); "f16": hi-plane-only bank
         if patch_threshold <= 0:
             raise NotImplementedError("patch_threshold must be > 0 (reference default 3; <= 0 disables the "
                                       "cycle check in the reference, which is not built)")

@@ -155,6 +155,7 @@ def main():
         for _ in range(args.warmup):
             step()
         dt, kern_timed = timed(args.steps, profile=True)
+        _lib.check_status()  # guard rails (lost hand-off / split range / labels): read once, outside the timed region
         if model.overlap_ist:
             model.overlap_ist = False
             dt_serial, kern = timed(args.steps, profile=True)
@@ -176,6 +177,43 @@ def main():
                  "ms_per_step": round(1e3 * odt / args.steps, 3), "serial_ms_per_step": round(1e3 * odt_serial / args.steps, 3),
                  "kernels": okern}
         model.set_numerics(args.numerics)
+    # BASELINE configs 3 and 5 at size on this one GPU (N = 1 only): same path, headline numerics, fewer steps.  Config 5's
+    # bank is the fp16 (hi-plane-only) one its text asks for; at N = 8 it would be sharded 8-way (1/8 of these bytes per GPU).
+    other_configs = None
+    if world == 1 and not dist.is_initialized() and not args.no_configs and args.variant == "dinov2_vitl14":
+        other_configs = {}
+        for key, n_obj, bank_dtype, text in (
+                ("config3", 8, "f32", "LM-O shape: 8 objects x 162 templates, 64-crop multi-detection batch with mixed labels, 1 GPU"),
+                ("config5", 40, "f16", "HANDAL/HOPE scale: 40 objects x 162 templates, fp16 feature bank resident in HBM, 1 GPU (unsharded replica)")):
+            tset_c = factory.TemplateSet(n_obj, args.templates, seed=300 + n_obj)
+            model.set_numerics(args.numerics)
+            model.testing_metric.bank_dtype = bank_dtype
+            model.template_datasets = {key: tset_c}
+            t0 = time.perf_counter()
+            model.set_template_data(key)
+            t_onboard = time.perf_counter() - t0
+            model.pose_recovery[key].check_asserts = False
+            qc = tset_c.crops(2000 + n_obj, args.batch, dev)
+            run = lambda: model.predict(qc["tar_img"], qc["tar_mask"], qc["tar_K"], qc["tar_M"], qc["labels"], key)
+            for _ in range(2):
+                run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_steps = max(3, args.steps // 2)
+            for _ in range(n_steps):
+                run()
+            torch.cuda.synchronize()
+            dtc = time.perf_counter() - t0
+            _lib.check_status()
+            bank = model.match_banks[key]
+            nbytes = sum(t.numel() * t.element_size() for t in (bank.hi, bank.lo, bank.features) if t is not None)
+            other_configs[key] = {"workload": text, "value": round(args.batch * n_steps / dtc, 2), "unit": "query-crops/sec", "steps": n_steps,
+                                  "ms_per_step": round(1e3 * dtc / n_steps, 3), "numerics": args.numerics, "bank_dtype": bank_dtype,
+                                  "matcher_bank_GB": round(nbytes / 1e9, 3), "onboarding_s_per_object": round(t_onboard / n_obj, 3)}
+            del model.match_banks[key], model.template_datas[key], tset_c
+            torch.cuda.empty_cache()
+        model.testing_metric.bank_dtype = None
+        model.template_datasets = {"syn": tset}
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -198,11 +236,13 @@ def main():
         roofline = {"kernel": "gemm_planes256_kernel (ViT linear layers; 3 x v_mfma_f32_32x32x16_f16 per k-block on f16-split f32 "
                               "operands held as hi / lo planes, f32 accumulate)", "bound": "mfma", "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / F16_MFMA_PEAK_TFLOPS, 4),
-                    "algorithmic_tflops_f32_equivalent": alg,
+                    "algorithmic_tflops_f32_equivalent": alg, "frac_algorithmic": round(alg / F16_MFMA_PEAK_TFLOPS, 4),
+                    "frac_of_split_bound": round(3.0 * alg / F16_MFMA_PEAK_TFLOPS, 4),
                     "note": "achieved = 3 x algorithmic 2IJK flops / launch time (the three f16 products per f32-equivalent "
-                            "product all execute on the matrix core); the f32-input MFMA peak this mode replaces is 157.3. "
-                            "The kernel runs power-limited: 1.62-1.78 GHz measured in-kernel against the 2.4 GHz the peak "
-                            "assumes (profiles/r01_probe_planes256_variants.txt), matrix pipe 84 % busy in its k loop",
+                            "product all execute on the matrix core; frac_algorithmic = the 2IJK flops alone against the same "
+                            "peak); the f32-input MFMA peak this mode replaces is 157.3. The kernel runs power-limited: 1.60 GHz "
+                            "measured in-kernel against the 2.4 GHz the peak assumes, matrix pipe 86 % busy in its k loop "
+                            "(profiles/r02_probe_planes256_fc2.txt)",
                     "traffic": traffic}
     else:
         g = kern.get("gemm_kmajor", {})
@@ -211,8 +251,10 @@ def main():
                     "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic}
     roofline.update({
-        "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json); algorithmic "
-                        "operand + result bytes per launch: see DESIGN.md section 4",
+        "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE); algorithmic operand + result bytes per launch: DESIGN.md section 4",
+        "traffic_source": "STATIC: read from profiles/pmc_traffic.json, the rocprofv3 --pmc passes of this same command recorded by "
+                          "tools/pmc_bench.sh (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction) -- PMC counters cannot be "
+                          "collected inside the timed run",
         "share_of_step": round(g.get("ms_per_step", 0.0) / (1e3 * dt_serial / args.steps), 3),
         "measured": "HIP events on the launch stream around every launch, over a single-stream replay of the "
                     "timed steps (kernels_timed_region: same events inside the timed, two-stream region)",
@@ -230,11 +272,16 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: {args.variant} random-init, {args.objects} object(s) x {args.templates} templates, "
                                f"batch={args.batch} crops per GPU, k={args.k}, full path ViT->match->IST->RANSAC->pose",
                    "numerics": args.numerics, "global_batch": world * args.batch, "parallelism": "single" if world == 1 else f"{mode}{world}",
-                   "streams": "ViT+match on stream 0, IST backbone on stream 1" if model.overlap_ist else "single stream"},
+                   "streams": "ViT+match on stream 0, IST backbone on stream 1" if model.overlap_ist else "single stream",
+                   "rccl_ranks": world if dist.is_initialized() else 0,
+                   "host_syncs_in_timed_loop": "none: pose recovery's crop-transform assert readback (reference lib3d/torch.py:54-55) is "
+                                               "disabled for the loop (check_asserts=False); the device status word is read once after it"},
         "roofline": roofline,
     }
     if other is not None:
         out["other_numerics"] = other
+    if other_configs:
+        out["other_configs"] = other_configs
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(args.variant, args.templates, args.k)

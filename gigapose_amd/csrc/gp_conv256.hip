@@ -1,0 +1,420 @@
+// IST backbone convolutions in split numerics, second generation: the plane x plane GEMM of gp_split256.hip turned into an
+// implicit GEMM.  (First generation: gp_split.hip's conv_split_kernel -- 128 x 128 tiles, two accumulators, lock-step
+// staging, 8-byte scattered epilogue accesses: 213-223 TF-eq = 26 % of the f16 peak with the plane GEMM at 42 %.)
+//
+//   Y[pix][co] = epi( 2^-9 * sum_k X8[pix][k] * W64[co][k] ),   k = (dy, dx, ci), ci fastest  (reference resnet.py:26-50, 364-381)
+//
+//   * activations: channel-LAST f16 planes hi / lo of shape (B, H, W, C) in the single-accumulator convention of
+//     gp_split256.hip -- hi = f16(8 x), lo = f16(8 x - hi), |x| < 8190 (guarded) -- weights (Cout, K) planes of 64 w; one
+//     16-byte chunk = 8 consecutive channels of one tap = the MFMA operand fragment, so the im2col gather is a chunk copy
+//     whose per-thread offset changes once per k-step (one tap and 32 channels per step; taps outside the image read as
+//     zeros through the buffer descriptor's range check);
+//   * tile 256 pixels (i) x 64 NI output channels (j), NI = 2, 3, 4 for Cout = 128, 192, >= 256: 8 waves as 4 x 2, wave
+//     tile 64 x 32 NI, ONE accumulator, k-step 32, two LDS buffers, the two wave groups half a k-step apart with one
+//     barrier per step (the loop of gemm_planes256_kernel);
+//   * work distribution of gemm_planes256_kernel: data-parallel rounds of whole tiles per XCD chunk, a stream-K remainder
+//     with deterministic accumulator hand-overs when the tile count does not fill the slots evenly (layer4 at B = 64:
+//     128 tiles on 256 slots -> every tile is cut in two k halves);
+//   * epilogue through LDS (per wave, 32 pixel rows at a time): eval-BatchNorm alpha / beta, residual (planes), ReLU,
+//     output planes (npix, Cout) with 8 contiguous bytes per lane and 256-byte row segments per 32 lanes -- or f32 NCHW for
+//     the last layer.
+#include "gp_common.h"
+
+typedef _Float16 c16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 c16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int cu32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr float kActScale = 8.0f, kOutScale = 1.0f / (8.0f * 64.0f);
+constexpr int CT = 256, CBK = 32, CNT = 512;
+constexpr int CROW = 32, CPLANE = CT * CROW;  // halfs
+constexpr int CBUF = 4 * CPLANE;              // A hi, A lo, B hi, B lo (B uses 64 NI of its 256 rows)
+constexpr int kSlots = 256, kErrWord = 1025;
+constexpr size_t kHeaderBytes = 8192;
+constexpr size_t kFragFloats = (size_t)CT * CT;
+constexpr int kSpin = 400000;
+constexpr unsigned kOob = 0x80000000u;        // buffer offset beyond every plane: the load returns zeros
+
+struct ConvPArgs {
+    const _Float16* xhi; const _Float16* xlo;   // (B, H, W, Cin) x 8
+    const _Float16* whi; const _Float16* wlo;   // (Cout, K) x 64
+    const float* alpha; const float* beta;      // folded BatchNorm (Cout) or null
+    const _Float16* rhi; const _Float16* rlo;   // residual planes (npix, Cout) x 8 or null
+    _Float16* ohi; _Float16* olo; float* of32;  // output planes (npix, Cout) x 8, or f32 (B, Cout, OH, OW)
+    int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, relu, K;
+    int tiles_i, tiles_j;
+    int* flags; float* partial; int epoch; int* status;
+};
+
+__device__ __forceinline__ int toff(int row, int kc) { return row * CROW + ((kc ^ ((row >> 2) & 3)) << 3); }
+
+template <int NI>
+__global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * CBUF];  // 128 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, grp = wave >> 2;
+    constexpr int P_AHI = 0, P_ALO = CPLANE, P_BHI = 2 * CPLANE, P_BLO = 3 * CPLANE;
+    constexpr int JT = 64 * NI;  // output channels per tile
+
+    // ---- this slot's range of (tile, k-step) units inside its XCD's tile chunk (gemm_planes256_kernel's scheme)
+    const int p = blockIdx.x, x = p & 7, n = p >> 3, slots_x = gridDim.x >> 3;
+    const int T = a.tiles_i * a.tiles_j;
+    const int t_lo = (int)((long long)T * x / 8), n_t = (int)((long long)T * (x + 1) / 8) - t_lo;
+    const int nstep = a.K / CBK;
+    const int rounds_dp = (n_t / slots_x > 1) ? n_t / slots_x - 1 : 0;
+    const int n_dp = rounds_dp * slots_x;
+    const long long U = (long long)(n_t - n_dp) * nstep;
+    const long long u0 = U * n / slots_x, u1 = U * (n + 1) / slots_x;
+    const int ta = (int)(u0 / nstep), sa = (int)(u0 % nstep);
+    const int tb = (int)(u1 / nstep), sb = (int)(u1 % nstep);
+    const int n_head = sb > 0 ? 1 : 0, n_rest = sa > 0 ? 1 : 0;
+    const int first_whole = ta + n_rest;
+    const int n_seg = rounds_dp + n_head + (tb - first_whole) + n_rest;
+
+    const unsigned x_bytes = (unsigned)a.B * a.H * a.W * a.Cin * 2u, w_bytes = (unsigned)a.Cout * a.K * 2u;
+    const __amdgpu_buffer_rsrc_t r_xhi = __builtin_amdgcn_make_buffer_rsrc((void*)a.xhi, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_xlo = __builtin_amdgcn_make_buffer_rsrc((void*)a.xlo, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_whi = __builtin_amdgcn_make_buffer_rsrc((void*)a.whi, 0, w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_wlo = __builtin_amdgcn_make_buffer_rsrc((void*)a.wlo, 0, w_bytes, 0x00020000);
+    const int srow = tid >> 2, schunk = tid & 3;
+    const int wofs = toff(srow, schunk);
+    const int OHW = a.OH * a.OW, cps = a.Cin / CBK;  // k-steps per tap
+    cu32x4 rg[8];
+    // fragment addressing
+    const int ar_ = 64 * wr + (lane & 31), br_ = 32 * NI * wc + (lane & 31), kh_ = lane >> 5;
+    const int arow = ar_ * CROW, brow = br_ * CROW;
+    const int ak0 = ((kh_ ^ ((ar_ >> 2) & 3)) << 3), ak1 = (((kh_ + 2) ^ ((ar_ >> 2) & 3)) << 3);
+    const int bk0 = ((kh_ ^ ((br_ >> 2) & 3)) << 3), bk1 = (((kh_ + 2) ^ ((br_ >> 2) & 3)) << 3);
+
+    for (int seg = 0; seg < n_seg; ++seg) {
+        const bool is_dp = seg < rounds_dp;
+        const bool is_head = !is_dp && seg - rounds_dp < n_head;
+        const bool is_rest = !is_dp && n_rest && seg == n_seg - 1;
+        const int t = is_dp ? seg * slots_x + n : n_dp + (is_head ? tb : (is_rest ? ta : first_whole + seg - rounds_dp - n_head));
+        const int s0 = is_rest ? sa : 0, s1 = is_head ? sb : nstep;
+        const int q = t_lo + t;
+        const int i0 = (q / a.tiles_j) * CT, j0 = (q % a.tiles_j) * JT;  // j fastest: the co tiles of one pixel tile are neighbours
+
+        // ---- gather state of this thread's two pixel rows (srow, srow + 128): byte offset of (b, oy*stride-pad, ox*stride-pad, 0)
+        // and one validity bit per tap (KH*KW <= 9)
+        int pbase[2];
+        unsigned pvalid[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pix = i0 + srow + 128 * h;
+            const int b = pix / OHW, rem = pix - b * OHW;
+            const int oy = rem / a.OW, ox = rem - oy * a.OW;
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            pbase[h] = (((b * a.H + iy0) * a.W + ix0) * a.Cin) * 2 + schunk * 16;
+            unsigned m = 0;
+            for (int dy = 0; dy < a.KH; ++dy)
+                for (int dx = 0; dx < a.KW; ++dx)
+                    if (iy0 + dy >= 0 && iy0 + dy < a.H && ix0 + dx >= 0 && ix0 + dx < a.W) m |= 1u << (dy * a.KW + dx);
+            pvalid[h] = m;
+        }
+        // weights: rows j0 + srow (+128) of (Cout, K); rows past Cout (Cout = 192 in a 256-row plane) read as zeros
+        unsigned wvoff[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int co = j0 + srow + 128 * h;
+            wvoff[h] = (srow + 128 * h < JT && co < a.Cout) ? (unsigned)co * (unsigned)a.K * 2u + (unsigned)schunk * 16u : kOob;
+        }
+
+        f32x16 acc[2][NI];
+        if (is_rest) {
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(a.flags + (p - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > kSpin) {
+                        __hip_atomic_store(a.flags + kErrWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gp_raise(a.status, GP_ST_HANDOFF_SPLIT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            const f32x4* w = reinterpret_cast<const f32x4*>(a.partial + (size_t)(p - 8) * kFragFloats) + tid * 32;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 v = w[(mi * 4 + ni) * 4 + r4];
+                        acc[mi][ni][r4 * 4 + 0] = v[0]; acc[mi][ni][r4 * 4 + 1] = v[1];
+                        acc[mi][ni][r4 * 4 + 2] = v[2]; acc[mi][ni][r4 * 4 + 3] = v[3];
+                    }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
+
+        // ---- k loop over steps [s0, s1)
+        const int ns = s1 - s0;
+        auto gload = [&](int slab) {
+            const int s = s0 + slab;
+            const int tap = s / cps, c0 = s - tap * cps;
+            const int dy = tap / a.KW, dx = tap - dy * a.KW;
+            const int toffb = ((dy * a.W + dx) * a.Cin + c0 * CBK) * 2;  // wave-uniform: one tap, 32 channels per k-step
+            const unsigned v0 = ((pvalid[0] >> tap) & 1u) ? (unsigned)(pbase[0] + toffb) : kOob;
+            const unsigned v1 = ((pvalid[1] >> tap) & 1u) ? (unsigned)(pbase[1] + toffb) : kOob;
+            const unsigned sw = (unsigned)s * (CBK * 2u);
+            rg[0] = __builtin_amdgcn_raw_buffer_load_b128(r_xhi, v0, 0, 0);
+            rg[1] = __builtin_amdgcn_raw_buffer_load_b128(r_xhi, v1, 0, 0);
+            rg[2] = __builtin_amdgcn_raw_buffer_load_b128(r_xlo, v0, 0, 0);
+            rg[3] = __builtin_amdgcn_raw_buffer_load_b128(r_xlo, v1, 0, 0);
+            rg[4] = __builtin_amdgcn_raw_buffer_load_b128(r_whi, wvoff[0], sw, 0);
+            rg[6] = __builtin_amdgcn_raw_buffer_load_b128(r_wlo, wvoff[0], sw, 0);
+            if (NI > 2) {
+                rg[5] = __builtin_amdgcn_raw_buffer_load_b128(r_whi, wvoff[1], sw, 0);
+                rg[7] = __builtin_amdgcn_raw_buffer_load_b128(r_wlo, wvoff[1], sw, 0);
+            }
+        };
+        auto stage = [&](int buf) {
+            _Float16* L = lds + buf * CBUF + wofs;
+            *reinterpret_cast<cu32x4*>(L + P_AHI) = rg[0];
+            *reinterpret_cast<cu32x4*>(L + P_AHI + 128 * CROW) = rg[1];
+            *reinterpret_cast<cu32x4*>(L + P_ALO) = rg[2];
+            *reinterpret_cast<cu32x4*>(L + P_ALO + 128 * CROW) = rg[3];
+            *reinterpret_cast<cu32x4*>(L + P_BHI) = rg[4];
+            *reinterpret_cast<cu32x4*>(L + P_BLO) = rg[6];
+            if (NI > 2) {
+                *reinterpret_cast<cu32x4*>(L + P_BHI + 128 * CROW) = rg[5];
+                *reinterpret_cast<cu32x4*>(L + P_BLO + 128 * CROW) = rg[7];
+            }
+        };
+        gload(0);
+        stage(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ns > 1) gload(1);
+        __syncthreads();
+
+#define C_MFMA(A_, B_, mi, ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[mi], B_[ni], acc[mi][ni], 0, 0, 0)
+        auto c_phase = [&](int s) __attribute__((always_inline)) {
+            const _Float16* L = lds + (s & 1) * CBUF;
+            __builtin_amdgcn_s_setprio(1);
+            c16x8 ah[2], al[2], bh[NI], bl[NI], ch[2], cl[2], dh[NI], dl[NI];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) ah[mi] = *reinterpret_cast<const c16x8*>(L + P_AHI + arow + mi * 32 * CROW + ak0);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bh[ni] = *reinterpret_cast<const c16x8*>(L + P_BHI + brow + ni * 32 * CROW + bk0);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bl[ni] = *reinterpret_cast<const c16x8*>(L + P_BLO + brow + ni * 32 * CROW + bk0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) al[mi] = *reinterpret_cast<const c16x8*>(L + P_ALO + arow + mi * 32 * CROW + ak0);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) { C_MFMA(ah, bh, 0, ni); C_MFMA(ah, bh, 1, ni); }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) { C_MFMA(ah, bl, 0, ni); C_MFMA(ah, bl, 1, ni); }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) ch[mi] = *reinterpret_cast<const c16x8*>(L + P_AHI + arow + mi * 32 * CROW + ak1);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) dh[ni] = *reinterpret_cast<const c16x8*>(L + P_BHI + brow + ni * 32 * CROW + bk1);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) { C_MFMA(al, bh, 0, ni); C_MFMA(al, bh, 1, ni); }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) dl[ni] = *reinterpret_cast<const c16x8*>(L + P_BLO + brow + ni * 32 * CROW + bk1);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) cl[mi] = *reinterpret_cast<const c16x8*>(L + P_ALO + arow + mi * 32 * CROW + ak1);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) { C_MFMA(ch, dh, 0, ni); C_MFMA(ch, dh, 1, ni); }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) { C_MFMA(ch, dl, 0, ni); C_MFMA(ch, dl, 1, ni); }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) { C_MFMA(cl, dh, 0, ni); C_MFMA(cl, dh, 1, ni); }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto m_phase = [&](int slab) __attribute__((always_inline)) {  // stages `slab`, loads slab + 1
+            if (slab < ns) stage(slab & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            gload(min(slab + 1, ns - 1));
+        };
+        //     waves 0-3:  C0 M1 | C1 M2 | ...          waves 4-7:  M1 C0 | M2 C1 | ...        (| = the one barrier per k-step)
+        if (grp) m_phase(1);
+        for (int s = 0; s < ns; ++s) {
+            c_phase(s);
+            if (grp && s + 1 < ns) __syncthreads();
+            m_phase(s + 1 + grp);
+            if (!grp && s + 1 < ns) __syncthreads();
+        }
+#undef C_MFMA
+
+        if (is_head) {  // publish the fragment for slot n + 1 (agent-scope release by one lane)
+            f32x4* w = reinterpret_cast<f32x4*>(a.partial + (size_t)p * kFragFloats) + tid * 32;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        f32x4 v;
+                        v[0] = acc[mi][ni][r4 * 4 + 0]; v[1] = acc[mi][ni][r4 * 4 + 1];
+                        v[2] = acc[mi][ni][r4 * 4 + 2]; v[3] = acc[mi][ni][r4 * 4 + 3];
+                        w[(mi * 4 + ni) * 4 + r4] = v;
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(a.flags + p, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            // ---- epilogue through LDS: per wave 32 pixel rows x 32 NI channels of f32 at a time (16 KiB regions, wave-private)
+            int tid_ = threadIdx.x;
+            asm volatile("" : "+v"(tid_));
+            __syncthreads();  // every wave has read its last operand fragments
+            const int ln = tid_ & 63, l31 = ln & 31;
+            float* wl = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + (tid_ >> 6) * 16384);
+            constexpr int WC = 32 * NI, QPR = 8 * NI;  // f32 columns / 4-column quads per row of the wave tile
+            int bad = 0;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) wl[frag_row(r, ln) * WC + 32 * ni + l31] = acc[mi][ni][r];
+#pragma unroll
+                for (int it = 0; it < 4 * NI; ++it) {
+                    const int f = it * 64 + ln, row = f / QPR, qd = f - row * QPR;
+                    const f32x4 tv = *reinterpret_cast<const f32x4*>(wl + row * WC + 4 * qd);
+                    const int pix = i0 + 64 * wr + 32 * mi + row, co = j0 + WC * wc + 4 * qd;
+                    if (co < a.Cout) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = tv[e] * kOutScale;
+                        if (a.alpha) {
+                            const f32x4 al4 = *reinterpret_cast<const f32x4*>(a.alpha + co), be4 = *reinterpret_cast<const f32x4*>(a.beta + co);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] * al4[e] + be4[e];
+                        }
+                        const size_t o = (size_t)pix * a.Cout + co;
+                        if (a.rhi) {
+                            const c16x4 rh = *reinterpret_cast<const c16x4*>(a.rhi + o), rl = *reinterpret_cast<const c16x4*>(a.rlo + o);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = ((float)rh[e] + (float)rl[e]) * (1.0f / kActScale) + v[e];
+                        }
+                        if (a.relu)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        if (a.of32) {  // (B, Cout, OH, OW): the last layer only
+                            const int b = pix / OHW, rem = pix - b * OHW;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a.of32[((size_t)b * a.Cout + co + e) * OHW + rem] = v[e];
+                        } else {
+                            c16x4 oh, ol;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float s8 = v[e] * kActScale;
+                                const _Float16 hh = (_Float16)s8;
+                                oh[e] = hh;
+                                ol[e] = (_Float16)(s8 - (float)hh);
+                                bad |= !(fabsf(s8) <= kSplitPlaneLimit);
+                            }
+                            *reinterpret_cast<c16x4*>(a.ohi + o) = oh;
+                            *reinterpret_cast<c16x4*>(a.olo + o) = ol;
+                        }
+                    }
+                }
+            }
+            if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE);
+            __syncthreads();  // LDS buffer 0 is re-staged by the next segment's prologue
+        }
+    }
+}
+
+// [C][npix] f32 (the f32 stem's channel-major output) -> planes [npix][C] of 8 x (hi + lo, unscaled lo).  32 x 32 tiles through LDS.
+__global__ __launch_bounds__(256) void planes_from_cm_kernel(const float* __restrict__ X, int C, int npix, _Float16* __restrict__ hi,
+                                                              _Float16* __restrict__ lo, int* __restrict__ status)
+{
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) t[r][tx] = (c0 + r < C && p0 + tx < npix) ? X[(size_t)(c0 + r) * npix + p0 + tx] : 0.f;
+    __syncthreads();
+    int bad = 0;
+    for (int r = ty; r < 32; r += 8) {
+        if (p0 + r < npix && c0 + tx < C) {
+            float v = t[tx][r] * kActScale;
+            const _Float16 h = (_Float16)v;
+            hi[(size_t)(p0 + r) * C + c0 + tx] = h;
+            lo[(size_t)(p0 + r) * C + c0 + tx] = (_Float16)(v - (float)h);
+            bad |= !(fabsf(v) <= kSplitPlaneLimit);
+        }
+    }
+    if (bad) gp_raise(status, GP_ST_SPLIT_RANGE);
+}
+
+unsigned g_epoch_conv = 0;
+
+}  // namespace
+
+extern "C" {
+
+size_t gp_conv2d_planes_workspace_bytes(void) { return kHeaderBytes + sizeof(float) * kFragFloats * kSlots; }
+
+int gp_planes_from_cm(const float* X, int C, int npix, void* hi, void* lo, void* stream)
+{
+    GP_REQUIRE(X && hi && lo && C > 0 && npix > 0, "gp_planes_from_cm: bad arguments");
+    hipLaunchKernelGGL(planes_from_cm_kernel, dim3((npix + 31) / 32, (C + 31) / 32), dim3(256), 0, (hipStream_t)stream, X, C, npix,
+                       (_Float16*)hi, (_Float16*)lo, gp_status_buffer());
+    GP_CHECK_LAUNCH("gp_planes_from_cm");
+    return GP_OK;
+}
+
+int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* alpha, const float* beta,
+                     const void* res_hi, const void* res_lo, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                     int relu, void* out_hi, void* out_lo, float* out_f32_nchw, float* scratch, size_t scratch_bytes, void* stream)
+{
+    GP_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "gp_conv2d_planes: bad sizes");
+    if (B == 0) return GP_OK;
+    ConvPArgs a;
+    a.xhi = (const _Float16*)x_hi; a.xlo = (const _Float16*)x_lo; a.whi = (const _Float16*)w_hi; a.wlo = (const _Float16*)w_lo;
+    a.alpha = alpha; a.beta = beta; a.rhi = (const _Float16*)res_hi; a.rlo = (const _Float16*)res_lo;
+    a.ohi = (_Float16*)out_hi; a.olo = (_Float16*)out_lo; a.of32 = out_f32_nchw;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu;
+    a.OH = (H + 2 * pad - KH) / stride + 1;
+    a.OW = (W + 2 * pad - KW) / stride + 1;
+    a.K = KH * KW * Cin;
+    const long long npix = (long long)B * a.OH * a.OW;
+    GP_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0 && KH * KW <= 9, "gp_conv2d_planes: Cin=%d must be a multiple of 32, Cout=%d of 64, at most 9 taps", Cin, Cout);
+    GP_REQUIRE(npix % CT == 0 && (long long)B * H * W * Cin * 2 < (1ll << 31) && (long long)Cout * a.K * 2 < (1ll << 31) && npix * Cout < (1ll << 31),
+               "gp_conv2d_planes: B*OH*OW=%lld must be a multiple of 256 and every plane below 2 GiB", npix);
+    GP_REQUIRE(x_hi && x_lo && w_hi && w_lo && ((out_hi && out_lo) || out_f32_nchw), "gp_conv2d_planes: null pointer");
+    GP_REQUIRE((alpha == nullptr) == (beta == nullptr) && (res_hi == nullptr) == (res_lo == nullptr), "gp_conv2d_planes: alpha/beta and res_hi/res_lo go together");
+    GP_REQUIRE(scratch && scratch_bytes >= gp_conv2d_planes_workspace_bytes() && ((uintptr_t)scratch % 16 == 0), "gp_conv2d_planes: scratch too small");
+    GP_REQUIRE(((uintptr_t)x_hi % 16 == 0) && ((uintptr_t)x_lo % 16 == 0) && ((uintptr_t)w_hi % 16 == 0) && ((uintptr_t)w_lo % 16 == 0) &&
+                   ((uintptr_t)alpha % 16 == 0) && ((uintptr_t)beta % 16 == 0), "gp_conv2d_planes: misaligned operand");
+    const int ni = Cout >= 256 ? 4 : Cout / 64;  // 128 -> 2, 192 -> 3, >= 256 -> 4
+    a.tiles_i = (int)(npix / CT);
+    a.tiles_j = (Cout + 64 * ni - 1) / (64 * ni);
+    hipStream_t st = (hipStream_t)stream;
+    // slots: all 256 CUs unless there are fewer tiles than slots AND so little work that cutting tiles would leave a slot with
+    // under 32 k-steps per hand-over (the 1 x 1 head: 64 tiles x 16 steps -> 32 slots of two whole tiles)
+    const long long n_tiles = (long long)a.tiles_i * a.tiles_j, units = n_tiles * (a.K / CBK);
+    int slots_x = 32;
+    while (slots_x > 1 && n_tiles < 8 * slots_x && units / (8 * slots_x) < 32) slots_x >>= 1;
+    if (hipMemsetAsync(scratch, 0, kHeaderBytes, st) != hipSuccess) return GP_ELAUNCH;
+    a.flags = reinterpret_cast<int*>(scratch);
+    a.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes);
+    g_epoch_conv = (g_epoch_conv + 1) & 0x3fffffff;
+    a.epoch = (int)(0x20000000u | g_epoch_conv);
+    a.status = gp_status_buffer();
+    GpProfScope prof(GP_PROF_CONV, 2.0 * Cout * (double)npix * a.K, st);
+    if (ni == 2) hipLaunchKernelGGL(conv_planes_kernel<2>, dim3(8 * slots_x), dim3(CNT), 0, st, a);
+    else if (ni == 3) hipLaunchKernelGGL(conv_planes_kernel<3>, dim3(8 * slots_x), dim3(CNT), 0, st, a);
+    else hipLaunchKernelGGL(conv_planes_kernel<4>, dim3(8 * slots_x), dim3(CNT), 0, st, a);
+    GP_CHECK_LAUNCH("gp_conv2d_planes");
+    return GP_OK;
+}
+
+}  // extern "C"

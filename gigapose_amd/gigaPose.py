@@ -161,11 +161,15 @@ class GigaPose(_Base):
         tar_ae = self.ae_net(tar_img)                                            # stage 1: ViT features
         if self.template_shard is None:
             pred = self.testing_metric.test_bank(bank, tar_ae, tar_mask, labels0)  # stage 3: matching
+            if side is None:
+                tar_ist = self.ist_net.forward_by_chunk(tar_img)                 # stage 4a: IST backbone (once)
         else:
-            pred = bank.test_bank(tar_ae, tar_mask, labels0)                      # sharded bank + all-gathers
-        if side is None:
-            tar_ist = self.ist_net.forward_by_chunk(tar_img)                     # stage 4a: IST backbone (once)
-        else:
+            # sharded bank: exchange #1 (query features to every rank) travels while the IST backbone runs
+            pending = bank.start_exchange(tar_ae, tar_mask, labels0)
+            if side is None:
+                tar_ist = self.ist_net.forward_by_chunk(tar_img)
+            pred = bank.finish(pending)                                          # match the shard + exchange #2 + merge
+        if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             tar_ist.record_stream(torch.cuda.current_stream())
         rel_scale, rel_inplane = self.ist_net.regress_bank(template_data.ist_features, labels0, pred.id_src,

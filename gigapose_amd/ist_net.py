@@ -60,7 +60,12 @@ class ResNet(nn.Module):
         self._bufs = None
         self._resized = None
         self._split = None
+        self._planes = None
+        self._conv_scratch = None
         self.numerics = os.environ.get("GIGAPOSE_NUMERICS", "chain")  # "chain" | "split" 
+        # split numerics: "256" = conv_planes_kernel (gp_conv256.hip: 256-pixel tiles, single accumulator, plane GEMM loop;
+        # needs B*OH*OW % 256 == 0, always true from the 16 x 16 output grid up); "128" = the first-generation 128 x 128 kernel
+        self.conv_kernel = os.environ.get("GIGAPOSE_SPLIT_CONV", "256")
 
     def set_numerics(self, mode):
         if mode not in ("chain", "split"):
@@ -72,6 +77,7 @@ class ResNet(nn.Module):
         """Drop the packed (folded-BN / split-plane) weight copies; they are rebuilt at the next forward."""
         self._packed = None
         self._split = None
+        self._planes = None
 
     def _load_from_state_dict(self, *a, **k):
         # nn.Module.load_state_dict on ANY ancestor (GigaPose, a Lightning checkpoint load) recurses through here
@@ -134,6 +140,38 @@ class ResNet(nn.Module):
             for blk in getattr(self, f"layer{li}"):
                 blocks.append((conv(blk.conv1), conv(blk.conv2), None if blk.downsample is None else conv(blk.downsample[0])))
         self._split = dict(device=device, blocks=blocks, out=conv(self.layer4_outconv))
+
+    @torch.no_grad()
+    def _pack_planes(self, device):
+        """conv_planes_kernel's weights: (Cout, KH*KW*Cin) planes of 64 w (hi + lo, unscaled lo), k = (dy, dx, ci)."""
+        from .vit import split_planes_x64
+
+        def conv(c):
+            co, ci, kh, kw = c.weight.shape
+            return split_planes_x64(c.weight.detach().float().to(device).permute(0, 2, 3, 1).reshape(co, kh * kw * ci).contiguous())
+
+        blocks = []
+        for li in range(1, 5):
+            for blk in getattr(self, f"layer{li}"):
+                blocks.append((conv(blk.conv1), conv(blk.conv2), None if blk.downsample is None else conv(blk.downsample[0])))
+        self._planes = dict(device=device, blocks=blocks, out=conv(self.layer4_outconv))
+
+    def _conv_planes(self, cv, w, x, y, B, H, W, residual=None, relu=True, out_f32=None):
+        """x, y, residual: (hi, lo) f16 plane pairs, channel-last, x 8 (gp_conv2d_planes)."""
+        dev = x[0].device
+        lib = _lib.lib()
+        lib.gp_conv2d_planes_workspace_bytes.restype = ctypes.c_size_t
+        need = lib.gp_conv2d_planes_workspace_bytes()
+        if self._conv_scratch is None or self._conv_scratch.device != dev:
+            self._conv_scratch = torch.zeros((need + 3) // 4, dtype=torch.float32, device=dev)
+        _lib.call("gp_conv2d_planes", _lib.ptr(x[0]), _lib.ptr(x[1]), _lib.ptr(w[0]), _lib.ptr(w[1]),
+                  _lib.ptr(cv["alpha"]), _lib.ptr(cv["beta"]), _lib.ptr(None if residual is None else residual[0]),
+                  _lib.ptr(None if residual is None else residual[1]), _lib.i(B), _lib.i(H), _lib.i(W), _lib.i(cv["cin"]),
+                  _lib.i(cv["cout"]), _lib.i(cv["k"]), _lib.i(cv["k"]), _lib.i(cv["stride"]), _lib.i(cv["pad"]),
+                  _lib.i(1 if relu else 0), _lib.ptr(None if y is None else y[0]), _lib.ptr(None if y is None else y[1]),
+                  _lib.ptr(out_f32), _lib.ptr(self._conv_scratch), ctypes.c_size_t(need), _lib.stream_ptr())
+        oh = (H + 2 * cv["pad"] - cv["k"]) // cv["stride"] + 1
+        return oh, (W + 2 * cv["pad"] - cv["k"]) // cv["stride"] + 1
 
     def _conv_split(self, cv, w, x, y, B, H, W, residual=None, relu=True, out_f32=None):
         """x, y, residual: (hi, lo) f16 plane pairs, channel-last."""
@@ -200,10 +238,17 @@ class ResNet(nn.Module):
         (7x7/2 on 3 channels, 1.6 % of the FLOPs) stays the f32 kernel; its channel-major output is split + transposed
         once.  The plane buffers alias the f32 ping-pong buffers (same bytes: 2 planes x f16 = f32)."""
         dev = stem_out.device
-        if self._split is None or self._split["device"] != dev:
-            self._pack_split(dev)
         c0 = pk["stem"]["cout"]
         npix = B * H * W
+        use256 = self.conv_kernel == "256"   # every later layer has B*OH*OW = B * 256 * 4^n pixels: multiples of 256
+        if use256:
+            if self._planes is None or self._planes["device"] != dev:
+                self._pack_planes(dev)
+            weights, conv = self._planes, self._conv_planes
+        else:
+            if self._split is None or self._split["device"] != dev:
+                self._pack_split(dev)
+            weights, conv = self._split, self._conv_split
 
         def planes(buf):  # one f32 buffer -> (hi, lo) f16 planes of the same total size
             h = buf.view(torch.float16)
@@ -215,18 +260,21 @@ class ResNet(nn.Module):
             self._stem_planes = (torch.empty(c0 * npix, dtype=torch.float16, device=dev),
                                  torch.empty(c0 * npix, dtype=torch.float16, device=dev))
         cur = self._stem_planes
-        _lib.call("gp_split_weights", _lib.ptr(stem_out), _lib.i(c0), _lib.i(npix), _lib.i(npix), _lib.ptr(cur[0]),
-                  _lib.ptr(cur[1]), _lib.stream_ptr())                           # [C][npix] f32 -> [npix][C] planes
-        for (c1, c2, ds), (w1, w2, wd) in zip(pk["blocks"], self._split["blocks"]):
-            oh, ow = self._conv_split(c1, w1, cur, y1, B, H, W)                 # relu(bn1(conv1(x)))
+        if use256:   # [C][npix] f32 -> [npix][C] planes of 8 x (single-accumulator convention)
+            _lib.call("gp_planes_from_cm", _lib.ptr(stem_out), _lib.i(c0), _lib.i(npix), _lib.ptr(cur[0]), _lib.ptr(cur[1]), _lib.stream_ptr())
+        else:        # ... of x with the low half scaled by 2^11 (two-accumulator convention)
+            _lib.call("gp_split_weights", _lib.ptr(stem_out), _lib.i(c0), _lib.i(npix), _lib.i(npix), _lib.ptr(cur[0]),
+                      _lib.ptr(cur[1]), _lib.stream_ptr())
+        for (c1, c2, ds), (w1, w2, wd) in zip(pk["blocks"], weights["blocks"]):
+            oh, ow = conv(c1, w1, cur, y1, B, H, W)                             # relu(bn1(conv1(x)))
             short = cur
             if ds is not None:
-                self._conv_split(ds, wd, cur, sc, B, H, W, relu=False)          # bn(conv1x1(x))
+                conv(ds, wd, cur, sc, B, H, W, relu=False)                      # bn(conv1x1(x))
                 short = sc
-            self._conv_split(c2, w2, y1, nxt, B, oh, ow, residual=short)        # relu(shortcut + bn2(conv2(.)))
+            conv(c2, w2, y1, nxt, B, oh, ow, residual=short)                    # relu(shortcut + bn2(conv2(.)))
             cur, nxt = nxt, cur
             H, W = oh, ow
-        self._conv_split(pk["out"], self._split["out"], cur, None, B, H, W, relu=False, out_f32=out)
+        conv(pk["out"], weights["out"], cur, None, B, H, W, relu=False, out_f32=out)
         return out
 
 

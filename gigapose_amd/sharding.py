@@ -36,16 +36,46 @@ def shard_bounds(n_templates, world, rank):
     return lo, hi
 
 
+def all_gather_rows(rows, group=None, async_op=False):
+    """ONE collective: every rank contributes the same number of equal-length u8 rows (n, L); returns ((W*n, L) in rank
+    order, work handle or None).  all_gather_into_tensor = a single RCCL ncclAllGather over the flat buffer (payloads
+    here are a few MB at most: latency-bound, one launch instead of one per tensor)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 and not _always_collective():
+        return rows, None
+    rows = rows.contiguous()
+    out = torch.empty((world * rows.shape[0],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    work = dist.all_gather_into_tensor(out, rows, group=group, async_op=async_op)
+    return out, (work if async_op else None)
+
+
 def all_gather_cat(t, group=None):
     """all-gather equal-shaped tensors and concatenate along dim 0 (rank order); tuples element-wise."""
     if isinstance(t, (tuple, list)):
         return tuple(all_gather_cat(x, group) for x in t)
-    world = dist.get_world_size(group)
-    if world == 1 and not _always_collective():
-        return t
-    outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t.contiguous(), group=group)
-    return torch.cat(outs, dim=0)
+    return all_gather_rows(t, group)[0]
+
+
+def pack_query(q, qmask, labels0):
+    """Exchange #1 payload, one byte row per crop: matcher-normalised features (f32 (B,C,256), or the f16 hi / lo planes
+    (B,256,Cp) of the split numerics) | patch mask f32[256] | label i32.  Returns (rows (B, L) u8, layout)."""
+    B = qmask.shape[0]
+    feats = list(q) if isinstance(q, (tuple, list)) else [q]
+    parts = [f.contiguous().view(torch.uint8).reshape(B, -1) for f in feats]
+    layout = [(tuple(f.shape[1:]), f.dtype, p.shape[1]) for f, p in zip(feats, parts)]
+    parts += [qmask.contiguous().view(torch.uint8).reshape(B, 4 * P), labels0.to(torch.int32).contiguous().view(torch.uint8).reshape(B, 4)]
+    return torch.cat(parts, dim=1), layout
+
+
+def unpack_query(rows, layout):
+    """Inverse of pack_query for (n, L) u8 rows: (features or (hi, lo)), qmask (n,256) f32, labels (n,) i32."""
+    n, o, feats = rows.shape[0], 0, []
+    for shape, dtype, nbytes in layout:
+        feats.append(rows[:, o:o + nbytes].contiguous().view(dtype).reshape(n, *shape))
+        o += nbytes
+    qmask = rows[:, o:o + 4 * P].contiguous().view(torch.float32).reshape(n, P)
+    labels = rows[:, o + 4 * P:o + 4 * P + 4].contiguous().view(torch.int32).reshape(n)
+    return (feats[0] if len(feats) == 1 else tuple(feats)), qmask, labels
 
 
 def pack_candidates(ids_global, scores, rec_idx, rec_score, rec_mask):
@@ -85,9 +115,9 @@ def exchange_and_merge(local_rows, n_own, k, rank, group=None):
     Returns merged ids (B,k) i64, scores (B,k), rec_idx/rec_score/rec_mask (B,k,256) for OWN crops."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world > 1 or _always_collective():
-        outs = [torch.empty_like(local_rows) for _ in range(world)]
-        dist.all_gather(outs, local_rows, group=group)
-        mine = torch.cat([o[rank * n_own:(rank + 1) * n_own] for o in outs], dim=1)  # (B, W*k, REC)
+        allrows, _ = all_gather_rows(local_rows, group)                               # (W * W*B, k, REC), one collective
+        allrows = allrows.reshape(world, -1, k, REC_BYTES)
+        mine = allrows[:, rank * n_own:(rank + 1) * n_own].permute(1, 0, 2, 3).reshape(n_own, world * k, REC_BYTES)
     else:
         mine = local_rows
     ids, sc, ridx, rsc, rma = unpack_candidates(mine)
@@ -109,22 +139,34 @@ class ShardedMatcher:
             raise ValueError(f"shard of {bank_shard.N} templates is smaller than k={metric.k}")
 
     @torch.no_grad()
-    def test_bank(self, tar_feat, tar_mask, labels0):
+    def start_exchange(self, tar_feat, tar_mask, labels0):
+        """Exchange #1, asynchronous: pack this rank's matcher-normalised query features, patch masks and labels into one byte
+        row per crop and all-gather them in ONE collective.  RCCL runs it on its own stream; the caller keeps launching
+        independent work (the IST backbone, gigaPose.py) and calls finish() when it needs the matches."""
+        from .matching import patch_grid_mask
+
+        rows, layout = pack_query(self.metric.normalize(tar_feat), patch_grid_mask(tar_mask), labels0)
+        allrows, work = all_gather_rows(rows, self.group, async_op=True)
+        return dict(rows=allrows, work=work, layout=layout, n_own=tar_feat.shape[0])
+
+    @torch.no_grad()
+    def finish(self, h):
         import pandas as pd
 
-        from .matching import patch_grid_mask
         from .tensor_collection import PandasTensorCollection
 
         m = self.metric
-        n_own = tar_feat.shape[0]
-        q = all_gather_cat(m.normalize(tar_feat), self.group)                       # exchange #1 (f32, or f16 hi/lo planes)
-        qmask = all_gather_cat(patch_grid_mask(tar_mask), self.group)
-        labels_all = all_gather_cat(labels0.to(torch.int32).contiguous(), self.group)
+        if h["work"] is not None:
+            h["work"].wait()                                                          # current stream waits for the collective
+        q, qmask, labels_all = unpack_query(h["rows"], h["layout"])
         idx, sc, ma, avg = m.match_tiles(q, qmask, self.bank, labels_all)
         ids, score = m.topk(avg)
         rec_idx, rec_score, rec_mask = m.gather_records(ids, idx, sc, ma)
         rows = pack_candidates(ids.long() + self.lo, score, rec_idx, rec_score, rec_mask)
-        gid, gsc, ridx, rsc, rma = exchange_and_merge(rows, n_own, m.k, self.rank, self.group)  # exchange #2
+        gid, gsc, ridx, rsc, rma = exchange_and_merge(rows, h["n_own"], m.k, self.rank, self.group)  # exchange #2
         tar_pts, src_pts = m.format_points(ridx.contiguous(), rma.contiguous())
         return PandasTensorCollection(infos=pd.DataFrame(), id_src=gid, score_src=gsc, score_pts=rsc.contiguous(),
                                       tar_pts=tar_pts, src_pts=src_pts)
+
+    def test_bank(self, tar_feat, tar_mask, labels0):
+        return self.finish(self.start_exchange(tar_feat, tar_mask, labels0))

@@ -269,6 +269,19 @@ int gp_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* w_hi, c
                          int KH, int KW, int stride, int pad, int relu, void* out_hi, void* out_lo, float* out_f32_nchw,
                          void* stream);
 
+/* Second-generation split convolution (gp_conv256.hip, conv_planes_kernel): the plane GEMM's structure as an implicit
+ * GEMM -- 256-pixel x (128 | 192 | 256)-channel tiles, ONE accumulator, half-step-offset wave groups, stream-K remainder,
+ * epilogue through LDS.  Same operation and argument meaning as gp_conv2d_nhwc_split, but the planes follow the
+ * single-accumulator convention of gp_gemm_planes256: activations / residual / output hi = f16(8 x), lo = f16(8 x - hi)
+ * (|x| < 8190, guarded through the status word), weights (Cout, KH*KW*Cin) planes of 64 w (gp_split256_weights), k =
+ * (dy*KW + dx)*Cin + ci.  Requires Cin % 32 == 0, Cout % 64 == 0, KH*KW <= 9, B*OH*OW % 256 == 0; scratch of
+ * gp_conv2d_planes_workspace_bytes() bytes (stream-K hand-overs).  gp_planes_from_cm: f32 [C][npix] -> such planes [npix][C]. */
+size_t gp_conv2d_planes_workspace_bytes(void);
+int gp_planes_from_cm(const float* X, int C, int npix, void* hi, void* lo, void* stream);
+int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* alpha, const float* beta,
+                     const void* res_hi, const void* res_lo, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                     int relu, void* out_hi, void* out_lo, float* out_f32_nchw, float* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- IST regressor: ISTNet.inference (src/models/network/ist_net.py:97-120) ----------------- */
 
 size_t gp_ist_workspace_bytes(int B, int k, int D, int H);

@@ -199,6 +199,61 @@ def test_split_conv_vs_f64(cin, cout, k, stride, pad, hw, B, res):
     np.testing.assert_allclose(got_planes, t, rtol=0, atol=3e-6 * max(1.0, np.abs(t).max()))
 
 
+def planes8(t, scale=8.0):
+    """f32 tensor -> (hi, lo) planes of scale * t in the single-accumulator convention (gp_split_planes)."""
+    t = t.contiguous()
+    hi = torch.empty(t.shape, dtype=torch.float16, device=t.device)
+    lo = torch.empty_like(hi)
+    _lib.call("gp_split_planes", _lib.ptr(t), ctypes.c_size_t(t.numel()), _lib.f(scale), _lib.ptr(hi), _lib.ptr(lo), _lib.stream_ptr())
+    return hi, lo
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,hw,B,res", [
+    (128, 128, 3, 1, 1, 32, 2, True),     # NI = 2 (layer1 shape), 8 whole tiles on few slots
+    (128, 192, 3, 2, 1, 32, 4, False),    # NI = 3, stride 2 (layer2 entry); 4 tiles
+    (128, 192, 1, 2, 0, 32, 4, False),    # 1 x 1 stride-2 shortcut, K = 128 (4 k-steps)
+    (256, 512, 3, 2, 1, 32, 4, False),    # two co tiles (NI = 4), K = 2304; 8 tiles x 72 steps: few tiles -> cut into k ranges with hand-overs
+    (512, 256, 1, 1, 0, 16, 4, False),    # the head: 1 x 1, f32 NCHW output too
+    (192, 192, 3, 1, 1, 64, 16, True),    # 256 tiles = one whole tile per slot, residual
+])
+def test_conv_planes_vs_f64(cin, cout, k, stride, pad, hw, B, res):
+    """gp_conv2d_planes (gp_conv256.hip) against an f64 convolution + BN + residual + ReLU: both outputs (planes, f32 NCHW)."""
+    rs = np.random.RandomState(cin + cout + k + hw)
+    X = (rs.standard_normal((B, hw, hw, cin)) * rs.uniform(0.2, 3.0)).astype(np.float32)        # NHWC
+    Wt = (rs.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    alpha = rs.uniform(0.5, 1.5, cout).astype(np.float32)
+    beta = rs.standard_normal(cout).astype(np.float32)
+    oh = (hw + 2 * pad - k) // stride + 1
+    R = rs.standard_normal((B, oh, oh, cout)).astype(np.float32) if res else None
+    xh, xl = planes8(torch.from_numpy(X).to(DEV))
+    wh, wl = planes8(torch.from_numpy(np.ascontiguousarray(Wt.transpose(0, 2, 3, 1).reshape(cout, -1))).to(DEV), 64.0)
+    rh, rl = planes8(torch.from_numpy(R).to(DEV)) if res else (None, None)
+    oh_, ol_ = torch.zeros(B, oh, oh, cout, dtype=torch.float16, device=DEV), torch.zeros(B, oh, oh, cout, dtype=torch.float16, device=DEV)
+    of32 = torch.zeros(B, cout, oh, oh, device=DEV)
+    ta, tb = torch.from_numpy(alpha).to(DEV), torch.from_numpy(beta).to(DEV)
+    lib = _lib.lib()
+    lib.gp_conv2d_planes_workspace_bytes.restype = ctypes.c_size_t
+    nb = lib.gp_conv2d_planes_workspace_bytes()
+    ws = torch.zeros(nb // 4, device=DEV)
+    _lib.status_word(DEV).zero_()
+    for out_f32 in (None, of32):
+        _lib.call("gp_conv2d_planes", _lib.ptr(xh), _lib.ptr(xl), _lib.ptr(wh), _lib.ptr(wl), _lib.ptr(ta), _lib.ptr(tb), _lib.ptr(rh), _lib.ptr(rl),
+                  _lib.i(B), _lib.i(hw), _lib.i(hw), _lib.i(cin), _lib.i(cout), _lib.i(k), _lib.i(k), _lib.i(stride), _lib.i(pad), _lib.i(1),
+                  _lib.ptr(oh_), _lib.ptr(ol_), _lib.ptr(out_f32), _lib.ptr(ws), ctypes.c_size_t(nb), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    _lib.check_status()
+    t = torch.nn.functional.conv2d(torch.from_numpy(X).double().permute(0, 3, 1, 2), torch.from_numpy(Wt).double(), stride=stride, padding=pad)
+    t = t * torch.from_numpy(alpha).double()[None, :, None, None] + torch.from_numpy(beta).double()[None, :, None, None]
+    if res:
+        t = t + torch.from_numpy(R).double().permute(0, 3, 1, 2)
+    t = torch.relu(t).numpy()
+    got_planes = ((oh_.double() + ol_.double()) / 8.0).cpu().numpy().transpose(0, 3, 1, 2)
+    tol = max(1.0, np.abs(t).max())
+    print(f"conv planes {cin}->{cout} k{k} s{stride} {hw}x{hw} B={B}: max err / max|y| f32 out {np.abs(of32.cpu().numpy() - t).max() / tol:.2e}, planes {np.abs(got_planes - t).max() / tol:.2e}")
+    np.testing.assert_allclose(of32.cpu().numpy(), t, rtol=0, atol=2e-6 * tol)
+    np.testing.assert_allclose(got_planes, t, rtol=0, atol=3e-6 * tol)
+
+
 def test_ist_backbone_split_vs_chain_and_torch():
     """The whole ResNet in split numerics: as close to the torch f32 reference as the chain kernels."""
     from test_oracle_pose_ist import build_ist
@@ -211,10 +266,13 @@ def test_ist_backbone_split_vs_chain_and_torch():
     net = net.float().to(DEV)
     chain = net.backbone.set_numerics("chain")(x.to(DEV)).cpu().numpy()
     split = net.backbone.set_numerics("split")(x.to(DEV)).cpu().numpy()
+    net.backbone.conv_kernel = "128"                                   # first-generation 128 x 128 two-accumulator kernel
+    split128 = net.backbone(x.to(DEV)).cpu().numpy()
+    net.backbone.conv_kernel = "256"
     scale = np.abs(ref).max()
-    e_chain, e_split = np.abs(chain - ref).max() / scale, np.abs(split - ref).max() / scale
-    print(f"IST backbone vs f64 torch: chain {e_chain:.2e}, split {e_split:.2e} (relative to max |feature|)")
-    assert e_split < 2e-5 and e_split <= 1.5 * e_chain + 1e-7
+    e_chain, e_split, e_128 = (np.abs(v - ref).max() / scale for v in (chain, split, split128))
+    print(f"IST backbone vs f64 torch: chain {e_chain:.2e}, split {e_split:.2e} (conv_planes_kernel), split-128 {e_128:.2e} (relative to max |feature|)")
+    assert e_split < 2e-5 and e_split <= 1.5 * e_chain + 1e-7 and e_128 <= 1.5 * e_chain + 1e-7
 
 
 def split256_gemm(act, W, act_is_b, epi=0, bias=None, scale=None, res=None):

@@ -98,3 +98,103 @@ def test_sharded_exchange_equals_unsharded_world2():
         bsel = np.arange(4)[own][:, None]
         np.testing.assert_array_equal(r["ridx"], full["idx_t2s"][bsel, full["id_src"][own]])
         np.testing.assert_array_equal(r["rma"], full["mask_all"][bsel, full["id_src"][own]])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The ShardedMatcher CLASS itself at world size 2: its kernel-level stages are the only thing replaced -- by a
+# test double that answers normalize / match_tiles / topk / gather_records / format_points from the CPU oracle -- so the
+# product's packing (one byte row per crop), the two single-collective exchanges, the shard offset and the merge run as
+# shipped.  Uneven shards (11 templates -> 6 + 5), labels over two objects, rank-dependent crops.
+class _OracleMetric:
+    def __init__(self, k):
+        self.k, self.numerics = k, "chain"
+
+    def normalize(self, feats):
+        f = feats.numpy()
+        return torch.from_numpy(oracle.l2norm_cp(f.reshape(f.shape[0], f.shape[1], 256)))
+
+    def match_tiles(self, query, qmask, bank, labels0):
+        idx, sc, ma, avg = oracle.match(query.numpy(), bank.features.numpy(), qmask.numpy(), bank.masks.numpy(), labels0.numpy())
+        return torch.from_numpy(idx), torch.from_numpy(sc), torch.from_numpy(ma), torch.from_numpy(avg)
+
+    def topk(self, sim_avg):
+        ids, score = oracle.topk(sim_avg.numpy(), self.k)
+        return torch.from_numpy(ids.astype(np.int32)), torch.from_numpy(score)
+
+    def gather_records(self, ids, idx, sc, ma):
+        b = torch.arange(ids.shape[0])[:, None]
+        i = ids.long()
+        return idx[b, i], sc[b, i], ma[b, i]
+
+    def format_points(self, rec_idx, rec_mask):
+        B, k = rec_idx.shape[:2]      # the oracle formats while gathering: gather the identity selection of the (B, k) records
+        ids = np.tile(np.arange(k, dtype=np.int32), (B, 1))
+        _, tar, src = oracle.gather_format(ids, rec_idx.numpy(), np.zeros((B, k, 256), np.float32), rec_mask.numpy())
+        return torch.from_numpy(tar), torch.from_numpy(src)
+
+
+class _Bank:
+    def __init__(self, case, lo, hi):
+        O, _, C = case["src_feats"].shape[:3]
+        self.features = torch.from_numpy(oracle.l2norm_cp(case["src_feats"][:, lo:hi].reshape(O, hi - lo, C, 256)))
+        self.masks = torch.from_numpy(oracle.patch_mask(case["src_masks"][:, lo:hi]))
+        self.O, self.N, self.C, self.numerics = O, hi - lo, C, "chain"
+
+
+def _class_worker(rank, world, port, case, k, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N = case["src_feats"].shape[1]
+        n_own = case["tar_feat"].shape[0] // world
+        own = slice(rank * n_own, (rank + 1) * n_own)
+        lo, hi = sharding.shard_bounds(N, world, rank)
+        sm = sharding.ShardedMatcher(_OracleMetric(k), _Bank(case, lo, hi), lo)
+        assert (sm.rank, sm.world, sm.lo) == (rank, world, lo)
+        h = sm.start_exchange(torch.from_numpy(case["tar_feat"][own]), torch.from_numpy(case["tar_mask"][own]),
+                              torch.from_numpy(case["labels"][own]))          # exchange #1 in flight ...
+        assert h["rows"].shape[0] == world * n_own and h["rows"].dtype == torch.uint8
+        out = sm.finish(h)                                                      # ... match, exchange #2, merge
+        ret[rank] = {n: v.numpy() for n, v in out.tensors.items()}
+        try:                                                                    # a shard smaller than k is rejected up front
+            sharding.ShardedMatcher(_OracleMetric(hi - lo + 1), _Bank(case, lo, hi), lo)
+            ret[f"reject{rank}"] = False
+        except ValueError:
+            ret[f"reject{rank}"] = True
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_matcher_class_world2_uneven_shards():
+    world, k = 2, 5
+    case = syn.matcher_case(seed=78, B=6, O=2, N=11, C=32)                      # shards of 6 and 5 templates, 3 crops per rank
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_class_worker, args=(world, _free_port(), case, k, ret), nprocs=world, join=True)
+    full = oracle.local_similarity_test(case["src_feats"], case["tar_feat"], case["src_masks"], case["tar_mask"], case["labels"], k)
+    for rank in range(world):
+        own = slice(rank * 3, rank * 3 + 3)
+        r = ret[rank]
+        assert ret[f"reject{rank}"]
+        for name in ["id_src", "tar_pts", "src_pts"]:
+            np.testing.assert_array_equal(r[name], full[name][own], err_msg=name)
+        for name in ["score_src", "score_pts"]:
+            np.testing.assert_array_equal(r[name].view(np.uint32), full[name][own].view(np.uint32), err_msg=name)
+
+
+def test_pack_unpack_query_roundtrip():
+    rs = np.random.RandomState(1)
+    qm = torch.from_numpy(rs.rand(3, 256).astype(np.float32))
+    lab = torch.tensor([2, 0, 1], dtype=torch.int32)
+    f32 = torch.from_numpy(rs.standard_normal((3, 48, 256)).astype(np.float32))
+    rows, layout = sharding.pack_query(f32, qm, lab)
+    assert rows.shape == (3, 48 * 256 * 4 + 1024 + 4)
+    q, m, l = sharding.unpack_query(rows, layout)
+    assert torch.equal(q, f32) and torch.equal(m, qm) and torch.equal(l, lab)
+    hi = torch.from_numpy(rs.standard_normal((3, 256, 64)).astype(np.float16))
+    lo = torch.from_numpy(rs.standard_normal((3, 256, 64)).astype(np.float16))
+    rows, layout = sharding.pack_query((hi, lo), qm, lab)
+    (h2, l2), m, l = sharding.unpack_query(rows, layout)
+    assert torch.equal(h2, hi) and torch.equal(l2, lo) and torch.equal(m, qm) and torch.equal(l, lab)

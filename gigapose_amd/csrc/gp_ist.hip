@@ -13,6 +13,10 @@ int gp_gemm_launch(const float* A, int lda, const float* B, int ldb, float* D, i
                    int K, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
                    float* sk_ws, hipStream_t st);
 
+int gp_gemm_split_launch(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J,
+                         int K, int act_is_b, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
+                         hipStream_t st);
+
 namespace {
 
 // X[c][r]: c < D -> tar_feat[b][c][ti],  c >= D -> src_bank[obj][view][c-D][si]     ("cat([tar, src])",
@@ -94,12 +98,14 @@ int gp_ist_regress(const float* tar_feat, const float* src_bank, const int* labe
     GP_REQUIRE(B >= 0 && O > 0 && N > 0 && k > 0, "gp_ist_regress: bad sizes");
     GP_REQUIRE(D > 0 && (2 * D) % 16 == 0 && H % 128 == 0 && H > 0,
                "gp_ist_regress: descriptor %d / hidden %d not supported (2D %% 16, H %% 128)", D, H);
-    GP_REQUIRE(n_weights == 12, "gp_ist_regress: expected 12 weight pointers, got %d", n_weights);
+    GP_REQUIRE(n_weights != 20 || (2 * D) % 32 == 0, "gp_ist_regress: split numerics need 2D %% 32 == 0");
+    GP_REQUIRE(n_weights == 12 || n_weights == 20, "gp_ist_regress: expected 12 (or 20: + split planes) weight pointers, got %d", n_weights);
     if (B == 0) return GP_OK;
     GP_REQUIRE(tar_feat && src_bank && labels && id_src && tar_pts && src_pts && weights && workspace && scales &&
                    cos_sin, "gp_ist_regress: null pointer");
     GP_REQUIRE(workspace_bytes >= gp_ist_workspace_bytes(B, k, D, H), "gp_ist_regress: workspace too small");
-    for (int i = 0; i < 12; ++i) GP_REQUIRE(weights[i], "gp_ist_regress: weight pointer %d is null", i);
+    for (int i = 0; i < n_weights; ++i) GP_REQUIRE(weights[i], "gp_ist_regress: weight pointer %d is null", i);
+    const bool split = n_weights == 20;  // entries 12..19: per head W1 hi, lo ([2H][2D]) and W2 hi, lo ([H][2H]) f16 planes, w ~= hi + lo 2^-11
     const size_t R = (size_t)B * k * GP_P;
     GP_REQUIRE(R < (size_t)1 << 31, "gp_ist_regress: too many rows");
     float* X = workspace;
@@ -111,12 +117,20 @@ int gp_ist_regress(const float* tar_feat, const float* src_bank, const int* labe
     int rc;
     for (int head = 0; head < 2; ++head) {  // 0: scale_predictor, 1: inplane_predictor (ist_net.py:140-155)
         const float* const* w = weights + head * 6;  // W1^T [2D][2H], b1, W2^T [2H][H], b2, W3 [nout][H], b3
-        if ((rc = gp_gemm_launch(w[0], 2 * H, X, (int)R, H1, (int)R, 2 * H, (int)R, 2 * D, 5, w[1], nullptr, nullptr,
-                                 0, nullptr, st)))
-            return rc;
-        if ((rc = gp_gemm_launch(w[2], H, H1, (int)R, H2, (int)R, H, (int)R, 2 * H, 5, w[3], nullptr, nullptr, 0,
-                                 nullptr, st)))
-            return rc;
+        if (split) {  // split numerics (3 x f16 MFMA, gp_split.hip): the two hidden layers = 99 % of the head's flops
+            const float* const* sp = weights + 12 + head * 4;
+            if ((rc = gp_gemm_split_launch(X, (int)R, sp[0], sp[1], H1, (int)R, 2 * H, (int)R, 2 * D, 1, 5, w[1], nullptr, nullptr, 0, st)))
+                return rc;
+            if ((rc = gp_gemm_split_launch(H1, (int)R, sp[2], sp[3], H2, (int)R, H, (int)R, 2 * H, 1, 5, w[3], nullptr, nullptr, 0, st)))
+                return rc;
+        } else {
+            if ((rc = gp_gemm_launch(w[0], 2 * H, X, (int)R, H1, (int)R, 2 * H, (int)R, 2 * D, 5, w[1], nullptr, nullptr,
+                                     0, nullptr, st)))
+                return rc;
+            if ((rc = gp_gemm_launch(w[2], H, H1, (int)R, H2, (int)R, H, (int)R, 2 * H, 5, w[3], nullptr, nullptr, 0,
+                                     nullptr, st)))
+                return rc;
+        }
         if (head == 0)
             hipLaunchKernelGGL(ist_head_kernel<1>, dim3((unsigned)(R / 256)), dim3(256), 0, st, H2, w[4], w[5],
                                tar_pts, src_pts, H, R, 0, scales);

@@ -413,7 +413,11 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     match_epilogue(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg);
 }
 
-// norms of gp_l2norm_cp (same sequential fma over c), then x / d * 32 split into f16 planes [row][patch][C]
+// norms of gp_l2norm_cp (same sequential fma over c), then x / d * 32 split into f16 planes [row][patch][C].
+// grid (rows, nchunk): a block recomputes the full norm of its 256 patches (the price of keeping the sequential chain) and
+// then converts its share of the channels, 32 at a time through an LDS transpose.  nchunk = 4 at C = 1024: with one block
+// per 32 channels (the first version) 64 query rows re-read their 1 MB 32 times each -- 0.5-0.66 ms per step for a 67 MB
+// conversion (rocprofv3, profiles/r02_kernel_stats.txt); 4 chunks keep 256 CUs busy at an eighth of the traffic.
 __global__ __launch_bounds__(256) void l2norm_split_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
                                                             _Float16* __restrict__ lo, int C, int Cp)
 {
@@ -427,9 +431,11 @@ __global__ __launch_bounds__(256) void l2norm_split_kernel(const float* __restri
         ss = __builtin_fmaf(v, v, ss);
     }
     dn[p] = fmaxf(__builtin_sqrtf(ss), 1e-12f);
-    {   // grid (rows, Cp / 32): this block's 32-channel chunk (Cp = round_up(C, 32): the planes are zero-padded along C)
-        const int c0 = blockIdx.y * 32;
-        __syncthreads();
+    // this block's channel range: 32-channel groups [g0, g1) of Cp / 32 (Cp = round_up(C, 32): planes are zero-padded along C)
+    const int ngrp = Cp / 32, g0 = ngrp * blockIdx.y / gridDim.y, g1 = ngrp * (blockIdx.y + 1) / gridDim.y;
+    for (int grp = g0; grp < g1; ++grp) {
+        const int c0 = grp * 32;
+        __syncthreads();  // dn visible (first round) / previous round's reads of t done
         for (int r = 0; r < 32; ++r) t[r][p] = (c0 + r < C) ? xr[(size_t)(c0 + r) * GP_P + p] : 0.f;  // coalesced along p
         __syncthreads();
         // thread -> (patch pp, 8-channel group g): 256 patches x 4 groups = 1024 items, 4 per thread
@@ -552,8 +558,9 @@ int gp_l2norm_split(const float* x, void* hi, void* lo, int rows, int C, void* s
     GP_REQUIRE(rows >= 0 && C > 0, "gp_l2norm_split: bad arguments (rows=%d C=%d)", rows, C);
     if (rows == 0) return GP_OK;
     GP_REQUIRE(x && hi && lo, "gp_l2norm_split: null pointer");
-    hipLaunchKernelGGL(l2norm_split_kernel, dim3(rows, (C + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)hi,
-                       (_Float16*)lo, C, (C + 31) / 32 * 32);
+    const int ngrp = (C + 31) / 32;
+    hipLaunchKernelGGL(l2norm_split_kernel, dim3(rows, ngrp < 4 ? ngrp : 4), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)hi,
+                       (_Float16*)lo, C, ngrp * 32);
     GP_CHECK_LAUNCH("gp_l2norm_split");
     return GP_OK;
 }

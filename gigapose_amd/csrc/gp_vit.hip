@@ -731,9 +731,11 @@ extern "C" void gp_attention_set_nq(int nq) { g_attn_nq = (nq >= 0 && nq <= 2) ?
 __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__ X, float* __restrict__ out,
                                                         int C, int Mpad, int normalize)
 {
-    // grid (B, C / 32): every block recomputes the full norm of its 256 patches (same sequential fma chain; the C/32-fold
-    // re-read is L2 traffic) and writes its own 32 channels -- B blocks alone cannot fill 256 CUs.
-    const int b = blockIdx.x, p = threadIdx.x, c0 = blockIdx.y * 32;
+    // grid (B, nchunk): every block recomputes the full norm of its 256 patches (same sequential fma chain; the nchunk-fold
+    // re-read is L2 traffic) and writes its share of the channels -- B blocks alone cannot fill 256 CUs, one block per 32
+    // channels (the first version) re-read X 32 times: 0.26 ms per step.
+    const int b = blockIdx.x, p = threadIdx.x;
+    const int c0 = (int)((long long)C * blockIdx.y / gridDim.y), c1 = (int)((long long)C * (blockIdx.y + 1) / gridDim.y);
     const float* x = X + (size_t)b * T_TOK + 1 + p;
     float d = 1.f;
     if (normalize) {
@@ -745,7 +747,7 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
         d = fmaxf(__builtin_sqrtf(ss), 1e-12f);
     }
     float* o = out + (size_t)b * C * GP_P + p;
-    for (int c = c0; c < c0 + 32 && c < C; ++c) o[(size_t)c * GP_P] = normalize ? x[(size_t)c * Mpad] / d : x[(size_t)c * Mpad];
+    for (int c = c0; c < c1; ++c) o[(size_t)c * GP_P] = normalize ? x[(size_t)c * Mpad] / d : x[(size_t)c * Mpad];
 }
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -965,7 +967,7 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
         else rc = gp_gemm_launch(w[L_FC2_WT], C, F, Mpad, X, Mpad, C, Mpad, mlp_dim, 3, w[L_FC2_B], w[L_LS2], X, Mpad, SK, st);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(features_kernel, dim3(B, (C + 31) / 32), dim3(256), 0, st, X, out_features, C, Mpad, normalize);
+    hipLaunchKernelGGL(features_kernel, dim3(B, B >= 64 ? 4 : (B >= 16 ? 16 : 32)), dim3(256), 0, st, X, out_features, C, Mpad, normalize);
     GP_CHECK_LAUNCH("gp_vit_forward/features");
     return GP_OK;
 }

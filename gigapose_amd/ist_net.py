@@ -336,8 +336,14 @@ class ISTNet(nn.Module):
         for seq in (self.regressor.scale_predictor, self.regressor.inplane_predictor):
             l1, l2, l3 = seq[0], seq[2], seq[4]
             tensors += [dev(l1.weight.t()), dev(l1.bias), dev(l2.weight.t()), dev(l2.bias), dev(l3.weight), dev(l3.bias)]
-        table = (ctypes.c_void_p * 12)(*[t.data_ptr() for t in tensors])
-        self._packed = (device, tensors, table)
+        numerics = getattr(self.backbone, "numerics", "chain")
+        if numerics == "split":   # the two hidden layers of each head as 3 x f16 MFMA (weights [out][in] as hi / lo planes)
+            from .vit import split_planes
+
+            for seq in (self.regressor.scale_predictor, self.regressor.inplane_predictor):
+                tensors += list(split_planes(seq[0].weight.to(device))) + list(split_planes(seq[2].weight.to(device)))
+        table = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        self._packed = (device, tensors, table, numerics)
 
     @torch.no_grad()
     def regress_bank(self, ist_bank, labels0, id_src, tar_feat, src_pts, tar_pts):
@@ -345,7 +351,7 @@ class ISTNet(nn.Module):
         ist_bank (O,N,D,16,16); labels0 (B) int32 0-based; id_src (B,k) int64; tar_feat (B,D,16,16);
         src_pts / tar_pts (B,k,256,2) int64 -> relScale (B,k,256), relInplane (B,k,256,2)."""
         dev = tar_feat.device
-        if self._packed is None or self._packed[0] != dev:
+        if self._packed is None or self._packed[0] != dev or self._packed[3] != getattr(self.backbone, "numerics", "chain"):
             self._pack(dev)
         B, k = id_src.shape
         O, N, D = ist_bank.shape[:3]
@@ -359,11 +365,11 @@ class ISTNet(nn.Module):
         need = lib.gp_ist_workspace_bytes(_lib.i(B), _lib.i(k), _lib.i(D), _lib.i(H))
         if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != dev:
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
-        _, tensors, table = self._packed
+        _, tensors, table, _ = self._packed
         _lib.call("gp_ist_regress", _lib.ptr(tar_feat.contiguous().float()), _lib.ptr(ist_bank.contiguous()),
                   _lib.ptr(labels0.to(torch.int32).contiguous()), _lib.ptr(id_src.contiguous()),
                   _lib.ptr(tar_pts.contiguous()), _lib.ptr(src_pts.contiguous()), _lib.i(B), _lib.i(O), _lib.i(N),
-                  _lib.i(k), _lib.i(D), _lib.i(H), table, _lib.i(12), _lib.i(1 if self.regressor.use_tanh_act else 0),
+                  _lib.i(k), _lib.i(D), _lib.i(H), table, _lib.i(len(tensors)), _lib.i(1 if self.regressor.use_tanh_act else 0),
                   _lib.ptr(self._ws), ctypes.c_size_t(need), _lib.ptr(scales), _lib.ptr(cos_sin), _lib.stream_ptr())
         return scales, cos_sin
 

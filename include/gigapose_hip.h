@@ -294,7 +294,8 @@ size_t gp_ist_workspace_bytes(int B, int k, int D, int H);
  *   tar_pts, src_pts (B,k,256,2) int64   ->  scales (B,k,256)  cos_sin (B,k,256,2)
  * weights: HOST array of 12 DEVICE pointers: for scale then in-plane head:
  *   W1^T (2D,2H), b1 (2H), W2^T (2H,H), b2 (H), W3 (nout,H), b3 (nout).
- * Requires 2D % 16 == 0, H % 128 == 0. */
+ * Requires 2D % 16 == 0, H % 128 == 0.  n_weights = 20: eight more pointers select the split numerics for the hidden layers
+ * (per head: W1 hi, lo ([2H][2D]), W2 hi, lo ([H][2H]) f16 planes of the PyTorch-native [out][in] weights, w ~= hi + lo 2^-11). */
 int gp_ist_regress(const float* tar_feat, const float* src_bank, const int* labels, const long long* id_src,
                    const long long* tar_pts, const long long* src_pts, int B, int O, int N, int k, int D,
                    int H, const float* const* weights, int n_weights, int use_tanh, float* workspace,

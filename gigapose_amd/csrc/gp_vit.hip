@@ -214,11 +214,106 @@ __global__ __launch_bounds__(1024) void layernorm_planes_kernel(const float* __r
     if (bad) gp_raise(status, GP_ST_SPLIT_RANGE);
 }
 
+// Second version: X is read ONCE.  Block = 32 tokens x 16 channel slices (512 threads, two blocks per CU); thread (tok, sl)
+// keeps its C / 16 values -- channels 128 k + 8 sl + e, the ones it later converts -- in registers through both statistics
+// passes and the conversion (the kernel above re-reads X from L2 for each of its three passes: 72 us per launch = 1.9 TB/s
+// for a 136 MB job, 6 % of the step).  Two-pass mean / variance as before (the per-thread summation order differs from
+// layernorm_wide_kernel's contiguous slices: y agrees with it to f32 round-off, not bit for bit).  Conversion: each thread
+// packs (hi, lo) of its 8 channels of chunk k into one 32-byte LDS row piece; after the barrier 16 consecutive lanes read
+// the 16 pieces of one token and store 256 contiguous bytes per plane.
+template <int NK>
+__global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* __restrict__ X, _Float16* __restrict__ Yhi,
+                                                                    _Float16* __restrict__ Ylo, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, int Mpad, float eps,
+                                                                    int* __restrict__ status)
+{
+    constexpr int C = 128 * NK, TP = 132;  // LDS row pitch in words: 16-byte aligned pieces, tokens 33 sixteen-byte slots apart
+    __shared__ float red[16][32];
+    __shared__ __attribute__((aligned(16))) unsigned int tile[2][32 * TP];
+    const int tok = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const size_t tok0 = (size_t)blockIdx.x * 32;
+    float xv[NK][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xv[k][e] = X[(size_t)(128 * k + 8 * sl + e) * Mpad + tok0 + tok];
+            s += xv[k][e];
+        }
+    red[sl][tok] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tot += red[j][tok];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = xv[k][e] - mean;
+            q = __builtin_fmaf(d, d, q);
+        }
+    red[sl][tok] = q;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tot += red[j][tok];
+    const float rstd = 1.0f / __builtin_sqrtf(tot / (float)C + eps);
+    const int g2 = threadIdx.x & 15, t2 = threadIdx.x >> 4;  // store phase: 16 lanes = the 16 eight-channel pieces of token t2
+    const size_t row = (tok0 + t2) * C + 8 * g2;
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        unsigned int* T = tile[k & 1];
+        const int c = 128 * k + 8 * sl;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
+        unsigned int w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float y = (xv[k][e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
+            const float v = y * kPlaneScale;
+            const _Float16 hh = (_Float16)v;
+            const _Float16 ll = (_Float16)(v - (float)hh);
+            bad |= !(fabsf(v) <= kSplitPlaneLimit);  // !(<=): a NaN / inf residual stream counts
+            w[e] = (unsigned int)__builtin_bit_cast(unsigned short, hh) | ((unsigned int)__builtin_bit_cast(unsigned short, ll) << 16);
+        }
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        u4 w0 = {w[0], w[1], w[2], w[3]}, w1 = {w[4], w[5], w[6], w[7]};
+        *reinterpret_cast<u4*>(T + tok * TP + 8 * sl) = w0;
+        *reinterpret_cast<u4*>(T + tok * TP + 8 * sl + 4) = w1;
+        __syncthreads();  // one barrier per chunk: the other tile is rewritten only after every thread passed this one
+        const u4 r0 = *reinterpret_cast<const u4*>(T + t2 * TP + 8 * g2), r1 = *reinterpret_cast<const u4*>(T + t2 * TP + 8 * g2 + 4);
+        v16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = __builtin_bit_cast(_Float16, (unsigned short)(r0[e] & 0xffffu));
+            l[e] = __builtin_bit_cast(_Float16, (unsigned short)(r0[e] >> 16));
+            h[4 + e] = __builtin_bit_cast(_Float16, (unsigned short)(r1[e] & 0xffffu));
+            l[4 + e] = __builtin_bit_cast(_Float16, (unsigned short)(r1[e] >> 16));
+        }
+        *reinterpret_cast<v16x8*>(Yhi + row + 128 * k) = h;
+        *reinterpret_cast<v16x8*>(Ylo + row + 128 * k) = l;
+    }
+    if (bad) gp_raise(status, GP_ST_SPLIT_RANGE);
+}
+
+static int g_ln_planes_reg = 1;  // A/B hook (gp_vit_set_ln_reg): 0 = the three-pass kernel
+extern "C" void gp_vit_set_ln_reg(int on) { g_ln_planes_reg = on ? 1 : 0; }
+
 int launch_layernorm_planes(const float* X, _Float16* hi, _Float16* lo, const float* g, const float* b, int C, int Mpad, float eps,
                             hipStream_t st)
 {
     GpProfScope prof(GP_PROF_LN, 8.0 * C * Mpad, st);
-    hipLaunchKernelGGL(layernorm_planes_kernel, dim3(Mpad / 64), dim3(1024), 0, st, X, hi, lo, g, b, C, Mpad, eps, gp_status_buffer());
+    if (g_ln_planes_reg && C == 1024 && Mpad % 32 == 0)
+        hipLaunchKernelGGL(layernorm_planes_reg_kernel<8>, dim3(Mpad / 32), dim3(512), 0, st, X, hi, lo, g, b, Mpad, eps, gp_status_buffer());
+    else if (g_ln_planes_reg && C == 768 && Mpad % 32 == 0)
+        hipLaunchKernelGGL(layernorm_planes_reg_kernel<6>, dim3(Mpad / 32), dim3(512), 0, st, X, hi, lo, g, b, Mpad, eps, gp_status_buffer());
+    else
+        hipLaunchKernelGGL(layernorm_planes_kernel, dim3(Mpad / 64), dim3(1024), 0, st, X, hi, lo, g, b, C, Mpad, eps, gp_status_buffer());
     return 0;
 }
 

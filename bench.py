@@ -30,7 +30,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense f32-input MFMA peak (MI355X_MICROAR
 FLOP_PER_CROP = {"dinov2_vitl14": 162.0e9, "dinov2_vits14": 12.25e9, "dinov2_vitb14": 0.0}
 
 
-def cpu_baseline(variant, n_templates, k, sample_crops=8):
+def cpu_baseline(variant, n_templates, k, sample_crops=4, threads=None):
     """The reference's CPU path restated operator for operator in torch (oracle/torch_port.py: HF DINOv2 stand-in forward
     in sub-batches of 4 detections, the 170 MB / detection bank gather, LocalSimilarity.test with its materialised
     similarity tensor, the IST backbone recomputed k times, MLP heads; RANSAC / recovery through the C oracle) on
@@ -43,7 +43,13 @@ def cpu_baseline(variant, n_templates, k, sample_crops=8):
     from oracle import torch_port
 
     dim, depth, heads = VARIANTS[variant]
-    threads = os.cpu_count() or 1
+    # torch's intra-op pool: the cores this process may run on, capped at 16 (the GPU boxes report 256 logical CPUs of a
+    # shared host; 256 threads measured 6 x SLOWER than 8 -- oversubscription; BASELINE.md's reference figure used 8)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = threads or max(1, min(16, avail))
     torch.set_num_threads(threads)
     hf = Dinov2Model(Dinov2Config(hidden_size=dim, num_hidden_layers=depth, num_attention_heads=heads, image_size=224, patch_size=14)).eval()
     ist = factory.build_model("dinov2_vits14", k=k, device="cpu", seed=0).ist_net   # reference-shaped ISTNet mirror (torch modules)
@@ -225,7 +231,8 @@ def main():
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if args.variant == "dinov2_vitl14" and args.batch == 64 and args.templates == 162:
-            traffic = round(pmc["gemm_split" if args.numerics == "split" else "gemm_kmajor"]["hbm_bytes_per_launch"])
+            fam = ("gemm_planes" if "gemm_planes" in pmc else "gemm_split") if args.numerics == "split" else "gemm_kmajor"
+            traffic = round(pmc[fam]["hbm_bytes_per_launch"])
     except Exception:
         pass
     F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)

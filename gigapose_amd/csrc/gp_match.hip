@@ -426,7 +426,15 @@ __global__ __launch_bounds__(256) void l2norm_split_kernel(const float* __restri
     const int row = blockIdx.x, p = threadIdx.x;
     const float* xr = x + (size_t)row * C * GP_P;
     float ss = 0.f;
-    for (int c = 0; c < C; ++c) {
+    int c = 0;
+    for (; c + 16 <= C; c += 16) {  // 16 independent loads in flight, then the fmas in order (same chain as gp_l2norm_cp)
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = xr[(size_t)(c + u) * GP_P + p];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) ss = __builtin_fmaf(v[u], v[u], ss);
+    }
+    for (; c < C; ++c) {
         const float v = xr[(size_t)c * GP_P + p];
         ss = __builtin_fmaf(v, v, ss);
     }

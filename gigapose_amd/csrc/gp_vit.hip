@@ -835,7 +835,15 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
     float d = 1.f;
     if (normalize) {
         float ss = 0.f;
-        for (int c = 0; c < C; ++c) {
+        int c = 0;
+        for (; c + 16 <= C; c += 16) {  // 16 independent loads in flight, then the fmas IN ORDER (the chain is unchanged; one
+            float v[16];                // load per dependent fma left the loop latency-bound: 0.3 ms for a 67 MB pass)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = x[(size_t)(c + u) * Mpad];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) ss = __builtin_fmaf(v[u], v[u], ss);
+        }
+        for (; c < C; ++c) {
             const float v = x[(size_t)c * Mpad];
             ss = __builtin_fmaf(v, v, ss);
         }

@@ -157,12 +157,20 @@ def build_e2e_model(cfg, numerics):
 
 
 def disagreement(a, b):
-    """oracle/make_goldens.py: disagreement -- detections whose top-k template SET / ORDER differ, differing correspondence
-    entries, hypotheses with a different inlier count."""
+    """Detection level: detections whose top-k template SET / ORDER differ.  Hypothesis level, over the hypotheses both runs
+    have (aligned by template id, so that one swapped pair of hypotheses is not counted as 2 x 512 differing entries):
+    differing correspondence entries (src_pts / tar_pts) and differing inlier counts, out of `common` shared hypotheses."""
     ida, idb = a["id_src"].astype(np.int64), b["id_src"].astype(np.int64)
-    return dict(set=int((np.sort(ida, 1) != np.sort(idb, 1)).any(1).sum()), order=int((ida != idb).any(1).sum()),
-                src_pts=int((a["src_pts"] != b["src_pts"]).sum()), tar_pts=int((a["tar_pts"] != b["tar_pts"]).sum()),
-                inliers=int((a["all_scores"] != b["all_scores"]).sum()))
+    out = dict(set=int((np.sort(ida, 1) != np.sort(idb, 1)).any(1).sum()), order=int((ida != idb).any(1).sum()), common=0, src_pts=0, tar_pts=0, inliers=0)
+    for d in range(len(ida)):
+        for ja, t in enumerate(ida[d]):
+            jb = np.flatnonzero(idb[d] == t)
+            if len(jb):
+                out["common"] += 1
+                out["src_pts"] += int((a["src_pts"][d, ja] != b["src_pts"][d, jb[0]]).sum())
+                out["tar_pts"] += int((a["tar_pts"][d, ja] != b["tar_pts"][d, jb[0]]).sum())
+                out["inliers"] += int(a["all_scores"][d, ja] != b["all_scores"][d, jb[0]])
+    return out
 
 
 @pytest.mark.parametrize("numerics", ["chain", "split"])
@@ -191,12 +199,28 @@ def test_eval_retrieval_at_benchmark_size_vs_reference(golden_dir, which, numeri
     p = {n: v.cpu().numpy() for n, v in model.last_predictions.tensors.items()}
     p["all_scores"] = p["scores"]
     np.testing.assert_allclose(model.template_datas["syn"].ae_features[0, 0].cpu().numpy(), g32["tmpl_ae_feat_sample"], rtol=0, atol=3e-5)
+    if "feat_f64_templates01_crops01" in g64.files:   # unit-norm ViT-L features of 2 templates + 2 crops (every 4th channel) in float64
+        from test_gpu_e2e import e2e_inputs
+
+        items, qq = e2e_inputs(cfg["seed"], cfg["O"], cfg["N"], cfg["B"])
+        x = torch.cat([items[0].rgb[:2], torch.from_numpy(qq["tar_img"][:2])]).to(DEV)
+        mine = model.ae_net(x).cpu().numpy()[:, ::4].astype(np.float64)
+        t64, r32 = g64["feat_f64_templates01_crops01"], g64["feat_ref32_templates01_crops01"].astype(np.float64)
+        e_m, e_r = np.abs(mine - t64), np.abs(r32 - t64)
+        print(f"{which} [{numerics}] ViT-L unit-norm features vs the float64 forward (feature rms {np.sqrt((t64 ** 2).mean()):.3e}): ours max {e_m.max():.2e} rms "
+              f"{np.sqrt((e_m ** 2).mean()):.2e} | the reference's f32 forward max {e_r.max():.2e} rms {np.sqrt((e_r ** 2).mean()):.2e}")
+        assert e_m.max() < 2e-6
     d_ref, d_ours, d_32 = disagreement(g32, g64), disagreement(p, g64), disagreement(p, g32)
     n = dict(set=len(p["id_src"]), order=len(p["id_src"]), src_pts=p["src_pts"].size, tar_pts=p["tar_pts"].size, inliers=p["scores"].size)
     print(f"{which} [{numerics}] disagreement with the reference evaluated in float64 -- ours: {d_ours} | the reference's own f32 run: {d_ref} "
           f"| (ours vs the f32 golden: {d_32}) out of {n}")
-    for key in d_ref:
-        assert d_ours[key] <= 1.25 * d_ref[key] + max(4, 0.0002 * n[key]), f"{key}: {d_ours[key]} vs the reference's own {d_ref[key]}"
+    # detection-level events are few (a handful of 64): small-number statistics, bounded with an absolute slack; the
+    # hypothesis-level counts (thousands of near-tied argmaxes) must be within 1.25 x the reference's own
+    for key in ("set", "order", "inliers"):
+        assert d_ours[key] <= 1.25 * d_ref[key] + 6, f"{key}: {d_ours[key]} vs the reference's own {d_ref[key]}"
+    for key in ("src_pts", "tar_pts"):
+        assert d_ours[key] <= 1.25 * d_ref[key] + 0.0002 * n[key], f"{key}: {d_ours[key]} vs the reference's own {d_ref[key]}"
+    assert d_ours["common"] >= d_ref["common"] - 8
     # poses: every hypothesis whose template id, correspondences and inlier count equal the float64 reference's AND whose
     # RANSAC winner is the same candidate (equal inlier COUNTS do not pin the winner: two candidates one inlier apart swap
     # places under any rounding difference; "same winner" = the 2-D similarity M within 1e-3)

@@ -76,3 +76,20 @@ def test_oracle_val_matches_reference_golden(golden_dir):
     np.testing.assert_array_equal(out["src_pts"], g["src_pts"].astype(np.int64))
     np.testing.assert_array_equal(out["tar_pts"], g["tar_pts"].astype(np.int64))
     np.testing.assert_allclose(out["score"], g["score"], rtol=0, atol=1e-6)
+
+
+def test_oracle_vs_reference_golden_at_config2_size(golden_dir):
+    """BASELINE config 2 (64 crops x 162 templates, C = 1024): the C oracle against the golden the unmodified reference wrote at
+    that size (oracle/make_goldens.py: gen_matcher_big) -- indices bit-exact over all 163 840 correspondence entries.
+    (~0.5-1.5 min of host cores; config 3's golden is checked the same way by the GPU suite through the HIP kernels.)"""
+    import ast
+
+    g = np.load(os.path.join(golden_dir, "match_cfg2.npz"))
+    case = syn.matcher_case(**ast.literal_eval(str(g["case_kwargs"])))
+    assert syn.checksum(*[case[x] for x in sorted(case)]) == str(g["input_checksum"])
+    ref = oracle.local_similarity_test(case["src_feats"], case["tar_feat"], case["src_masks"], case["tar_mask"], case["labels"], int(g["k"]))
+    np.testing.assert_array_equal(ref["id_src"], g["id_src"])
+    np.testing.assert_array_equal(ref["src_pts"], g["src_pts"].astype(np.int64))
+    np.testing.assert_array_equal(ref["tar_pts"], g["tar_pts"].astype(np.int64))
+    np.testing.assert_allclose(ref["score_src"], g["score_src"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ref["score_pts"], g["score_pts"], rtol=0, atol=3e-6)

@@ -16,8 +16,8 @@ def short(n):
 
 FAMILIES = [("gemm_kmajor", ("gemm_kmajor_kernel", "gemm_streamk_kernel")), ("match_tiles", ("match_tiles_kernel",)),
             ("attention", ("attention_kernel", "attention_planes_kernel")), ("attention_split", ("attention_split_kernel",)), ("layernorm", ("layernorm",)), ("conv", ("conv_kernel", "conv3x3_kernel")),
-            ("gemm_split", ("gemm_split_kernel", "gemm_split256_kernel", "gemm_planes256_kernel")), ("match_split", ("match_tiles_split_kernel",)),
-            ("conv_split", ("conv_split_kernel",))]
+            ("gemm_split", ("gemm_split_kernel", "gemm_split256_kernel", "gemm_planes256_kernel")), ("gemm_planes", ("gemm_planes256_kernel",)),
+            ("match_split", ("match_tiles_split_kernel",)), ("conv_split", ("conv_split_kernel", "conv_planes_kernel"))]
 
 
 def family_json(acc, path):

@@ -497,7 +497,14 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
     const int lane = tid & 63, l31 = lane & 31, half = lane >> 5, wave = tid >> 6;
     const int nfi = a.tiles_i * (TB / 32), nfrag = nfi * a.strip_fj;
     const int nkb = a.K >> 4;                                        // k16 blocks
-    const int kb0 = nkb * wave / 8, kb1 = nkb * (wave + 1) / 8;      // this wave's share of K
+    const int kb0 = nkb * wave / 8, kb1 = nkb * (wave + 1) / 8;      // this wave's share of K (direct path)
+    // K % 256 == 0 (every ViT shape): operands through LDS in coalesced 256-byte row pieces, two 256-k super-steps (64 KB + padding
+    // each) per round with all 16 loads of a thread in flight; wave w then multiplies k16 blocks 2w, 2w + 1 of each super-step.  The
+    // direct path below (each lane loading its own operand rows, 32 bytes per row per instruction) moves the same 256 KB per
+    // fragment through the CU's vector-memory path at ~12 B/clk: 13 us at K = 1024, 42 us at K = 4096 (r02 timeline).
+    constexpr int SP = 264, SPLANE = 32 * SP, SSTEP = 4 * SPLANE;    // halfs: padded row (528 B), plane, super-step (A hi, A lo, B hi, B lo)
+    _Float16* sl = reinterpret_cast<_Float16*>(red);
+    const bool staged = (a.K & 255) == 0;
     for (int f = slot; f < nfrag; f += nslots) {                     // uniform over the workgroup (barriers inside)
         const int i0 = (f % nfi) * 32, j0 = a.strip_j0 + (f / nfi) * 32;
         const _Float16* pah = a.ahi + (size_t)(i0 + l31) * a.K + 8 * half;
@@ -507,7 +514,74 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        int kb = kb0;
+        // epilogue operands of this fragment (used by wave 0 only, requested now: their latency hides behind the K loop)
+        constexpr bool kBiasI = EPI == XEPI_BIAS_I || EPI == XEPI_BIAS_I_GELU || EPI == XEPI_BIAS_I_SCALE_RES || EPI == XEPI_BIAS_I_RELU ||
+                                EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES;
+        f32x4 pre_bias[4], pre_scale[4], pre_res[4];
+        if (wave == 0) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int i = i0 + frag_row(4 * r4, lane);
+                if (kBiasI) pre_bias[r4] = *reinterpret_cast<const f32x4*>(a.bias + i);
+                if (EPI == XEPI_BIAS_I_SCALE_RES) {
+                    pre_scale[r4] = *reinterpret_cast<const f32x4*>(a.scale + i);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pre_res[r4][e] = a.res[(unsigned)(i + e) * (unsigned)a.ldr + (unsigned)(j0 + l31)];
+                }
+            }
+        }
+        if (staged) {
+            const int srow = tid >> 4, sc = tid & 15;                // this thread's row and 16-byte piece (and piece + 16)
+            const _Float16* g[4] = {a.ahi + (size_t)(i0 + srow) * a.K + 8 * sc, a.alo + (size_t)(i0 + srow) * a.K + 8 * sc,
+                                    a.bhi + (size_t)(j0 + srow) * a.K + 8 * sc, a.blo + (size_t)(j0 + srow) * a.K + 8 * sc};
+            const int nss = a.K >> 8, nr = (nss + 1) >> 1;           // rounds of two super-steps
+            u32x4 va[2][4][2], vb[2][4][2];
+            auto load = [&](u32x4 (&v)[2][4][2], int r) {
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                    for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            v[b2][pl][h] = *reinterpret_cast<const u32x4*>(g[pl] + (size_t)min(2 * r + b2, nss - 1) * 256 + 128 * h);
+            };
+            auto round = [&](const u32x4 (&v)[2][4][2], int r) {
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                    for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            *reinterpret_cast<u32x4*>(sl + b2 * SSTEP + pl * SPLANE + srow * SP + 8 * sc + 128 * h) = v[b2][pl][h];
+                __syncthreads();
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    if (2 * r + b2 < nss) {                          // wave-uniform
+                        const _Float16* L = sl + b2 * SSTEP + l31 * SP + 8 * half;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int ko = 16 * (2 * wave + u);
+                            const g16x8 ah = *reinterpret_cast<const g16x8*>(L + ko), al = *reinterpret_cast<const g16x8*>(L + SPLANE + ko);
+                            const g16x8 bh = *reinterpret_cast<const g16x8*>(L + 2 * SPLANE + ko), bl = *reinterpret_cast<const g16x8*>(L + 3 * SPLANE + ko);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+                        }
+                    }
+                }
+                __syncthreads();                                     // the buffers are rewritten by the next round / by `red`
+            };
+            load(va, 0);
+            for (int r = 0; r < nr; r += 2) {                        // the next round's 16 loads fly while this one is written and multiplied
+                if (r + 1 < nr) load(vb, r + 1);
+                round(va, r);
+                if (r + 1 < nr) {
+                    if (r + 2 < nr) load(va, r + 2);
+                    round(vb, r + 1);
+                }
+            }
+        }
+        int kb = staged ? kb1 : kb0;
         for (; kb + 8 <= kb1; kb += 8) {  // 32 unconditional 16-byte loads in flight, then 24 MFMAs (a guard per load would make
             g16x8 ah[8], al[8], bh[8], bl[8];  // hipcc branch around each one and wait for it: 32 dependent round trips)
 #pragma unroll
@@ -559,7 +633,7 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
                     g16x4 oh, ol;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float x = acc[4 * r4 + e] * a.out_scale + a.bias[i + e];
+                        const float x = acc[4 * r4 + e] * a.out_scale + pre_bias[r4][e];
                         const float v = (EPI == PEPI_GELU_PLANES ? gelu_x(x) : x) * kActScale;
                         const _Float16 hh = (_Float16)v;
                         oh[e] = hh;
@@ -574,11 +648,11 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
                     for (int e = 0; e < 4; ++e) {
                         float v = acc[4 * r4 + e] * a.out_scale;
                         if (EPI == XEPI_BIAS_I || EPI == XEPI_BIAS_I_GELU || EPI == XEPI_BIAS_I_SCALE_RES || EPI == XEPI_BIAS_I_RELU)
-                            v = v + a.bias[i + e];
+                            v = v + pre_bias[r4][e];
                         if (EPI == XEPI_BIAS_J) v = v + a.bias[j];
                         if (EPI == XEPI_BIAS_I_GELU) v = gelu_x(v);
                         if (EPI == XEPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
-                        if (EPI == XEPI_BIAS_I_SCALE_RES) v = a.res[(unsigned)(i + e) * (unsigned)a.ldr + (unsigned)j] + a.scale[i + e] * v;
+                        if (EPI == XEPI_BIAS_I_SCALE_RES) v = pre_res[r4][e] + pre_scale[r4][e] * v;
                         a.D[(unsigned)(i + e) * (unsigned)a.ldd + (unsigned)j] = v;
                     }
                 }
@@ -594,7 +668,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
 {
     unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     const unsigned long long k_c0 = TIMING ? __builtin_readcyclecounter() : 0, k_w0 = TIMING ? wall_clock64() : 0;
-    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * TBUF];  // 128 KiB
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * TBUF + 2048];  // 128 KiB of operand buffers (+ 4 KiB: the strip's padded rows)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, grp = wave >> 2;

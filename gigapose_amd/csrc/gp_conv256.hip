@@ -45,6 +45,7 @@ struct ConvPArgs {
     int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, relu, K;
     int tiles_i, tiles_j;
     int* flags; float* partial; int epoch; int* status;
+    int stem;  // 1: the 7 x 7 / stride 2 stem on a zero-framed 4-channel image, see gp_conv2d_stem_planes
 };
 
 __device__ __forceinline__ int toff(int row, int kc) { return row * CROW + ((kc ^ ((row >> 2) & 3)) << 3); }
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
     const __amdgpu_buffer_rsrc_t r_wlo = __builtin_amdgcn_make_buffer_rsrc((void*)a.wlo, 0, w_bytes, 0x00020000);
     const int srow = tid >> 2, schunk = tid & 3;
     const int wofs = toff(srow, schunk);
-    const int OHW = a.OH * a.OW, cps = a.Cin / CBK;  // k-steps per tap
+    const int OHW = a.OH * a.OW, cps = a.stem ? 1 : a.Cin / CBK;  // k-steps per tap
     cu32x4 rg[8];
     // fragment addressing
     const int ar_ = 64 * wr + (lane & 31), br_ = 32 * NI * wc + (lane & 31), kh_ = lane >> 5;
@@ -110,9 +111,13 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
             const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
             pbase[h] = (((b * a.H + iy0) * a.W + ix0) * a.Cin) * 2 + schunk * 16;
             unsigned m = 0;
-            for (int dy = 0; dy < a.KH; ++dy)
-                for (int dx = 0; dx < a.KW; ++dx)
-                    if (iy0 + dy >= 0 && iy0 + dy < a.H && ix0 + dx >= 0 && ix0 + dx < a.W) m |= 1u << (dy * a.KW + dx);
+            if (a.stem) {  // the frame of zeros is part of the image buffer (pad = 0 in its coordinates): every tap row is in range
+                m = 0xffffffffu;
+            } else {
+                for (int dy = 0; dy < a.KH; ++dy)
+                    for (int dx = 0; dx < a.KW; ++dx)
+                        if (iy0 + dy >= 0 && iy0 + dy < a.H && ix0 + dx >= 0 && ix0 + dx < a.W) m |= 1u << (dy * a.KW + dx);
+            }
             pvalid[h] = m;
         }
         // weights: rows j0 + srow (+128) of (Cout, K); rows past Cout (Cout = 192 in a 256-row plane) read as zeros
@@ -162,9 +167,15 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
         const int ns = s1 - s0;
         auto gload = [&](int slab) {
             const int s = s0 + slab;
-            const int tap = s / cps, c0 = s - tap * cps;
-            const int dy = tap / a.KW, dx = tap - dy * a.KW;
-            const int toffb = ((dy * a.W + dx) * a.Cin + c0 * CBK) * 2;  // wave-uniform: one tap, 32 channels per k-step
+            int tap, toffb;  // wave-uniform
+            if (a.stem) {    // one k-step = one kernel ROW: 8 taps x 4 channels = 64 contiguous bytes of the framed image
+                tap = 0;
+                toffb = s * a.W * a.Cin * 2;
+            } else {         // one tap, 32 channels per k-step
+                tap = s / cps;
+                const int c0 = s - tap * cps, dy = tap / a.KW, dx = tap - dy * a.KW;
+                toffb = ((dy * a.W + dx) * a.Cin + c0 * CBK) * 2;
+            }
             const unsigned v0 = ((pvalid[0] >> tap) & 1u) ? (unsigned)(pbase[0] + toffb) : kOob;
             const unsigned v1 = ((pvalid[1] >> tap) & 1u) ? (unsigned)(pbase[1] + toffb) : kOob;
             const unsigned sw = (unsigned)s * (CBK * 2u);
@@ -354,6 +365,43 @@ __global__ __launch_bounds__(256) void planes_from_cm_kernel(const float* __rest
     if (bad) gp_raise(status, GP_ST_SPLIT_RANGE);
 }
 
+// F.interpolate(x, (S, S), mode="bilinear", align_corners=True) (reference resnet.py:366-368; arithmetic of gp_conv.hip's
+// resize_kernel = ATen's upsample_bilinear2d) written straight into what the split stem reads: channel-last planes of 8 x the
+// value, 4 channels per pixel (the 4th zero: one pixel = 8 bytes, two pixels = one 16-byte operand chunk) inside a frame of
+// zeros -- 3 rows / columns before (the 7 x 7 kernel's padding) and enough after for the 8th, zero-weighted tap column -- so
+// that no tap needs a range check and a kernel row of 8 taps is 64 contiguous bytes.  The frame is zeroed once by the host.
+__global__ __launch_bounds__(256) void resize_stem_planes_kernel(const float* __restrict__ in, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                                  int B, int IH, int IW, int S, int Hp, int Wp, int* __restrict__ status)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= S) return;
+    const float rh = (S > 1) ? (float)(IH - 1) / (float)(S - 1) : 0.f;
+    const float rw = (S > 1) ? (float)(IW - 1) / (float)(S - 1) : 0.f;
+    const float h1r = rh * y, w1r = rw * x;
+    const int h1 = (int)h1r, w1 = (int)w1r;
+    const int h1p = (h1 < IH - 1) ? 1 : 0, w1p = (w1 < IW - 1) ? 1 : 0;
+    const float h1l = h1r - h1, h0l = 1.f - h1l, w1l = w1r - w1, w0l = 1.f - w1l;
+    c16x4 oh, ol;
+    int bad = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* src = in + ((size_t)b * 3 + c) * IH * IW;
+        float v = h0l * (w0l * src[h1 * IW + w1] + w1l * src[h1 * IW + w1 + w1p]) +
+                  h1l * (w0l * src[(h1 + h1p) * IW + w1] + w1l * src[(h1 + h1p) * IW + w1 + w1p]);
+        v = v * kActScale;
+        const _Float16 hh = (_Float16)v;
+        oh[c] = hh;
+        ol[c] = (_Float16)(v - (float)hh);
+        bad |= !(fabsf(v) <= kSplitPlaneLimit);
+    }
+    oh[3] = (_Float16)0.f;
+    ol[3] = (_Float16)0.f;
+    const size_t o = (((size_t)b * Hp + y + 3) * Wp + x + 3) * 4;
+    *reinterpret_cast<c16x4*>(hi + o) = oh;
+    *reinterpret_cast<c16x4*>(lo + o) = ol;
+    if (bad) gp_raise(status, GP_ST_SPLIT_RANGE);
+}
+
 unsigned g_epoch_conv = 0;
 
 }  // namespace
@@ -394,6 +442,7 @@ int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const
     GP_REQUIRE(scratch && scratch_bytes >= gp_conv2d_planes_workspace_bytes() && ((uintptr_t)scratch % 16 == 0), "gp_conv2d_planes: scratch too small");
     GP_REQUIRE(((uintptr_t)x_hi % 16 == 0) && ((uintptr_t)x_lo % 16 == 0) && ((uintptr_t)w_hi % 16 == 0) && ((uintptr_t)w_lo % 16 == 0) &&
                    ((uintptr_t)alpha % 16 == 0) && ((uintptr_t)beta % 16 == 0), "gp_conv2d_planes: misaligned operand");
+    a.stem = 0;
     const int ni = Cout >= 256 ? 4 : Cout / 64;  // 128 -> 2, 192 -> 3, >= 256 -> 4
     a.tiles_i = (int)(npix / CT);
     a.tiles_j = (Cout + 64 * ni - 1) / (64 * ni);
@@ -414,6 +463,55 @@ int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const
     else if (ni == 3) hipLaunchKernelGGL(conv_planes_kernel<3>, dim3(8 * slots_x), dim3(CNT), 0, st, a);
     else hipLaunchKernelGGL(conv_planes_kernel<4>, dim3(8 * slots_x), dim3(CNT), 0, st, a);
     GP_CHECK_LAUNCH("gp_conv2d_planes");
+    return GP_OK;
+}
+
+/* The stem of the IST ResNet (reference resnet.py:333-337, 366-370: bilinear resize to S x S, Conv2d(3 -> Cout, 7 x 7, stride 2,
+ * padding 3, no bias) + BatchNorm + ReLU) in split numerics.  gp_resize_stem_planes writes the resized crops as framed 4-channel
+ * planes (B, S + 6, S + 8, 4) (the caller zeroes the buffers ONCE: the frame is never written); gp_conv2d_stem_planes runs
+ * conv_planes_kernel over them: k = dy * 32 + dx * 4 + ci (K = 224; weight planes (Cout, 224) of 64 w with zeros at dx = 7 and
+ * ci = 3), output planes (B * (S/2)^2, Cout) x 8 as every later layer reads them. */
+int gp_resize_stem_planes(const float* images, void* hi, void* lo, int B, int IH, int IW, int S, void* stream)
+{
+    GP_REQUIRE(B >= 0 && IH > 0 && IW > 0 && S > 0 && S % 2 == 0, "gp_resize_stem_planes: bad sizes");
+    if (B == 0) return GP_OK;
+    GP_REQUIRE(images && hi && lo && ((uintptr_t)hi % 16 == 0) && ((uintptr_t)lo % 16 == 0), "gp_resize_stem_planes: null / misaligned pointer");
+    GpProfScope prof(GP_PROF_OTHER, 0.0, (hipStream_t)stream);
+    hipLaunchKernelGGL(resize_stem_planes_kernel, dim3((S + 255) / 256, S, B), dim3(256), 0, (hipStream_t)stream, images, (_Float16*)hi, (_Float16*)lo,
+                       B, IH, IW, S, S + 6, S + 8, gp_status_buffer());
+    GP_CHECK_LAUNCH("gp_resize_stem_planes");
+    return GP_OK;
+}
+
+int gp_conv2d_stem_planes(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* alpha, const float* beta,
+                          int B, int S, int Cout, int relu, void* out_hi, void* out_lo, float* scratch, size_t scratch_bytes, void* stream)
+{
+    GP_REQUIRE(B >= 0 && S > 0 && S % 2 == 0 && (Cout == 128 || Cout == 192 || Cout % 256 == 0), "gp_conv2d_stem_planes: bad sizes");
+    if (B == 0) return GP_OK;
+    ConvPArgs a;
+    a.xhi = (const _Float16*)x_hi; a.xlo = (const _Float16*)x_lo; a.whi = (const _Float16*)w_hi; a.wlo = (const _Float16*)w_lo;
+    a.alpha = alpha; a.beta = beta; a.rhi = nullptr; a.rlo = nullptr; a.ohi = (_Float16*)out_hi; a.olo = (_Float16*)out_lo; a.of32 = nullptr;
+    a.B = B; a.H = S + 6; a.W = S + 8; a.Cin = 4; a.OH = S / 2; a.OW = S / 2; a.Cout = Cout; a.KH = 7; a.KW = 8; a.stride = 2; a.pad = 0;
+    a.relu = relu; a.K = 7 * 32; a.stem = 1;
+    const long long npix = (long long)B * a.OH * a.OW;
+    GP_REQUIRE(npix % CT == 0 && (long long)B * a.H * a.W * 8 < (1ll << 31) && npix * Cout < (1ll << 31), "gp_conv2d_stem_planes: B*OH*OW=%lld must be a multiple of 256", npix);
+    GP_REQUIRE(x_hi && x_lo && w_hi && w_lo && out_hi && out_lo && (alpha == nullptr) == (beta == nullptr), "gp_conv2d_stem_planes: null pointer");
+    GP_REQUIRE(scratch && scratch_bytes >= gp_conv2d_planes_workspace_bytes() && ((uintptr_t)scratch % 16 == 0), "gp_conv2d_stem_planes: scratch too small");
+    const int ni = Cout >= 256 ? 4 : Cout / 64;
+    a.tiles_i = (int)(npix / CT);
+    a.tiles_j = (Cout + 64 * ni - 1) / (64 * ni);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(scratch, 0, kHeaderBytes, st) != hipSuccess) return GP_ELAUNCH;
+    a.flags = reinterpret_cast<int*>(scratch);
+    a.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes);
+    g_epoch_conv = (g_epoch_conv + 1) & 0x3fffffff;
+    a.epoch = (int)(0x20000000u | g_epoch_conv);
+    a.status = gp_status_buffer();
+    GpProfScope prof(GP_PROF_CONV, 2.0 * Cout * (double)npix * 147.0, st);  // algorithmic: 3 x 7 x 7 taps
+    if (ni == 2) hipLaunchKernelGGL(conv_planes_kernel<2>, dim3(kSlots), dim3(CNT), 0, st, a);
+    else if (ni == 3) hipLaunchKernelGGL(conv_planes_kernel<3>, dim3(kSlots), dim3(CNT), 0, st, a);
+    else hipLaunchKernelGGL(conv_planes_kernel<4>, dim3(kSlots), dim3(CNT), 0, st, a);
+    GP_CHECK_LAUNCH("gp_conv2d_stem_planes");
     return GP_OK;
 }
 

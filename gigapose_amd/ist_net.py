@@ -154,7 +154,12 @@ class ResNet(nn.Module):
         for li in range(1, 5):
             for blk in getattr(self, f"layer{li}"):
                 blocks.append((conv(blk.conv1), conv(blk.conv2), None if blk.downsample is None else conv(blk.downsample[0])))
-        self._planes = dict(device=device, blocks=blocks, out=conv(self.layer4_outconv))
+        # stem (7 x 7, 3 channels): k = dy * 32 + dx * 4 + ci over a kernel row of 8 taps x 4 channels (dx = 7 and ci = 3 are zeros)
+        w = self.conv1.weight.detach().float().to(device)                     # (Cout, 3, 7, 7)
+        ws = torch.zeros(w.shape[0], 7, 8, 4, dtype=torch.float32, device=device)
+        ws[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+        stem = split_planes_x64(ws.reshape(w.shape[0], 224).contiguous()) if tuple(w.shape[1:]) == (3, 7, 7) else None
+        self._planes = dict(device=device, blocks=blocks, out=conv(self.layer4_outconv), stem=stem)
 
     def _conv_planes(self, cv, w, x, y, B, H, W, residual=None, relu=True, out_f32=None):
         """x, y, residual: (hi, lo) f16 plane pairs, channel-last, x 8 (gp_conv2d_planes)."""
@@ -214,9 +219,11 @@ class ResNet(nn.Module):
         if self._resized is None or self._resized.numel() < 3 * B * S * S:
             self._resized = torch.empty(3 * B * S * S, dtype=torch.float32, device=dev)
         xin = x.contiguous().float()
+        cur, y1, sc, nxt = self._bufs
+        if self.numerics == "split" and self.conv_kernel == "256" and self._stem_planes_ok(pk):
+            return self._forward_split(pk, None, out, B, S // 2, S // 2, (y1, sc, nxt), images=xin)   # stem in split numerics too
         _lib.call("gp_resize_bilinear_cm", _lib.ptr(xin), _lib.ptr(self._resized), _lib.i(B), _lib.i(3),
                   _lib.i(x.shape[2]), _lib.i(x.shape[3]), _lib.i(S), _lib.stream_ptr())
-        cur, y1, sc, nxt = self._bufs
         H, W = self._conv(pk["stem"], self._resized, cur, B, S, S)
         if self.numerics == "split":
             return self._forward_split(pk, cur, out, B, H, W, (y1, sc, nxt))
@@ -233,11 +240,15 @@ class ResNet(nn.Module):
         return out
 
 
-    def _forward_split(self, pk, stem_out, out, B, H, W, f32_bufs):
+    def _stem_planes_ok(self, pk):
+        st = pk["stem"]
+        return (st["cin"], st["k"], st["stride"], st["pad"]) == (3, 7, 2, 3) and st["cout"] in (128, 192, 256) and self.input_size % 2 == 0
+
+    def _forward_split(self, pk, stem_out, out, B, H, W, f32_bufs, images=None):
         """Everything after the stem in split numerics: channel-last f16 planes, gp_conv2d_nhwc_split.  The stem
         (7x7/2 on 3 channels, 1.6 % of the FLOPs) stays the f32 kernel; its channel-major output is split + transposed
         once.  The plane buffers alias the f32 ping-pong buffers (same bytes: 2 planes x f16 = f32)."""
-        dev = stem_out.device
+        dev = stem_out.device if stem_out is not None else images.device
         c0 = pk["stem"]["cout"]
         npix = B * H * W
         use256 = self.conv_kernel == "256"   # every later layer has B*OH*OW = B * 256 * 4^n pixels: multiples of 256
@@ -260,7 +271,23 @@ class ResNet(nn.Module):
             self._stem_planes = (torch.empty(c0 * npix, dtype=torch.float16, device=dev),
                                  torch.empty(c0 * npix, dtype=torch.float16, device=dev))
         cur = self._stem_planes
-        if use256:   # [C][npix] f32 -> [npix][C] planes of 8 x (single-accumulator convention)
+        if images is not None:   # resize -> zero-framed 4-channel planes -> the stem as conv_planes_kernel (one kernel row per k-step)
+            S = self.input_size
+            if getattr(self, "_framed", None) is None or self._framed[0].shape[0] != B or self._framed[0].device != dev:
+                self._framed = (torch.zeros(B, S + 6, S + 8, 4, dtype=torch.float16, device=dev),
+                                torch.zeros(B, S + 6, S + 8, 4, dtype=torch.float16, device=dev))   # the frame stays zero
+            _lib.call("gp_resize_stem_planes", _lib.ptr(images), _lib.ptr(self._framed[0]), _lib.ptr(self._framed[1]), _lib.i(B),
+                      _lib.i(images.shape[2]), _lib.i(images.shape[3]), _lib.i(S), _lib.stream_ptr())
+            lib = _lib.lib()
+            lib.gp_conv2d_planes_workspace_bytes.restype = ctypes.c_size_t
+            need = lib.gp_conv2d_planes_workspace_bytes()
+            if self._conv_scratch is None or self._conv_scratch.device != dev:
+                self._conv_scratch = torch.zeros((need + 3) // 4, dtype=torch.float32, device=dev)
+            st, sw = pk["stem"], weights["stem"]
+            _lib.call("gp_conv2d_stem_planes", _lib.ptr(self._framed[0]), _lib.ptr(self._framed[1]), _lib.ptr(sw[0]), _lib.ptr(sw[1]),
+                      _lib.ptr(st["alpha"]), _lib.ptr(st["beta"]), _lib.i(B), _lib.i(S), _lib.i(c0), _lib.i(1), _lib.ptr(cur[0]), _lib.ptr(cur[1]),
+                      _lib.ptr(self._conv_scratch), ctypes.c_size_t(need), _lib.stream_ptr())
+        elif use256:   # [C][npix] f32 -> [npix][C] planes of 8 x (single-accumulator convention)
             _lib.call("gp_planes_from_cm", _lib.ptr(stem_out), _lib.i(c0), _lib.i(npix), _lib.ptr(cur[0]), _lib.ptr(cur[1]), _lib.stream_ptr())
         else:        # ... of x with the low half scaled by 2^11 (two-accumulator convention)
             _lib.call("gp_split_weights", _lib.ptr(stem_out), _lib.i(c0), _lib.i(npix), _lib.i(npix), _lib.ptr(cur[0]),

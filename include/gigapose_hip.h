@@ -282,6 +282,16 @@ int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const
                      const void* res_hi, const void* res_lo, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                      int relu, void* out_hi, void* out_lo, float* out_f32_nchw, float* scratch, size_t scratch_bytes, void* stream);
 
+/* The ResNet stem (reference resnet.py:333-337, 366-370: bilinear resize to S x S, Conv2d(3 -> Cout, 7 x 7, stride 2, padding 3, no
+ * bias) + BatchNorm + ReLU) in split numerics: gp_resize_stem_planes writes the resized crops as 4-channel planes (B, S + 6, S + 8,
+ * 4) x 8 inside a frame of zeros (the caller zeroes the buffers ONCE: the frame is never written) so that a kernel row of 8 taps is
+ * 64 contiguous bytes and no tap needs a range check; gp_conv2d_stem_planes runs conv_planes_kernel over them, one kernel row per
+ * k-step: k = dy * 32 + dx * 4 + ci, K = 224, weight planes (Cout, 224) of 64 w with zeros at dx = 7 and ci = 3; output planes
+ * (B * (S/2)^2, Cout) x 8. */
+int gp_resize_stem_planes(const float* images, void* hi, void* lo, int B, int IH, int IW, int S, void* stream);
+int gp_conv2d_stem_planes(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* alpha, const float* beta,
+                          int B, int S, int Cout, int relu, void* out_hi, void* out_lo, float* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- IST regressor: ISTNet.inference (src/models/network/ist_net.py:97-120) ----------------- */
 
 size_t gp_ist_workspace_bytes(int B, int k, int D, int H);

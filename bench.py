@@ -30,7 +30,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense f32-input MFMA peak (MI355X_MICROAR
 FLOP_PER_CROP = {"dinov2_vitl14": 162.0e9, "dinov2_vits14": 12.25e9, "dinov2_vitb14": 0.0}
 
 
-def cpu_baseline(variant, n_templates, k, sample_crops=4, threads=None):
+def cpu_baseline(variant, n_templates, k, sample_crops=32, threads=None):
     """The reference's CPU path restated operator for operator in torch (oracle/torch_port.py: HF DINOv2 stand-in forward
     in sub-batches of 4 detections, the 170 MB / detection bank gather, LocalSimilarity.test with its materialised
     similarity tensor, the IST backbone recomputed k times, MLP heads; RANSAC / recovery through the C oracle) on

@@ -976,12 +976,23 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
                 // Q | K | V as planes [Mpad][3C] (aliasing the f32 QK + Vt buffers): W_qk / W_v (A) x tokens (B), plane epilogue
                 _Float16* Ahi = reinterpret_cast<_Float16*>(QK);
                 _Float16* Alo = Ahi + (size_t)3 * C * Mpad;
-                if ((rc = gp_gemm_planes256_launch(sq[S_QK_HI], sq[S_QK_LO], Hhi, Hlo, nullptr, 0, Ahi, Alo, 3 * C, 2 * C, Mpad, Mtok, C,
-                                                   7 /*BIAS_I -> planes*/, w[L_QK_B], nullptr, nullptr, 0, os, SK, st)))
-                    return rc;
-                if ((rc = gp_gemm_planes256_launch(sq[S_V_HI], sq[S_V_LO], Hhi, Hlo, nullptr, 0, Ahi + 2 * C, Alo + 2 * C, 3 * C, C, Mpad, Mtok, C,
-                                                   7 /*BIAS_I -> planes*/, w[L_V_B], nullptr, nullptr, 0, os, SK, st)))
-                    return rc;
+                // one launch when the host packed q|k and v contiguously (planes and biases are views of one tensor, vit.py): 12 x 64 =
+                // 768 tiles = 3 per slot instead of 512 + 256 in two launches (one strip, one launch boundary less per layer)
+                const bool fused_qkv = (const char*)sq[S_V_HI] == (const char*)sq[S_QK_HI] + (size_t)2 * C * C * 2 &&
+                                       (const char*)sq[S_V_LO] == (const char*)sq[S_QK_LO] + (size_t)2 * C * C * 2 && w[L_V_B] == w[L_QK_B] + 2 * C &&
+                                       gp_gemm_planes256_usable(3 * C, Mpad, Mtok, C);
+                if (fused_qkv) {
+                    if ((rc = gp_gemm_planes256_launch(sq[S_QK_HI], sq[S_QK_LO], Hhi, Hlo, nullptr, 0, Ahi, Alo, 3 * C, 3 * C, Mpad, Mtok, C,
+                                                       7 /*BIAS_I -> planes*/, w[L_QK_B], nullptr, nullptr, 0, os, SK, st)))
+                        return rc;
+                } else {
+                    if ((rc = gp_gemm_planes256_launch(sq[S_QK_HI], sq[S_QK_LO], Hhi, Hlo, nullptr, 0, Ahi, Alo, 3 * C, 2 * C, Mpad, Mtok, C,
+                                                       7 /*BIAS_I -> planes*/, w[L_QK_B], nullptr, nullptr, 0, os, SK, st)))
+                        return rc;
+                    if ((rc = gp_gemm_planes256_launch(sq[S_V_HI], sq[S_V_LO], Hhi, Hlo, nullptr, 0, Ahi + 2 * C, Alo + 2 * C, 3 * C, C, Mpad, Mtok, C,
+                                                       7 /*BIAS_I -> planes*/, w[L_V_B], nullptr, nullptr, 0, os, SK, st)))
+                        return rc;
+                }
                 {
                     GpProfScope prof(GP_PROF_ATTN, 4.0 * B * heads * 257.0 * 257.0 * 64.0, st);
                     hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(576), 0, st, Ahi, Alo, Hhi, Hlo, B,

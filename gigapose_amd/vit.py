@@ -190,9 +190,10 @@ class Dinov2ViT(nn.Module):
                    dev(self.pos_embed[0, 1:].t())]
         for blk in self.blocks:
             qkv_w, qkv_b = blk.attn.qkv.weight, blk.attn.qkv.bias
+            qkv_bd = dev(qkv_b)   # ONE tensor: the q|k and v biases are views, so a fused q|k|v launch can read them as one (3C) bias
             tensors += [dev(blk.norm1.weight), dev(blk.norm1.bias),
-                        dev(qkv_w[:2 * C].t()), dev(qkv_b[:2 * C]),
-                        dev(qkv_w[2 * C:].t()), dev(qkv_b[2 * C:]),
+                        dev(qkv_w[:2 * C].t()), qkv_bd[:2 * C],
+                        dev(qkv_w[2 * C:].t()), qkv_bd[2 * C:],
                         dev(blk.attn.proj.weight.t()), dev(blk.attn.proj.bias), dev(blk.ls1.gamma),
                         dev(blk.norm2.weight), dev(blk.norm2.bias),
                         dev(blk.mlp.fc1.weight.t()), dev(blk.mlp.fc1.bias),
@@ -207,9 +208,13 @@ class Dinov2ViT(nn.Module):
                 for w in ws:                       # entries 0..9: hi + lo * 2^-11 planes (128 x 128 kernel)
                     split += list(split_planes(w))
                 if os.environ.get("GIGAPOSE_SPLIT_GEMM", "256") != "128":
-                    for w in ws:                   # entries 10..19: x64 single-accumulator planes (256 x 256 kernel;
-                        split += list(split_planes_x64(w))  # needs |activation| < 8190 -- GIGAPOSE_SPLIT_GEMM=128 keeps
-                                                            # every GEMM on the two-accumulator kernel, range 65504)
+                    # entries 10..19: x64 single-accumulator planes (256 x 256 kernel; needs |activation| < 8190 --
+                    # GIGAPOSE_SPLIT_GEMM=128 keeps every GEMM on the two-accumulator kernel, range 65504).  The q|k and v planes are
+                    # views of ONE (3C, C) tensor: gp_vit_forward_split then runs q|k|v as a single launch (768 tiles at B = 64)
+                    qkv_hi, qkv_lo = split_planes_x64(qkv_w)
+                    split += [qkv_hi[:2 * C], qkv_lo[:2 * C], qkv_hi[2 * C:], qkv_lo[2 * C:]]
+                    for w in ws[2:]:
+                        split += list(split_planes_x64(w))
             split_table = (ctypes.c_void_p * len(split))(*[t.data_ptr() for t in split])
             if "GIGAPOSE_VIT_PLANES" in os.environ:  # A/B probes (csrc/gp_vit.hip): 0 f32 activations, 1 f32 attention, 2 default
                 _lib.lib().gp_vit_set_planes(int(os.environ["GIGAPOSE_VIT_PLANES"]))

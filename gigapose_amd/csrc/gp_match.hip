@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void l2norm_cp_kernel(const float* __restrict_
 using MM = KMajor<4, 2, 2, 4, 16>;
 static_assert(MM::BM == 256 && MM::BN == 256 && MM::NT == 512, "matcher tile must be 256x256");
 
-struct MatchSmem {
+struct alignas(16) MatchSmem {
     float stage[MM::LDS_FLOATS];  // 64 KiB operand staging
     float qmask[GP_P];
     float smask[GP_P];
@@ -54,13 +54,35 @@ struct MatchSmem {
     float maskv[GP_P];
 };
 
+// One step of the row-maximum reduce-scatter (match_epilogue): lanes L and L ^ CNT split the 2 CNT rows they both still hold --
+// the lane with bit CNT set keeps the upper CNT rows, its partner the lower -- and fold the partner's candidates into theirs.
+// CNT is a template parameter so that every rv[] / ri[] index is a compile-time constant (registers, not select chains).
+template <int CNT>
+__device__ __forceinline__ void rowmax_exchange(float (&rv)[32], int (&ri)[32], int lane)
+{
+    const bool hi = (lane & CNT) != 0;
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) {
+        const float sv = hi ? rv[j] : rv[j + CNT];
+        const int si = hi ? ri[j] : ri[j + CNT];
+        const float mv = hi ? rv[j + CNT] : rv[j];
+        const int mj = hi ? ri[j + CNT] : ri[j];
+        const float ov = __shfl_xor(sv, CNT);
+        const int oi = __shfl_xor(si, CNT);
+        const bool take = (ov > mv) | ((ov == mv) & (oi < mj));
+        rv[j] = take ? ov : mv;
+        ri[j] = take ? oi : mj;
+    }
+}
+
 // Everything after the 256x256 similarity tile sits in the accumulators (8 waves as 4 (t) x 2 (s), wave tile
 // 64 x 128 = acc[2][4]): masks, threshold, bidirectional argmax, cycle check, template score.  Shared by the
 // f32-chain kernel and the split-f16 kernel (gp_match_split below); SM is the kernel's shared-memory struct.
 template <class SM>
 __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int b, int n, int N, float thr, float patch_thr,
                                                uint8_t* __restrict__ idx_t2s, float* __restrict__ score_t2s,
-                                               float* __restrict__ mask_all, float* __restrict__ sim_avg)
+                                               float* __restrict__ mask_all, float* __restrict__ sim_avg,
+                                               unsigned long long* trace = nullptr)  // probe build only: 8 stamps per tile
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -84,6 +106,12 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
         }
 
     // ---- row maxima (over s, first max wins)   torch.max(sim, dim=3)  (matching.py:240)
+    // (value desc, index asc) is a total order, so any reduction tree gives the same winner.  Each lane first folds its
+    // 4 column blocks, then the 32 lanes of a half-wave run a reduce-scatter butterfly over the 32 rows they share:
+    // at offset 16 a lane hands 16 rows to its partner and keeps 16, at 8 it keeps 8, ... -- 31 exchanges per lane
+    // instead of 32 x 5, all selects (no short-circuit branches), and lane L ends up owning row L.
+    float rv[32];
+    int ri[32];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -93,20 +121,24 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
 #pragma unroll
             for (int ni = 1; ni < 4; ++ni) {
                 const float x = acc[mi][ni][r];
-                if (x > bv) { bv = x; bi = s_lane + 32 * ni; }
+                const bool take = x > bv;
+                bv = take ? x : bv;
+                bi = take ? s_lane + 32 * ni : bi;
             }
-#pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) {
-                const float ov = __shfl_xor(bv, off);
-                const int oi = __shfl_xor(bi, off);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            if ((lane & 31) == 0) {
-                const int t = t_lane + 32 * mi + (r & 3) + 8 * (r >> 2);
-                sm.rowv[wc][t] = bv;
-                sm.rowi[wc][t] = bi;
-            }
+            rv[mi * 16 + r] = bv;
+            ri[mi * 16 + r] = bi;
         }
+    rowmax_exchange<16>(rv, ri, lane);  // exchange offset == rows kept
+    rowmax_exchange<8>(rv, ri, lane);
+    rowmax_exchange<4>(rv, ri, lane);
+    rowmax_exchange<2>(rv, ri, lane);
+    rowmax_exchange<1>(rv, ri, lane);
+    {
+        const int j = lane & 31;  // the row this lane ended up with: mi = j >> 4, r = j & 15
+        const int t = t_lane + 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2);
+        sm.rowv[wc][t] = rv[0];
+        sm.rowi[wc][t] = ri[0];
+    }
 
     // ---- column maxima (over t, first max wins)   torch.max(sim, dim=2)  (matching.py:241)
 #pragma unroll
@@ -129,6 +161,7 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
         }
     }
     __syncthreads();
+    if (trace && tid == 0) trace[3] = wall_clock64();
 
     // ---- merge the per-wave partials (lower index range first, strict > keeps first max)
     if (tid < GP_P) {
@@ -148,6 +181,7 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
         sm.id_s2t[s] = bi;
     }
     __syncthreads();
+    if (trace && tid == 0) trace[4] = wall_clock64();
 
     // ---- masks + per-patch outputs   (matching.py:247-271, find_consistency_patches :80-113)
     if (tid < GP_P) {
@@ -174,13 +208,27 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
         sm.maskv[t] = m;
     }
     __syncthreads();
-    if (tid == 0) {  // fixed sequential order (oracle: same loop); 256 adds, negligible
+    if (trace && tid == 0) trace[5] = wall_clock64();
+    if (tid == 0) {  // fixed sequential order (oracle: same loop); loads batched 32 at a time, adds stay in order
         float a = 0.f, cnt = 0.f;
-        for (int t = 0; t < GP_P; ++t) {
-            a = a + sm.contrib[t];
-            cnt = cnt + sm.maskv[t];
+#pragma unroll 1
+        for (int t0 = 0; t0 < GP_P; t0 += 32) {
+            f32x4 c[8], m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                c[u] = *reinterpret_cast<const f32x4*>(&sm.contrib[t0 + 4 * u]);
+                m[u] = *reinterpret_cast<const f32x4*>(&sm.maskv[t0 + 4 * u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a = a + c[u][e];
+                    cnt = cnt + m[u][e];
+                }
         }
         sim_avg[(size_t)b * N + n] = (cnt > 0.f) ? a / 256.0f : 0.f;
+        if (trace) trace[6] = wall_clock64();
     }
 }
 
@@ -236,7 +284,7 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 constexpr float kFeatScale = 32.0f;
 constexpr int MS_BK = 32, MS_PLANE = 256 * MS_BK;  // halfs per plane per buffer
 
-struct MatchSplitSmem {
+struct alignas(16) MatchSplitSmem {
     _Float16 stage[2 * 4 * MS_PLANE];  // 128 KiB
     float qmask[GP_P];
     float smask[GP_P];
@@ -260,17 +308,27 @@ struct MatchSplitSmem {
 // bytes, 2 of the 3 products; the query keeps both planes) -- f16-rounded template features, measured flip rate in DESIGN.md.
 typedef unsigned int mu32x4 __attribute__((ext_vector_type(4)));
 
-template <bool BANK_LO>
+template <bool BANK_LO, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo,  // (B, 256, C)
     const _Float16* __restrict__ b_hi, const _Float16* __restrict__ b_lo,  // (O*N, 256, C)
     const float* __restrict__ qmask, const float* __restrict__ bmask, const int* __restrict__ labels, int B, int O, int N, int C,
     float thr, float patch_thr, int* __restrict__ status, uint8_t* __restrict__ idx_t2s, float* __restrict__ score_t2s,
-    float* __restrict__ mask_all, float* __restrict__ sim_avg)
+    float* __restrict__ mask_all, float* __restrict__ sim_avg, unsigned long long* __restrict__ trace_all)
 {
     __shared__ MatchSplitSmem sm;
+    const unsigned long long w_in = TRACE ? wall_clock64() : 0;
     const int q = xcd_chunked_tile(blockIdx.x, B * N);
     if (q < 0) return;
+    unsigned long long* trace = TRACE ? trace_all + (size_t)q * 8 : nullptr;
+    if (TRACE && threadIdx.x == 0) {
+        unsigned hw;  // HW_ID: cu 8..11, sh 12, se 13..15 (+ XCC_ID register 20 on gfx94x/95x)
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trace[0] = w_in;
+        trace[7] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+    }
     const int band = q / (8 * N), r8 = q - band * (8 * N);
     const int gsz = min(8, B - band * 8);
     const int b = band * 8 + r8 % gsz, n = r8 / gsz;
@@ -343,6 +401,7 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     __builtin_amdgcn_sched_barrier(0);
     if (ns > 1) gload(1);
     __syncthreads();
+    if (TRACE && tid == 0) trace[1] = wall_clock64();
 
 #define M_MFMA(A_, B_, mi, ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[mi], B_[ni], acc[mi][ni], 0, 0, 0)
     auto c_phase = [&](int s) __attribute__((always_inline)) {
@@ -402,6 +461,7 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     }
 #undef M_MFMA
     __syncthreads();  // the epilogue reuses nothing of `stage`, but its first LDS writes must follow every wave's mask reads
+    if (TRACE && tid == 0) trace[2] = wall_clock64();
 
     constexpr float inv = 1.0f / (kFeatScale * kFeatScale);  // exact power of two
 #pragma unroll
@@ -410,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= inv;
-    match_epilogue(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg);
+    match_epilogue(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg, trace);
 }
 
 // norms of gp_l2norm_cp (same sequential fma over c), then x / d * 32 split into f16 planes [row][patch][C].
@@ -573,10 +633,10 @@ int gp_l2norm_split(const float* x, void* hi, void* lo, int rows, int C, void* s
     return GP_OK;
 }
 
-int gp_match_tiles_split(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
-                         const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
-                         float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
-                         void* stream)
+static int match_tiles_split_launch(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
+                                    const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
+                                    float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
+                                    unsigned long long* trace, void* stream)
 {
     GP_REQUIRE(B >= 0 && O > 0 && N > 0, "gp_match_tiles_split: bad sizes B=%d O=%d N=%d", B, O, N);
     GP_REQUIRE(C > 0 && C % 32 == 0, "gp_match_tiles_split: C=%d must be a positive multiple of 32", C);
@@ -585,16 +645,43 @@ int gp_match_tiles_split(const void* q_hi, const void* q_lo, const void* b_hi, c
                "gp_match_tiles_split: null pointer");
     GP_REQUIRE((long long)GP_P * C * 2 < (1ll << 31), "gp_match_tiles_split: C too large");
     GpProfScope prof(GP_PROF_MATCH_SPLIT, 2.0 * B * N * 256.0 * 256.0 * C, (hipStream_t)stream);
-    if (b_lo)
-        hipLaunchKernelGGL(match_tiles_split_kernel<true>, dim3(xcd_chunked_grid(B * N)), dim3(512), 0, (hipStream_t)stream,
-                           (const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)b_hi, (const _Float16*)b_lo, qmask,
-                           bmask, labels, B, O, N, C, sim_threshold, patch_threshold, gp_status_buffer(), idx_t2s, score_t2s, mask_all, sim_avg);
-    else  // fp16 bank: hi plane only
-        hipLaunchKernelGGL(match_tiles_split_kernel<false>, dim3(xcd_chunked_grid(B * N)), dim3(512), 0, (hipStream_t)stream,
-                           (const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)b_hi, (const _Float16*)nullptr, qmask,
-                           bmask, labels, B, O, N, C, sim_threshold, patch_threshold, gp_status_buffer(), idx_t2s, score_t2s, mask_all, sim_avg);
+#define GP_MATCH_SPLIT_LAUNCH(LO, TR)                                                                                             \
+    hipLaunchKernelGGL((match_tiles_split_kernel<LO, TR>), dim3(xcd_chunked_grid(B * N)), dim3(512), 0, (hipStream_t)stream,      \
+                       (const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)b_hi, (const _Float16*)b_lo, qmask, bmask,  \
+                       labels, B, O, N, C, sim_threshold, patch_threshold, gp_status_buffer(), idx_t2s, score_t2s, mask_all,      \
+                       sim_avg, trace)
+    if (trace) {
+        GP_REQUIRE(b_lo, "gp_match_tiles_split_trace: the probe build takes the two-plane bank");
+        GP_MATCH_SPLIT_LAUNCH(true, true);
+    } else if (b_lo) {
+        GP_MATCH_SPLIT_LAUNCH(true, false);
+    } else {  // fp16 bank: hi plane only
+        GP_MATCH_SPLIT_LAUNCH(false, false);
+    }
+#undef GP_MATCH_SPLIT_LAUNCH
     GP_CHECK_LAUNCH("gp_match_tiles_split");
     return GP_OK;
+}
+
+int gp_match_tiles_split(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
+                         const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
+                         float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
+                         void* stream)
+{
+    return match_tiles_split_launch(q_hi, q_lo, b_hi, b_lo, qmask, bmask, labels, B, O, N, C, sim_threshold, patch_threshold,
+                                    idx_t2s, score_t2s, mask_all, sim_avg, nullptr, stream);
+}
+
+// probe build: trace[(tile q) * 8 + i] = 100 MHz wall-clock stamps (0 entry, 1 first slab staged, 2 k loop done, 3 maxima,
+// 4 merge, 5 per-patch outputs, 6 end) and [7] = XCC_ID << 32 | HW_ID (tools/probe_match_fixed.py)
+int gp_match_tiles_split_trace(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
+                               const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
+                               float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
+                               unsigned long long* trace, void* stream)
+{
+    GP_REQUIRE(trace, "gp_match_tiles_split_trace: null trace buffer");
+    return match_tiles_split_launch(q_hi, q_lo, b_hi, b_lo, qmask, bmask, labels, B, O, N, C, sim_threshold, patch_threshold,
+                                    idx_t2s, score_t2s, mask_all, sim_avg, trace, stream);
 }
 
 int gp_topk(const float* sim_avg, int B, int N, int k, int* ids, float* scores, void* stream)

@@ -93,6 +93,11 @@ int gp_match_tiles_split(const void* q_hi, const void* q_lo, const void* b_hi, c
                          const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
                          float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
                          void* stream);
+/* probe build of gp_match_tiles_split (two-plane bank) writing 8 time stamps per tile, see gp_match.hip */
+int gp_match_tiles_split_trace(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
+                         const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
+                         float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
+                         unsigned long long* trace, void* stream);
 
 /* torch.topk(sim_avg, k, dim=1) (matching.py:279); ties: lower template index first.
  * Fails (-1) when k > N, like torch.topk raises. ids int32 (B,k), scores (B,k). */

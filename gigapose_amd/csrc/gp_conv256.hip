@@ -452,7 +452,8 @@ int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const
     const long long n_tiles = (long long)a.tiles_i * a.tiles_j, units = n_tiles * (a.K / CBK);
     int slots_x = 32;
     while (slots_x > 1 && n_tiles < 8 * slots_x && units / (8 * slots_x) < 32) slots_x >>= 1;
-    if (hipMemsetAsync(scratch, 0, kHeaderBytes, st) != hipSuccess) return GP_ELAUNCH;
+    // no per-launch reset of the hand-off flags: a flag is valid only when it holds THIS launch's epoch (below); the
+    // scratch must start zeroed once (the caller allocates it with zeros)
     a.flags = reinterpret_cast<int*>(scratch);
     a.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes);
     g_epoch_conv = (g_epoch_conv + 1) & 0x3fffffff;
@@ -501,7 +502,8 @@ int gp_conv2d_stem_planes(const void* x_hi, const void* x_lo, const void* w_hi, 
     a.tiles_i = (int)(npix / CT);
     a.tiles_j = (Cout + 64 * ni - 1) / (64 * ni);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(scratch, 0, kHeaderBytes, st) != hipSuccess) return GP_ELAUNCH;
+    // no per-launch reset of the hand-off flags: a flag is valid only when it holds THIS launch's epoch (below); the
+    // scratch must start zeroed once (the caller allocates it with zeros)
     a.flags = reinterpret_cast<int*>(scratch);
     a.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes);
     g_epoch_conv = (g_epoch_conv + 1) & 0x3fffffff;

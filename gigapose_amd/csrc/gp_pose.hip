@@ -230,6 +230,76 @@ __global__ __launch_bounds__(64) void recover_kernel(
     o[12] = tP[12]; o[13] = tP[13]; o[14] = tP[14]; o[15] = tP[15];
 }
 
+// ------------------------------------------------------------------ hypothesis ranking (gigaPose.py:588-594)
+// score[b, j] = sum_p inlier_score[b, j, p] / P (an integer sum: exact in any order), then every per-hypothesis tensor
+// of the prediction collection is reordered along k by descending score (ties: lower hypothesis index first -- the
+// reference's torch.argsort leaves ties unspecified; NaN cannot occur, the sum is an integer).  One launch replaces
+// torch.sum + a stable sort + one advanced-indexing kernel per tensor (13 of them).
+constexpr int GP_RANK_MAX_TENSORS = 16, GP_RANK_MAX_K = 64;
+struct RankTable {
+    const unsigned char* src[GP_RANK_MAX_TENSORS];
+    unsigned char* dst[GP_RANK_MAX_TENSORS];
+    int row_bytes[GP_RANK_MAX_TENSORS];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void rank_hypotheses_kernel(const long long* __restrict__ inl_score, int k, int P, int sort,
+                                                               float* __restrict__ scores, long long* __restrict__ order,
+                                                               RankTable tab)
+{
+    __shared__ long long part[4][GP_RANK_MAX_K];
+    __shared__ float sc[GP_RANK_MAX_K];
+    __shared__ int rank[GP_RANK_MAX_K];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int j = 0; j < k; ++j) {
+        long long acc = 0;
+        for (int p = tid; p < P; p += 256) acc += inl_score[((size_t)b * k + j) * P + p];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) part[wave][j] = acc;
+    }
+    __syncthreads();
+    if (tid < k) {  // torch: int64 sum / int -> both operands converted to float32, true division
+        const long long t = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+        sc[tid] = (float)t / (float)P;
+    }
+    __syncthreads();
+    if (tid < k) {
+        int r = tid;
+        if (sort) {
+            r = 0;
+            for (int i = 0; i < k; ++i) r += (sc[i] > sc[tid]) | ((sc[i] == sc[tid]) & (i < tid));
+        }
+        rank[tid] = r;
+        scores[(size_t)b * k + r] = sc[tid];
+        order[(size_t)b * k + r] = tid;
+    }
+    __syncthreads();
+    for (int t = 0; t < tab.n; ++t) {
+        const int rb = tab.row_bytes[t];
+        const unsigned char* s = tab.src[t] + (size_t)b * k * rb;
+        unsigned char* d = tab.dst[t] + (size_t)b * k * rb;
+        if ((rb & 15) == 0 && (((size_t)s | (size_t)d) & 15) == 0) {
+            const int w = rb >> 4;
+            for (int i = tid; i < k * w; i += 256) {
+                const int j = i / w, c = i - j * w;
+                reinterpret_cast<uint4*>(d)[(size_t)rank[j] * w + c] = reinterpret_cast<const uint4*>(s)[i];
+            }
+        } else if ((rb & 3) == 0 && (((size_t)s | (size_t)d) & 3) == 0) {
+            const int w = rb >> 2;
+            for (int i = tid; i < k * w; i += 256) {
+                const int j = i / w, c = i - j * w;
+                reinterpret_cast<unsigned*>(d)[(size_t)rank[j] * w + c] = reinterpret_cast<const unsigned*>(s)[i];
+            }
+        } else {
+            for (int i = tid; i < k * rb; i += 256) {
+                const int j = i / rb, c = i - j * rb;
+                d[(size_t)rank[j] * rb + c] = s[i];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -259,6 +329,29 @@ int gp_recover_poses(const int* labels, const float* tar_K, const float* tar_M, 
     hipLaunchKernelGGL(recover_kernel, dim3((B * k + 63) / 64), dim3(64), 0, (hipStream_t)stream, labels, tar_K,
                        tar_M, id_src, pred_M, tmpl_K, tmpl_M, tmpl_pose, B, O, N, k, poses, bad_crop_M, gp_status_buffer());
     GP_CHECK_LAUNCH("gp_recover_poses");
+    return GP_OK;
+}
+
+int gp_rank_hypotheses(const long long* inl_score, int B, int k, int P, int sort, float* scores, long long* order, int n_tensors,
+                       const void* const* src, void* const* dst, const int* row_bytes, void* stream)
+{
+    GP_REQUIRE(B >= 0 && k > 0 && k <= GP_RANK_MAX_K && P > 0, "gp_rank_hypotheses: bad sizes B=%d k=%d P=%d (k <= %d)", B, k, P,
+               GP_RANK_MAX_K);
+    GP_REQUIRE(n_tensors >= 0 && n_tensors <= GP_RANK_MAX_TENSORS, "gp_rank_hypotheses: at most %d tensors per call, got %d",
+               GP_RANK_MAX_TENSORS, n_tensors);
+    if (B == 0) return GP_OK;
+    GP_REQUIRE(inl_score && scores && order && (n_tensors == 0 || (src && dst && row_bytes)), "gp_rank_hypotheses: null pointer");
+    RankTable tab;
+    tab.n = n_tensors;
+    for (int t = 0; t < n_tensors; ++t) {
+        GP_REQUIRE(src[t] && dst[t] && src[t] != dst[t] && row_bytes[t] > 0,
+                   "gp_rank_hypotheses: bad tensor %d (null, empty rows, or in place)", t);
+        tab.src[t] = static_cast<const unsigned char*>(src[t]);
+        tab.dst[t] = static_cast<unsigned char*>(dst[t]);
+        tab.row_bytes[t] = row_bytes[t];
+    }
+    hipLaunchKernelGGL(rank_hypotheses_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, inl_score, k, P, sort, scores, order, tab);
+    GP_CHECK_LAUNCH("gp_rank_hypotheses");
     return GP_OK;
 }
 

@@ -11,6 +11,7 @@ What changes relative to the reference control flow (results are identical):
   * the only host syncs per image are the label upload and the final result download.
 """
 import os
+import ctypes
 import os.path as osp
 import time
 
@@ -45,6 +46,35 @@ def stable_argsort_desc(score):
     """argsort(score, dim=1, descending=True) with ties -> lower hypothesis index first
     (the reference's torch.argsort leaves tie order unspecified, gigaPose.py:591)."""
     return torch.sort(score, dim=1, descending=True, stable=True).indices
+
+
+def rank_hypotheses(pred, sort=True):
+    """gigaPose.py:588-594 in one launch (gp_rank_hypotheses): scores = sum(ransac_scores, dim=2) / num_patches
+    (an int64 sum: exact), and -- when `sort` -- every tensor of the collection reordered along k by descending score,
+    ties keeping the lower hypothesis index (stable_argsort_desc).  Registers "scores"; returns the order (B,k)."""
+    isc = pred.ransac_scores.contiguous()
+    B, k, num_patches = isc.shape
+    dev = isc.device
+    score = torch.empty(B, k, dtype=torch.float32, device=dev)
+    order = torch.empty(B, k, dtype=torch.int64, device=dev)
+    names = list(pred.tensors) if sort else []
+    srcs = [pred.tensors[n].contiguous() for n in names]
+    for v in srcs:
+        if v.shape[:2] != (B, k):
+            raise ValueError(f"per-hypothesis tensors must be (B, k, ...), got {tuple(v.shape)}")
+    dsts = [torch.empty_like(v) for v in srcs]
+    for s0 in range(0, max(len(srcs), 1), 16):                                   # the launch takes <= 16 tensors
+        a, b = srcs[s0:s0 + 16], dsts[s0:s0 + 16]
+        n = len(a)
+        src_t = (ctypes.c_void_p * max(n, 1))(*[v.data_ptr() for v in a])
+        dst_t = (ctypes.c_void_p * max(n, 1))(*[v.data_ptr() for v in b])
+        rb_t = (ctypes.c_int * max(n, 1))(*[v[0, 0].numel() * v.element_size() if B else 1 for v in a])
+        _lib.call("gp_rank_hypotheses", _lib.ptr(isc), _lib.i(B), _lib.i(k), _lib.i(num_patches), _lib.i(1 if sort else 0),
+                  _lib.ptr(score), _lib.ptr(order), _lib.i(n), src_t, dst_t, rb_t, _lib.stream_ptr())
+    for name, v in zip(names, dsts):
+        pred.register_tensor(name, v)
+    pred.register_tensor("scores", score)
+    return order
 
 
 class GigaPose(_Base):
@@ -146,6 +176,10 @@ class GigaPose(_Base):
             raise IndexError(f"detection label outside 1..{n_obj} (the reference indexes ae_features[label - 1], gigaPose.py:520)")
         if tar_img.is_cuda:
             _lib.status_word(tar_img.device)  # device labels / hand-offs / split range are checked by the kernels (check_status)
+        if not labels.is_cuda and tar_img.is_cuda:
+            # stream-ordered upload from pinned memory: a pageable-memory copy would block the host until the stream drains,
+            # i.e. a host sync per call that exposes the launch latency of everything after it
+            labels = labels.pin_memory().to(tar_img.device, non_blocking=True)
         labels0 = (labels.to(tar_img.device) - 1).to(torch.int32).contiguous()
         side = None
         if self.overlap_ist and tar_img.is_cuda:
@@ -177,14 +211,7 @@ class GigaPose(_Base):
         pred.register_tensor("relScale", rel_scale)
         pred.register_tensor("relInplane", rel_inplane)
         pred = self.pose_recovery[dataset_name].forward_ransac(predictions=pred)  # stage 5
-        num_patches = pred.src_pts.shape[2]
-        score = torch.sum(pred.ransac_scores, dim=2) / num_patches               # gigaPose.py:588
-        pred.register_tensor("scores", score)
-        if sort_pred_by_inliers:
-            order = stable_argsort_desc(score)
-            rows = torch.arange(score.shape[0], device=score.device)[:, None]
-            for name, v in list(pred.tensors.items()):
-                pred.register_tensor(name, v[rows, order])
+        rank_hypotheses(pred, sort_pred_by_inliers)                              # gigaPose.py:588-594, one launch
         poses = self.pose_recovery[dataset_name].forward_recovery(                # stage 6
             tar_label=labels, tar_K=tar_K, tar_M=tar_M, pred_src_views=pred.id_src, pred_M=pred.M)
         pred.register_tensor("pred_poses", poses)

@@ -280,7 +280,8 @@ int gp_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* w_hi, c
  * single-accumulator convention of gp_gemm_planes256: activations / residual / output hi = f16(8 x), lo = f16(8 x - hi)
  * (|x| < 8190, guarded through the status word), weights (Cout, KH*KW*Cin) planes of 64 w (gp_split256_weights), k =
  * (dy*KW + dx)*Cin + ci.  Requires Cin % 32 == 0, Cout % 64 == 0, KH*KW <= 9, B*OH*OW % 256 == 0; scratch of
- * gp_conv2d_planes_workspace_bytes() bytes (stream-K hand-overs).  gp_planes_from_cm: f32 [C][npix] -> such planes [npix][C]. */
+ * gp_conv2d_planes_workspace_bytes() bytes (stream-K hand-overs; zeroed ONCE by the caller at allocation -- launches tag their
+ * hand-off flags with a per-launch epoch and never reset them).  gp_planes_from_cm: f32 [C][npix] -> such planes [npix][C]. */
 size_t gp_conv2d_planes_workspace_bytes(void);
 int gp_planes_from_cm(const float* X, int C, int npix, void* hi, void* lo, void* stream);
 int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* alpha, const float* beta,
@@ -336,6 +337,14 @@ int gp_ransac(const long long* src_pts, const long long* tar_pts, const float* r
 int gp_recover_poses(const int* labels, const float* tar_K, const float* tar_M, const long long* id_src,
                      const float* pred_M, const float* tmpl_K, const float* tmpl_M, const float* tmpl_pose, int B,
                      int O, int N, int k, float* poses, int* bad_crop_M, void* stream);
+
+/* ---- hypothesis ranking: GigaPose.eval_retrieval's score + sort (src/models/gigaPose.py:588-594) ----
+ * inl_score (B,k,P) int64 = RANSAC inlier scores -> scores (B,k) = sum / P in float32, written in ranked order; order (B,k)
+ * int64 = the hypothesis index at each rank (sort != 0: descending score, ties keep the lower index; sort == 0: identity).
+ * Each of the n_tensors (<= 16) tensors src[t] (B,k,row_bytes[t] bytes) is copied to dst[t] with its k rows in ranked
+ * order (dst != src).  Replaces torch.sum + torch.argsort + `v[rows, order]` per tensor. */
+int gp_rank_hypotheses(const long long* inl_score, int B, int k, int P, int sort, float* scores, long long* order, int n_tensors,
+                       const void* const* src, void* const* dst, const int* row_bytes, void* stream);
 
 #ifdef __cplusplus
 }

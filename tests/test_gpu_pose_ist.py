@@ -140,3 +140,43 @@ def test_resnet_on_gpu_vs_reference_golden(golden_dir):
     tmpl, _ = syn.template_images(102, 2)
     feat = net.forward_by_chunk(t(tmpl)).cpu().numpy()
     np.testing.assert_allclose(feat, g["resnet_feat"], rtol=2e-4, atol=2e-3)
+
+
+def test_rank_hypotheses_vs_torch():
+    """gp_rank_hypotheses (one launch) == the reference's torch.sum / argsort / advanced indexing (gigaPose.py:588-594),
+    ties keeping the lower hypothesis index; 16-byte, 4-byte and odd row sizes, bool and int64 payloads, > 16 tensors."""
+    from gigapose_amd.gigaPose import rank_hypotheses, stable_argsort_desc
+    from gigapose_amd.tensor_collection import PandasTensorCollection
+    import pandas as pd
+
+    g = torch.Generator().manual_seed(4)
+    B, k, P = 7, 5, 256
+    isc = (torch.rand(B, k, P, generator=g) < 0.3).long()
+    isc[2, 3] = isc[2, 1]                                   # an exact tie inside a row
+    isc[4] = 0                                              # a row of all-equal scores
+    tensors = dict(ransac_scores=isc,
+                   pts=torch.randint(-1, 16, (B, k, P, 2), generator=g),          # 4096-byte rows
+                   M=torch.randn(B, k, 3, 3, generator=g),                        # 36-byte rows
+                   failed=torch.rand(B, k, generator=g) < 0.5,                    # 1-byte rows
+                   odd=torch.randint(0, 255, (B, k, 7), generator=g).to(torch.uint8),  # 7-byte rows
+                   ids=torch.randint(0, 162, (B, k), generator=g))
+    for j in range(14):                                     # more than one launch's worth of tensors
+        tensors[f"extra{j}"] = torch.randn(B, k, 3 + j, generator=g)
+    dev = {n: v.cuda() for n, v in tensors.items()}
+    score = torch.sum(dev["ransac_scores"], dim=2) / P
+    order_ref = stable_argsort_desc(score)
+    rows = torch.arange(B, device="cuda")[:, None]
+    for sort in (True, False):
+        pred = PandasTensorCollection(infos=pd.DataFrame(), **{n: v.clone() for n, v in dev.items()})
+        order = rank_hypotheses(pred, sort)
+        torch.cuda.synchronize()
+        if sort:
+            assert torch.equal(order, order_ref)
+            assert torch.equal(pred.scores, score[rows, order_ref])
+            for n, v in dev.items():
+                assert torch.equal(getattr(pred, n), v[rows, order_ref]), n
+        else:
+            assert torch.equal(order, torch.arange(k, device="cuda").expand(B, k))
+            assert torch.equal(pred.scores, score)
+            for n, v in dev.items():
+                assert torch.equal(getattr(pred, n), v), n

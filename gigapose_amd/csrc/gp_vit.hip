@@ -143,6 +143,8 @@ int launch_layernorm(const float* X, float* Y, const float* g, const float* b, i
 // plane stores are 256 contiguous bytes per token row.
 typedef _Float16 v16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 v16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int au32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr float kPlaneScale = 8.0f;  // == kActScale of gp_split256.hip
 
 __global__ __launch_bounds__(1024) void layernorm_planes_kernel(const float* __restrict__ X, _Float16* __restrict__ Yhi,
@@ -301,6 +303,8 @@ __global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* 
     if (bad) gp_raise(status, GP_ST_SPLIT_RANGE);
 }
 
+static int g_attn_probe = 0;     // timing probe (gp_vit_set_attn_probe): 1 = return after staging, 2 = after query 256
+extern "C" void gp_vit_set_attn_probe(int mode) { g_attn_probe = mode; }
 static int g_ln_planes_reg = 1;  // A/B hook (gp_vit_set_ln_reg): 0 = the three-pass kernel
 extern "C" void gp_vit_set_ln_reg(int on) { g_ln_planes_reg = on ? 1 : 0; }
 
@@ -510,9 +514,9 @@ __global__ __launch_bounds__(64, 4) void attention_planes_kernel(const float* __
 
 // ---------------------------------------------------------------------------------------------------------------
 // Attention in split numerics.  Inputs: Q | K | V of every token as f16 planes [Mpad][3C] (x 8; written by the qk and v
-// GEMMs' plane epilogue), output: activation planes [Mpad][C] for proj.  One workgroup per (image, head), nine waves =
-// the nine 32-query tiles; K [288 keys][64] and V^T [64][288 keys] (both planes) are staged in LDS ONCE and shared by the
-// nine waves (the f32 kernel re-reads them from L2 per query tile).  Per wave the S^T trick of attention_body:
+// GEMMs' plane epilogue), output: activation planes [Mpad][C] for proj.  One workgroup per (image, head), eight waves =
+// the eight full 32-query tiles (query 256 takes a vector-ALU path first); K [288 keys][64] and V^T [64][288 keys] (both
+// planes) are staged in LDS ONCE and shared by the waves (the f32 kernel re-reads them from L2 per query tile).  Per wave the S^T trick of attention_body:
 //   S^T[key][query] = sum_d K[key][d] Q[query][d]   as  3 x v_mfma_f32_32x32x16_f16 per 16-d block (hi hi, hi lo, lo hi),
 // so a lane owns one query column, the softmax over keys is in-register, and its P registers 8m .. 8m+7 ARE the B
 // fragment of the P.V MFMA once the hardware k index (lane half, element e) is read as key 16m + 8 (e >> 2) + 4 half
@@ -534,11 +538,21 @@ __device__ __forceinline__ float exp_neg(float x)  // x <= 0 (or -inf)
     return __builtin_fmaf(r, e * 0.6931471824645996f, r);
 }
 
-__global__ __launch_bounds__(576) void attention_split_kernel(const _Float16* __restrict__ QKVhi, const _Float16* __restrict__ QKVlo,
+typedef const __attribute__((address_space(3))) v16x8* lds_v16x8p;
+typedef const __attribute__((address_space(3))) v16x4* lds_v16x4p;
+__device__ __forceinline__ unsigned lds_addr(const _Float16* p)  // byte address inside the workgroup's LDS
+{
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) _Float16*)p;
+}
+
+constexpr int ATH = 512;  // threads: eight waves = the eight full 32-query tiles (two waves per SIMD)
+
+__global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __restrict__ QKVhi, const _Float16* __restrict__ QKVlo,
                                                                _Float16* __restrict__ Ohi, _Float16* __restrict__ Olo, int B, int H,
-                                                               int C, int Mpad)
+                                                               int C, int Mpad, int probe)
 {
     __shared__ __attribute__((aligned(16))) _Float16 sm[2 * AKEYS * AKS + 2 * 64 * AVS];  // 157,696 bytes
+    __shared__ __attribute__((aligned(16))) float xq[64], xs[T_TOK + 3], xred[2][8], xo[8][64];  // the 257th query's VALU path
     _Float16* sKh = sm;
     _Float16* sKl = sKh + AKEYS * AKS;
     _Float16* sVh = sKl + AKEYS * AKS;
@@ -549,54 +563,149 @@ __global__ __launch_bounds__(576) void attention_split_kernel(const _Float16* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const size_t ld = 3 * (size_t)C, tok0 = (size_t)b * T_TOK;
 
-    // ---- stage K (rows = keys) and V^T (rows = channels); 8 lanes copy the 128 bytes of one key.  All loads first.
+    // ---- stage K (rows = keys) and V^T (rows = channels).  Threads 0..255 take the hi planes, 256..511 the lo planes; 8 lanes
+    // copy the 128 bytes of one key (coalesced), all loads first.  K rows go to LDS as they are.  V is transposed on the way:
+    // lanes L and L ^ 8 hold keys 2j and 2j + 1 of the same 8 channels -- they swap half of their data so that each writes
+    // FOUR dwords (key 2j | key 2j + 1 of one channel row) instead of eight scattered halfwords, which cost 8-way bank
+    // conflicts and 6 us of the 35 us a workgroup took (tools/probe_attn_split.py).  Key 257 = zeros (key 256's partner).
     {
-        constexpr int NCH = 2 * T_TOK * 8, NIT = (NCH + 575) / 576;
-        v16x8 kv[NIT], vv[NIT];
+        constexpr int NCHP = (T_TOK + 1) * 8, NIT = (NCHP + 255) / 256;
+        const int pl = tid >> 8, t8 = tid & 255;
+        const _Float16* Qsrc = (pl ? QKVlo : QKVhi) + tok0 * ld + C + h * 64;
+        _Float16* sK = pl ? sKl : sKh;
+        unsigned* sV = reinterpret_cast<unsigned*>(pl ? sVl : sVh);
+        const bool odd = (lane & 8) != 0;  // key parity: chunk c = t8 + 256 i -> key = c >> 3
+        au32x4 kv[NIT], vv[NIT];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int c = tid + 576 * i;
-            if (c < NCH) {
-                const int plane = c >= T_TOK * 8 ? 1 : 0, r = c - plane * T_TOK * 8, key = r >> 3, ch = r & 7;
-                const _Float16* src = (plane ? QKVlo : QKVhi) + (tok0 + key) * ld + C + h * 64 + 8 * ch;
-                kv[i] = *reinterpret_cast<const v16x8*>(src);
-                vv[i] = *reinterpret_cast<const v16x8*>(src + C);
+            const int c = t8 + 256 * i, key = c >> 3, ch = c & 7;
+            kv[i] = au32x4{0u, 0u, 0u, 0u};
+            vv[i] = au32x4{0u, 0u, 0u, 0u};
+            if (key < T_TOK) {
+                const _Float16* src = Qsrc + (size_t)key * ld + 8 * ch;
+                kv[i] = *reinterpret_cast<const au32x4*>(src);
+                vv[i] = *reinterpret_cast<const au32x4*>(src + C);
             }
         }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int c = tid + 576 * i;
-            if (c < NCH) {
-                const int plane = c >= T_TOK * 8 ? 1 : 0, r = c - plane * T_TOK * 8, key = r >> 3, ch = r & 7;
-                *reinterpret_cast<v16x8*>((plane ? sKl : sKh) + key * AKS + 8 * ch) = kv[i];
-                _Float16* dst = (plane ? sVl : sVh) + (8 * ch) * AVS + key;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dst[e * AVS] = vv[i][e];
+            const int c = t8 + 256 * i, key = c >> 3, ch = c & 7;
+            // every lane takes part in the exchange (chunks past the plane carry zeros)
+            const unsigned r0 = __shfl_xor(odd ? vv[i][0] : vv[i][2], 8), r1 = __shfl_xor(odd ? vv[i][1] : vv[i][3], 8);
+            if (c < NCHP) {
+                *reinterpret_cast<au32x4*>(sK + key * AKS + 8 * ch) = kv[i];
+                const unsigned e0 = odd ? r0 : vv[i][0], e1 = odd ? r1 : vv[i][1];  // the even key's channels 4 odd .. 4 odd + 3
+                const unsigned o0 = odd ? vv[i][2] : r0, o1 = odd ? vv[i][3] : r1;  // the odd key's
+                unsigned* dst = sV + ((8 * ch + (odd ? 4 : 0)) * AVS + (key & ~1)) / 2;
+                dst[0 * (AVS / 2)] = (e0 & 0xffffu) | (o0 << 16);
+                dst[1 * (AVS / 2)] = (e0 >> 16) | (o0 & 0xffff0000u);
+                dst[2 * (AVS / 2)] = (e1 & 0xffffu) | (o1 << 16);
+                dst[3 * (AVS / 2)] = (e1 >> 16) | (o1 & 0xffff0000u);
             }
         }
     }
-    for (int c = tid; c < 2 * (AKEYS - T_TOK) * 8; c += 576) {  // keys 257..287: zero rows (masked below)
-        const int plane = c >= (AKEYS - T_TOK) * 8 ? 1 : 0, r = c - plane * (AKEYS - T_TOK) * 8;
-        v16x8 z;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
-        *reinterpret_cast<v16x8*>((plane ? sKl : sKh) + (T_TOK + (r >> 3)) * AKS + 8 * (r & 7)) = z;
+    for (int c = tid; c < 2 * (AKEYS - T_TOK - 1) * 8; c += ATH) {  // keys 258..287: zero rows (masked below)
+        const int plane = c >= (AKEYS - T_TOK - 1) * 8 ? 1 : 0, r = c - plane * (AKEYS - T_TOK - 1) * 8;
+        *reinterpret_cast<au32x4*>((plane ? sKl : sKh) + (T_TOK + 1 + (r >> 3)) * AKS + 8 * (r & 7)) = au32x4{0u, 0u, 0u, 0u};
     }
-    for (int c = tid; c < 2 * 64 * (AVS - T_TOK); c += 576) {   // V^T columns 257..291: zero (finite x p = 0)
-        const int plane = c >= 64 * (AVS - T_TOK) ? 1 : 0, r = c - plane * 64 * (AVS - T_TOK);
-        (plane ? sVl : sVh)[(r / (AVS - T_TOK)) * AVS + T_TOK + r % (AVS - T_TOK)] = (_Float16)0.f;
+    {
+        constexpr int ZW = (AVS - T_TOK - 1) / 2;  // V^T columns 258..291 as dwords: zero (finite x p = 0)
+        for (int c = tid; c < 2 * 64 * ZW; c += ATH) {
+            const int plane = c >= 64 * ZW ? 1 : 0, r = c - plane * 64 * ZW;
+            reinterpret_cast<unsigned*>(plane ? sVl : sVh)[((r / ZW) * AVS + T_TOK + 1) / 2 + r % ZW] = 0u;
+        }
     }
 
     // ---- this wave's query tile: Q fragments (B operand: column = query, k = 8 half + e inside each 16-d block)
-    const int tq = wave * 32 + l31, tq_c = tq < T_TOK ? tq : T_TOK - 1;
-    const size_t qo = (tok0 + tq_c) * ld + h * 64 + 8 * half;
+    const int tq = wave * 32 + l31;  // < 256: the eight waves cover queries 0..255
+    const size_t qo = (tok0 + tq) * ld + h * 64 + 8 * half;
+    if (tid < 64) {  // query 256 (257 = 8 x 32 + 1): the exact f32 value hi + lo of its 64 channels (x 8)
+        const size_t q256 = (tok0 + (T_TOK - 1)) * ld + h * 64 + tid;
+        xq[tid] = (float)QKVhi[q256] + (float)QKVlo[q256];
+    }
     __syncthreads();
+    if (probe == 1) return;  // timing probe (gp_vit_set_attn_probe): staging only
+
+    // ---- query 256 on the vector ALU, all eight waves, before the matrix loop (a ninth wave would put three waves on one
+    // SIMD and its 31 idle query columns would cost as much as a full tile: 141 -> 1xx us per launch).  The
+    // planes are exact f32 values (hi + lo), so plain f32 FMAs over them are at least as accurate as the split products.
+    {
+        float sv = -INFINITY;
+        if (tid < T_TOK) {  // score of key `tid`
+            const _Float16* kh = sKh + tid * AKS;
+            const _Float16* kl = sKl + tid * AKS;
+            float a = 0.f;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                const v16x8 h8 = *reinterpret_cast<const v16x8*>(kh + 8 * c8), l8 = *reinterpret_cast<const v16x8*>(kl + 8 * c8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a = __builtin_fmaf((float)h8[e] + (float)l8[e], xq[8 * c8 + e], a);
+            }
+            sv = a * (0.125f / 64.0f);
+        }
+        float mx = sv;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if (lane == 0) xred[0][wave] = mx;
+        __syncthreads();
+        mx = xred[0][0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) mx = fmaxf(mx, xred[0][w]);
+        const float pr = tid < T_TOK ? exp_neg(sv - mx) : 0.f;
+        if (tid < T_TOK) xs[tid] = pr;
+        float ps = pr;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ps += __shfl_xor(ps, off);
+        if (lane == 0) xred[1][wave] = ps;
+        __syncthreads();
+        // out[d] = sum_key p[key] v[key][d]: thread = (d = lane, key slice = wave: keys 32 w .. 32 w + 31; wave 0 adds key 256)
+        {
+            const _Float16* vh = sVh + lane * AVS + 32 * wave;
+            const _Float16* vl = sVl + lane * AVS + 32 * wave;
+            v16x4 h4[8], l4[8];
+            f32x4 p4[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                h4[u] = *reinterpret_cast<const v16x4*>(vh + 4 * u);
+                l4[u] = *reinterpret_cast<const v16x4*>(vl + 4 * u);
+                p4[u] = *reinterpret_cast<const f32x4*>(xs + 32 * wave + 4 * u);
+            }
+            float a = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a = __builtin_fmaf((float)h4[u][e] + (float)l4[u][e], p4[u][e], a);
+            if (wave == 0) a = __builtin_fmaf((float)sVh[lane * AVS + T_TOK - 1] + (float)sVl[lane * AVS + T_TOK - 1], xs[T_TOK - 1], a);
+            xo[wave][lane] = a;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float l = xred[1][0], a = xo[0][tid];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) { l += xred[1][w]; a += xo[w][tid]; }
+            float v = a * (1.0f / l);  // = 8 x O (the V planes carry x 8)
+            asm volatile("" : "+v"(v));
+            const _Float16 hh = (_Float16)v;
+            const size_t o = (tok0 + (T_TOK - 1)) * C + h * 64 + tid;
+            Ohi[o] = hh;
+            Olo[o] = (_Float16)(v - (float)hh);
+        }
+    }
+    if (probe == 2) return;  // timing probe: staging + query 256
+    if (probe >= 3 && wave >= 4) {  // experiment: offset the two wave groups (one wave of each per SIMD) by ~(probe - 2) us
+        for (int i = 0; i < probe - 2; ++i) __builtin_amdgcn_s_sleep(25);
+    }
 
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m_run = -INFINITY, l_part = 0.f;
-    const float s_scale = 0.125f / 64.0f;  // softmax scale 64^-0.5, Q and K planes carry x 8 each
+    // scores in log2 units: softmax scale 64^-0.5 (Q and K planes carry x 8 each) x log2(e), so p = exp2(v - max) is ONE
+    // hardware exp2 per element (v_exp_f32, 1 ulp).  The argument v = s * c carries one f32 rounding (<= 30 x 2^-24 in log2
+    // units at the largest |v| that matters, i.e. ~1e-6 relative in p) -- the same error the reference's f32 softmax has in
+    // x = (q.k) * scale before its exp; the compensated exp_neg of the f32 kernels costs 6 more VALU instructions per
+    // element, and this loop is bound by VALU issue (SQ_ACTIVE_INST_VALU 52 % vs matrix pipe 26 %, profiles/r02_pmc_attention.txt).
+    const float s_scale = (0.125f / 64.0f) * 1.4426950408889634f;
 
 #pragma unroll 1
     for (int ch = 0; ch < 3; ++ch) {
@@ -607,49 +716,69 @@ __global__ __launch_bounds__(576) void attention_split_kernel(const _Float16* __
             qh[kb] = *reinterpret_cast<const v16x8*>(QKVhi + qo + 16 * kb);
             ql[kb] = *reinterpret_cast<const v16x8*>(QKVlo + qo + 16 * kb);
         }
+        // one LDS base address per plane and chunk, made opaque so that every fragment read below is base + a 16-bit
+        // instruction offset (left alone, hipcc folds the plane's position into a per-read constant > 64 KB: one v_add
+        // per read, 55 per chunk in a loop that is bound by vector-ALU issue)
+        unsigned akh = lds_addr(sKh) + 2u * ((ch * 96 + l31) * AKS + 8 * half), akl = akh + 2u * (AKEYS * AKS);
+        unsigned avh = lds_addr(sVh) + 2u * (l31 * AVS + ch * 96 + 4 * half), avl = avh + 2u * (64 * AVS);
+        asm volatile("" : "+v"(akh), "+v"(akl), "+v"(avh), "+v"(avl));
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-            const int krow = (ch * 3 + t) * 32 + l31;
-            const _Float16* kph = sKh + krow * AKS + 8 * half;
-            const _Float16* kpl = sKl + krow * AKS + 8 * half;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
-                const v16x8 kh = *reinterpret_cast<const v16x8*>(kph + 16 * kb);
-                const v16x8 kl = *reinterpret_cast<const v16x8*>(kpl + 16 * kb);
+                const v16x8 kh = *(lds_v16x8p)(size_t)(akh + 2u * (t * 32 * AKS + 16 * kb));
+                const v16x8 kl = *(lds_v16x8p)(size_t)(akl + 2u * (t * 32 * AKS + 16 * kb));
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[kb], s[t], 0, 0, 0);
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[kb], s[t], 0, 0, 0);
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[kb], s[t], 0, 0, 0);
             }
         }
-        // online softmax over this chunk of 96 keys (same structure as attention_body)
+        // online softmax over this chunk of 96 keys; element pairs (r, r + 1) as 2-vectors: packed f32 multiply / add
+        const f32x2 sc2 = {s_scale, s_scale};
         float cmax = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int tk = (ch * 3 + t) * 32 + frag_row(r, lane);
-                const float v = (tk < T_TOK) ? s[t][r] * s_scale : -INFINITY;
-                s[t][r] = v;
-                cmax = fmaxf(cmax, v);
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 v = f32x2{s[t][r], s[t][r + 1]} * sc2;
+                if (t == 2) {  // only a chunk's last tile can hold keys >= 257 (chunk 2: keys 256..287)
+                    const int tk = (ch * 3 + 2) * 32 + frag_row(r, lane);
+                    v.x = (tk < T_TOK) ? v.x : -INFINITY;
+                    v.y = (tk + 1 < T_TOK) ? v.y : -INFINITY;
+                }
+                s[t][r] = v.x;
+                s[t][r + 1] = v.y;
+                cmax = fmaxf(cmax, fmaxf(v.x, v.y));
             }
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
-        const float m_new = fmaxf(m_run, cmax);
-        const float alpha = exp_neg(m_run - m_new);  // first chunk: exp(-inf) = 0
-        float psum = 0.f;
+        // running reference mb = max - 15: P carries x 2^15 for its f16 split (and so does l_part); the SAME rounded value
+        // serves the exponentials of this chunk and the rescaling of the earlier ones
+        const float mb = fmaxf(m_run, cmax - 15.0f);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - mb);     // first chunk: exp2(-inf) = 0
+        const f32x2 mb2 = {mb, mb};
+        f32x2 psum2 = {0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = exp_neg(s[t][r] - m_new);
-                s[t][r] = p;
-                psum += p;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 d = f32x2{s[t][r], s[t][r + 1]} - mb2;
+                const f32x2 pp = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
+                s[t][r] = pp.x;
+                s[t][r + 1] = pp.y;
+                psum2 += pp;
             }
-        l_part = l_part * alpha + psum;
+        l_part = l_part * alpha + (psum2.x + psum2.y);
+        {
+            const f32x2 al2 = {alpha, alpha};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        m_run = m_new;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 a0 = f32x2{o0[r], o0[r + 1]} * al2, a1 = f32x2{o1[r], o1[r + 1]} * al2;
+                o0[r] = a0.x; o0[r + 1] = a0.y; o1[r] = a1.x; o1[r + 1] = a1.y;
+            }
+        }
+        m_run = mb;
         // O^T[d][query] += sum_key V^T[d][key] P^T[key][query], 16 keys per MFMA block (m)
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -657,18 +786,23 @@ __global__ __launch_bounds__(576) void attention_split_kernel(const _Float16* __
             for (int m = 0; m < 2; ++m) {
                 v16x8 ph, pl;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float pv = s[t][8 * m + e] * 32768.0f;
-                    const _Float16 hh = (_Float16)pv;
-                    ph[e] = hh;
-                    pl[e] = (_Float16)(pv - (float)hh);
+                for (int e = 0; e < 8; e += 2) {
+                    // hi = the top 11 significant bits (mantissa TRUNCATED to f16's 10: exact in f16, no conversion back), lo =
+                    // f16(p - hi): 11 + 11 bits as with a rounded hi, for 2.5 instead of 4 instructions per element
+                    const float px = s[t][8 * m + e], py = s[t][8 * m + e + 1];
+                    const f32x2 pv = {px, py};
+                    const f32x2 top = {__uint_as_float(__float_as_uint(px) & 0xffffe000u), __uint_as_float(__float_as_uint(py) & 0xffffe000u)};
+                    const f32x2 rest = pv - top;
+                    ph[e] = (_Float16)top.x;
+                    ph[e + 1] = (_Float16)top.y;
+                    pl[e] = (_Float16)rest.x;
+                    pl[e + 1] = (_Float16)rest.y;
                 }
-                const int key0 = (ch * 3 + t) * 32 + 16 * m + 4 * half;
 #pragma unroll
                 for (int dh = 0; dh < 2; ++dh) {
-                    const int vo = (32 * dh + l31) * AVS + key0;
-                    const v16x4 a0 = *reinterpret_cast<const v16x4*>(sVh + vo), a1 = *reinterpret_cast<const v16x4*>(sVh + vo + 8);
-                    const v16x4 b0 = *reinterpret_cast<const v16x4*>(sVl + vo), b1 = *reinterpret_cast<const v16x4*>(sVl + vo + 8);
+                    const unsigned vo = 2u * (32 * dh * AVS + t * 32 + 16 * m);
+                    const v16x4 a0 = *(lds_v16x4p)(size_t)(avh + vo), a1 = *(lds_v16x4p)(size_t)(avh + vo + 16u);
+                    const v16x4 b0 = *(lds_v16x4p)(size_t)(avl + vo), b1 = *(lds_v16x4p)(size_t)(avl + vo + 16u);
                     v16x8 vh, vl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { vh[e] = a0[e]; vh[4 + e] = a1[e]; vl[e] = b0[e]; vl[4 + e] = b1[e]; }
@@ -684,9 +818,9 @@ __global__ __launch_bounds__(576) void attention_split_kernel(const _Float16* __
                 }
             }
     }
-    // planes out: 8 * O = acc * inv / 2^15  (acc carries 2^15 p x 8 v); lane = (query, half): 4 consecutive channels per r4
-    const float sc = (1.0f / (l_part + __shfl_xor(l_part, 32))) * (1.0f / 32768.0f);
-    if (tq < T_TOK) {
+    // planes out: 8 * O = acc / l  (acc carries 2^15 p x 8 v, l carries 2^15); lane = (query, half): 4 consecutive channels per r4
+    const float sc = 1.0f / (l_part + __shfl_xor(l_part, 32));
+    {
         const size_t row = (tok0 + tq) * C + h * 64;
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh)
@@ -890,8 +1024,8 @@ int gp_attention_split(const void* qkv_hi, const void* qkv_lo, void* out_hi, voi
 {
     GP_REQUIRE(qkv_hi && qkv_lo && out_hi && out_lo && B > 0 && heads > 0 && dim == heads * 64 && Mpad >= B * T_TOK,
                "gp_attention_split: bad arguments");
-    hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(576), 0, (hipStream_t)stream,
-                       (const _Float16*)qkv_hi, (const _Float16*)qkv_lo, (_Float16*)out_hi, (_Float16*)out_lo, B, heads, dim, Mpad);
+    hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(ATH), 0, (hipStream_t)stream,
+                       (const _Float16*)qkv_hi, (const _Float16*)qkv_lo, (_Float16*)out_hi, (_Float16*)out_lo, B, heads, dim, Mpad, g_attn_probe);
     GP_CHECK_LAUNCH("gp_attention_split");
     return GP_OK;
 }
@@ -995,8 +1129,8 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
                 }
                 {
                     GpProfScope prof(GP_PROF_ATTN, 4.0 * B * heads * 257.0 * 257.0 * 64.0, st);
-                    hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(576), 0, st, Ahi, Alo, Hhi, Hlo, B,
-                                       heads, C, Mpad);
+                    hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(ATH), 0, st, Ahi, Alo, Hhi, Hlo, B,
+                                       heads, C, Mpad, 0);
                 }
                 GP_CHECK_LAUNCH("gp_vit_forward/attention_split");
             } else {

@@ -12,6 +12,9 @@
 //   * tile 256 pixels (i) x 64 NI output channels (j), NI = 2, 3, 4 for Cout = 128, 192, >= 256: 8 waves as 4 x 2, wave
 //     tile 64 x 32 NI, ONE accumulator, k-step 32, two LDS buffers, the two wave groups half a k-step apart with one
 //     barrier per step (the loop of gemm_planes256_kernel);
+//     (a 512 x 128 tile with the waves as 8 x 1 -- the plane GEMM's 48 matrix instructions per wave and k-step for
+//     Cout = 128, all 160 KiB of LDS -- was built and measured: bit-identical, no faster: 2.76 us per k-step against 2 x
+//     1.33, the loop is bound by the global -> LDS staging rate per CU, not by LDS reads; DESIGN.md, negative results)
 //   * work distribution of gemm_planes256_kernel: data-parallel rounds of whole tiles per XCD chunk, a stream-K remainder
 //     with deterministic accumulator hand-overs when the tile count does not fill the slots evenly (layer4 at B = 64:
 //     128 tiles on 256 slots -> every tile is cut in two k halves);
@@ -23,6 +26,7 @@
 typedef _Float16 c16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 c16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int cu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int cu32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -46,6 +50,7 @@ struct ConvPArgs {
     int tiles_i, tiles_j;
     int* flags; float* partial; int epoch; int* status;
     int stem;  // 1: the 7 x 7 / stride 2 stem on a zero-framed 4-channel image, see gp_conv2d_stem_planes
+    unsigned long long* trace;  // probe (gp_conv2d_planes_set_trace): per slot 8 words -- segments, k-steps, 100 MHz ticks in prologue / k loop / tail
 };
 
 __device__ __forceinline__ int toff(int row, int kc) { return row * CROW + ((kc ^ ((row >> 2) & 3)) << 3); }
@@ -53,11 +58,17 @@ __device__ __forceinline__ int toff(int row, int kc) { return row * CROW + ((kc 
 template <int NI>
 __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
 {
-    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * CBUF];  // 128 KiB
+    constexpr int MT = CT;                   // pixel rows per tile
+    constexpr int BR = CT;                   // weight rows of an LDS buffer (64 NI of them used)
+    constexpr int NIW = NI;                  // 32-channel matrix tiles per wave
+    constexpr int AH = MT / 128;             // pixel rows each thread stages per k-step (rows srow + 128 h)
+    constexpr int BH = NI > 2 ? 2 : 1;       // weight rows each thread stages
+    constexpr int P_AHI = 0, P_ALO = MT * CROW, P_BHI = 2 * MT * CROW, P_BLO = P_BHI + BR * CROW;
+    constexpr int TBUF = 2 * (MT + BR) * CROW;  // halfs per LDS buffer: 64 KiB
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * TBUF];  // 128 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, grp = wave >> 2;
-    constexpr int P_AHI = 0, P_ALO = CPLANE, P_BHI = 2 * CPLANE, P_BLO = 3 * CPLANE;
     constexpr int JT = 64 * NI;  // output channels per tile
 
     // ---- this slot's range of (tile, k-step) units inside its XCD's tile chunk (gemm_planes256_kernel's scheme)
@@ -80,16 +91,21 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
     const __amdgpu_buffer_rsrc_t r_xlo = __builtin_amdgcn_make_buffer_rsrc((void*)a.xlo, 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_whi = __builtin_amdgcn_make_buffer_rsrc((void*)a.whi, 0, w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_wlo = __builtin_amdgcn_make_buffer_rsrc((void*)a.wlo, 0, w_bytes, 0x00020000);
+    const unsigned r_bytes = a.rhi ? (unsigned)a.B * a.OH * a.OW * a.Cout * 2u : 0u;
+    const __amdgpu_buffer_rsrc_t r_rhi = __builtin_amdgcn_make_buffer_rsrc((void*)a.rhi, 0, r_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rlo = __builtin_amdgcn_make_buffer_rsrc((void*)a.rlo, 0, r_bytes, 0x00020000);
     const int srow = tid >> 2, schunk = tid & 3;
     const int wofs = toff(srow, schunk);
     const int OHW = a.OH * a.OW, cps = a.stem ? 1 : a.Cin / CBK;  // k-steps per tap
-    cu32x4 rg[8];
+    cu32x4 ra_h[AH], ra_l[AH], rb_h[BH], rb_l[BH];
     // fragment addressing
-    const int ar_ = 64 * wr + (lane & 31), br_ = 32 * NI * wc + (lane & 31), kh_ = lane >> 5;
+    const int ar_ = 64 * wr + (lane & 31), br_ = 32 * NIW * wc + (lane & 31), kh_ = lane >> 5;
     const int arow = ar_ * CROW, brow = br_ * CROW;
     const int ak0 = ((kh_ ^ ((ar_ >> 2) & 3)) << 3), ak1 = (((kh_ + 2) ^ ((ar_ >> 2) & 3)) << 3);
     const int bk0 = ((kh_ ^ ((br_ >> 2) & 3)) << 3), bk1 = (((kh_ + 2) ^ ((br_ >> 2) & 3)) << 3);
 
+    unsigned long long tr_pro = 0, tr_loop = 0, tr_tail = 0, tr_steps = 0, tr_t0 = a.trace ? wall_clock64() : 0;
+    const unsigned long long tr_begin = tr_t0;
     for (int seg = 0; seg < n_seg; ++seg) {
         const bool is_dp = seg < rounds_dp;
         const bool is_head = !is_dp && seg - rounds_dp < n_head;
@@ -97,14 +113,14 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
         const int t = is_dp ? seg * slots_x + n : n_dp + (is_head ? tb : (is_rest ? ta : first_whole + seg - rounds_dp - n_head));
         const int s0 = is_rest ? sa : 0, s1 = is_head ? sb : nstep;
         const int q = t_lo + t;
-        const int i0 = (q / a.tiles_j) * CT, j0 = (q % a.tiles_j) * JT;  // j fastest: the co tiles of one pixel tile are neighbours
+        const int i0 = (q / a.tiles_j) * MT, j0 = (q % a.tiles_j) * JT;  // j fastest: the co tiles of one pixel tile are neighbours
 
-        // ---- gather state of this thread's two pixel rows (srow, srow + 128): byte offset of (b, oy*stride-pad, ox*stride-pad, 0)
+        // ---- gather state of this thread's pixel rows (srow + 128 h): byte offset of (b, oy*stride-pad, ox*stride-pad, 0)
         // and one validity bit per tap (KH*KW <= 9)
-        int pbase[2];
-        unsigned pvalid[2];
+        int pbase[AH];
+        unsigned pvalid[AH];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < AH; ++h) {
             const int pix = i0 + srow + 128 * h;
             const int b = pix / OHW, rem = pix - b * OHW;
             const int oy = rem / a.OW, ox = rem - oy * a.OW;
@@ -121,14 +137,14 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
             pvalid[h] = m;
         }
         // weights: rows j0 + srow (+128) of (Cout, K); rows past Cout (Cout = 192 in a 256-row plane) read as zeros
-        unsigned wvoff[2];
+        unsigned wvoff[BH];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < BH; ++h) {
             const int co = j0 + srow + 128 * h;
             wvoff[h] = (srow + 128 * h < JT && co < a.Cout) ? (unsigned)co * (unsigned)a.K * 2u + (unsigned)schunk * 16u : kOob;
         }
 
-        f32x16 acc[2][NI];
+        f32x16 acc[2][NIW];
         if (is_rest) {
             if (tid == 0) {
                 int spins = 0;
@@ -147,7 +163,7 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
+                for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         const f32x4 v = w[(mi * 4 + ni) * 4 + r4];
@@ -158,7 +174,7 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
+                for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         }
@@ -176,31 +192,30 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
                 const int c0 = s - tap * cps, dy = tap / a.KW, dx = tap - dy * a.KW;
                 toffb = ((dy * a.W + dx) * a.Cin + c0 * CBK) * 2;
             }
-            const unsigned v0 = ((pvalid[0] >> tap) & 1u) ? (unsigned)(pbase[0] + toffb) : kOob;
-            const unsigned v1 = ((pvalid[1] >> tap) & 1u) ? (unsigned)(pbase[1] + toffb) : kOob;
             const unsigned sw = (unsigned)s * (CBK * 2u);
-            rg[0] = __builtin_amdgcn_raw_buffer_load_b128(r_xhi, v0, 0, 0);
-            rg[1] = __builtin_amdgcn_raw_buffer_load_b128(r_xhi, v1, 0, 0);
-            rg[2] = __builtin_amdgcn_raw_buffer_load_b128(r_xlo, v0, 0, 0);
-            rg[3] = __builtin_amdgcn_raw_buffer_load_b128(r_xlo, v1, 0, 0);
-            rg[4] = __builtin_amdgcn_raw_buffer_load_b128(r_whi, wvoff[0], sw, 0);
-            rg[6] = __builtin_amdgcn_raw_buffer_load_b128(r_wlo, wvoff[0], sw, 0);
-            if (NI > 2) {
-                rg[5] = __builtin_amdgcn_raw_buffer_load_b128(r_whi, wvoff[1], sw, 0);
-                rg[7] = __builtin_amdgcn_raw_buffer_load_b128(r_wlo, wvoff[1], sw, 0);
+#pragma unroll
+            for (int h = 0; h < AH; ++h) {
+                const unsigned v = ((pvalid[h] >> tap) & 1u) ? (unsigned)(pbase[h] + toffb) : kOob;
+                ra_h[h] = __builtin_amdgcn_raw_buffer_load_b128(r_xhi, v, 0, 0);
+                ra_l[h] = __builtin_amdgcn_raw_buffer_load_b128(r_xlo, v, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < BH; ++h) {
+                rb_h[h] = __builtin_amdgcn_raw_buffer_load_b128(r_whi, wvoff[h], sw, 0);
+                rb_l[h] = __builtin_amdgcn_raw_buffer_load_b128(r_wlo, wvoff[h], sw, 0);
             }
         };
         auto stage = [&](int buf) {
-            _Float16* L = lds + buf * CBUF + wofs;
-            *reinterpret_cast<cu32x4*>(L + P_AHI) = rg[0];
-            *reinterpret_cast<cu32x4*>(L + P_AHI + 128 * CROW) = rg[1];
-            *reinterpret_cast<cu32x4*>(L + P_ALO) = rg[2];
-            *reinterpret_cast<cu32x4*>(L + P_ALO + 128 * CROW) = rg[3];
-            *reinterpret_cast<cu32x4*>(L + P_BHI) = rg[4];
-            *reinterpret_cast<cu32x4*>(L + P_BLO) = rg[6];
-            if (NI > 2) {
-                *reinterpret_cast<cu32x4*>(L + P_BHI + 128 * CROW) = rg[5];
-                *reinterpret_cast<cu32x4*>(L + P_BLO + 128 * CROW) = rg[7];
+            _Float16* L = lds + buf * TBUF + wofs;
+#pragma unroll
+            for (int h = 0; h < AH; ++h) {
+                *reinterpret_cast<cu32x4*>(L + P_AHI + 128 * h * CROW) = ra_h[h];
+                *reinterpret_cast<cu32x4*>(L + P_ALO + 128 * h * CROW) = ra_l[h];
+            }
+#pragma unroll
+            for (int h = 0; h < BH; ++h) {
+                *reinterpret_cast<cu32x4*>(L + P_BHI + 128 * h * CROW) = rb_h[h];
+                *reinterpret_cast<cu32x4*>(L + P_BLO + 128 * h * CROW) = rb_l[h];
             }
         };
         gload(0);
@@ -208,40 +223,41 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
         __builtin_amdgcn_sched_barrier(0);
         if (ns > 1) gload(1);
         __syncthreads();
+        if (a.trace) { const unsigned long long t = wall_clock64(); tr_pro += t - tr_t0; tr_t0 = t; tr_steps += ns; }
 
 #define C_MFMA(A_, B_, mi, ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[mi], B_[ni], acc[mi][ni], 0, 0, 0)
         auto c_phase = [&](int s) __attribute__((always_inline)) {
-            const _Float16* L = lds + (s & 1) * CBUF;
+            const _Float16* L = lds + (s & 1) * TBUF;
             __builtin_amdgcn_s_setprio(1);
-            c16x8 ah[2], al[2], bh[NI], bl[NI], ch[2], cl[2], dh[NI], dl[NI];
+            c16x8 ah[2], al[2], bh[NIW], bl[NIW], ch[2], cl[2], dh[NIW], dl[NIW];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) ah[mi] = *reinterpret_cast<const c16x8*>(L + P_AHI + arow + mi * 32 * CROW + ak0);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bh[ni] = *reinterpret_cast<const c16x8*>(L + P_BHI + brow + ni * 32 * CROW + bk0);
+            for (int ni = 0; ni < NIW; ++ni) bh[ni] = *reinterpret_cast<const c16x8*>(L + P_BHI + brow + ni * 32 * CROW + bk0);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bl[ni] = *reinterpret_cast<const c16x8*>(L + P_BLO + brow + ni * 32 * CROW + bk0);
+            for (int ni = 0; ni < NIW; ++ni) bl[ni] = *reinterpret_cast<const c16x8*>(L + P_BLO + brow + ni * 32 * CROW + bk0);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) al[mi] = *reinterpret_cast<const c16x8*>(L + P_ALO + arow + mi * 32 * CROW + ak0);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) { C_MFMA(ah, bh, 0, ni); C_MFMA(ah, bh, 1, ni); }
+            for (int ni = 0; ni < NIW; ++ni) { C_MFMA(ah, bh, 0, ni); C_MFMA(ah, bh, 1, ni); }
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) { C_MFMA(ah, bl, 0, ni); C_MFMA(ah, bl, 1, ni); }
+            for (int ni = 0; ni < NIW; ++ni) { C_MFMA(ah, bl, 0, ni); C_MFMA(ah, bl, 1, ni); }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) ch[mi] = *reinterpret_cast<const c16x8*>(L + P_AHI + arow + mi * 32 * CROW + ak1);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) dh[ni] = *reinterpret_cast<const c16x8*>(L + P_BHI + brow + ni * 32 * CROW + bk1);
+            for (int ni = 0; ni < NIW; ++ni) dh[ni] = *reinterpret_cast<const c16x8*>(L + P_BHI + brow + ni * 32 * CROW + bk1);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) { C_MFMA(al, bh, 0, ni); C_MFMA(al, bh, 1, ni); }
+            for (int ni = 0; ni < NIW; ++ni) { C_MFMA(al, bh, 0, ni); C_MFMA(al, bh, 1, ni); }
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) dl[ni] = *reinterpret_cast<const c16x8*>(L + P_BLO + brow + ni * 32 * CROW + bk1);
+            for (int ni = 0; ni < NIW; ++ni) dl[ni] = *reinterpret_cast<const c16x8*>(L + P_BLO + brow + ni * 32 * CROW + bk1);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) cl[mi] = *reinterpret_cast<const c16x8*>(L + P_ALO + arow + mi * 32 * CROW + ak1);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) { C_MFMA(ch, dh, 0, ni); C_MFMA(ch, dh, 1, ni); }
+            for (int ni = 0; ni < NIW; ++ni) { C_MFMA(ch, dh, 0, ni); C_MFMA(ch, dh, 1, ni); }
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) { C_MFMA(ch, dl, 0, ni); C_MFMA(ch, dl, 1, ni); }
+            for (int ni = 0; ni < NIW; ++ni) { C_MFMA(ch, dl, 0, ni); C_MFMA(ch, dl, 1, ni); }
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) { C_MFMA(cl, dh, 0, ni); C_MFMA(cl, dh, 1, ni); }
+            for (int ni = 0; ni < NIW; ++ni) { C_MFMA(cl, dh, 0, ni); C_MFMA(cl, dh, 1, ni); }
             __builtin_amdgcn_s_setprio(0);
         };
         auto m_phase = [&](int slab) __attribute__((always_inline)) {  // stages `slab`, loads slab + 1
@@ -258,13 +274,14 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
             if (!grp && s + 1 < ns) __syncthreads();
         }
 #undef C_MFMA
+        if (a.trace) { const unsigned long long t = wall_clock64(); tr_loop += t - tr_t0; tr_t0 = t; }
 
         if (is_head) {  // publish the fragment for slot n + 1 (agent-scope release by one lane)
             f32x4* w = reinterpret_cast<f32x4*>(a.partial + (size_t)p * kFragFloats) + tid * 32;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
+                for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         f32x4 v;
@@ -286,53 +303,72 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
             __syncthreads();  // every wave has read its last operand fragments
             const int ln = tid_ & 63, l31 = ln & 31;
             float* wl = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + (tid_ >> 6) * 16384);
-            constexpr int WC = 32 * NI, QPR = 8 * NI;  // f32 columns / 4-column quads per row of the wave tile
+            constexpr int WC = 32 * NIW, QPR = 8 * NIW;  // f32 columns / 4-column quads per row of the wave tile
             int bad = 0;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
+                for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) wl[frag_row(r, ln) * WC + 32 * ni + l31] = acc[mi][ni][r];
+                // residual planes: the loads of a round of RG items up front (RG x 2 x 8 bytes per lane in flight).  Loaded inside
+                // the item loop, one dependent 8-byte load per item, they cost 16 us of a 25 us tile tail (tools/probe_conv_timeline.py).
+                constexpr int RG = NIW == 2 ? 8 : (NIW == 3 ? 6 : 4);  // items per round (divides 4 NIW); fewer where the accumulators leave fewer registers
 #pragma unroll
-                for (int it = 0; it < 4 * NI; ++it) {
-                    const int f = it * 64 + ln, row = f / QPR, qd = f - row * QPR;
-                    const f32x4 tv = *reinterpret_cast<const f32x4*>(wl + row * WC + 4 * qd);
-                    const int pix = i0 + 64 * wr + 32 * mi + row, co = j0 + WC * wc + 4 * qd;
-                    if (co < a.Cout) {
-                        float v[4];
+                for (int it0 = 0; it0 < 4 * NIW; it0 += RG) {
+                    cu32x2 rh[RG], rl[RG];
+                    if (a.rhi) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = tv[e] * kOutScale;
-                        if (a.alpha) {
-                            const f32x4 al4 = *reinterpret_cast<const f32x4*>(a.alpha + co), be4 = *reinterpret_cast<const f32x4*>(a.beta + co);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = v[e] * al4[e] + be4[e];
+                        for (int u = 0; u < RG; ++u) {
+                            const int f = (it0 + u) * 64 + ln, row = f / QPR, qd = f - row * QPR;
+                            const int pix = i0 + 64 * wr + 32 * mi + row, co = j0 + WC * wc + 4 * qd;
+                            const unsigned ob = co < a.Cout ? ((unsigned)pix * (unsigned)a.Cout + (unsigned)co) * 2u : kOob;  // one offset, both planes
+                            rh[u] = __builtin_amdgcn_raw_buffer_load_b64(r_rhi, ob, 0, 0);
+                            rl[u] = __builtin_amdgcn_raw_buffer_load_b64(r_rlo, ob, 0, 0);
                         }
-                        const size_t o = (size_t)pix * a.Cout + co;
-                        if (a.rhi) {
-                            const c16x4 rh = *reinterpret_cast<const c16x4*>(a.rhi + o), rl = *reinterpret_cast<const c16x4*>(a.rlo + o);
+                    }
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = ((float)rh[e] + (float)rl[e]) * (1.0f / kActScale) + v[e];
-                        }
-                        if (a.relu)
+                    for (int u = 0; u < RG; ++u) {
+                        const int f = (it0 + u) * 64 + ln, row = f / QPR, qd = f - row * QPR;
+                        const f32x4 tv = *reinterpret_cast<const f32x4*>(wl + row * WC + 4 * qd);
+                        const int pix = i0 + 64 * wr + 32 * mi + row, co = j0 + WC * wc + 4 * qd;
+                        if (co < a.Cout) {
+                            float v[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                        if (a.of32) {  // (B, Cout, OH, OW): the last layer only
-                            const int b = pix / OHW, rem = pix - b * OHW;
+                            for (int e = 0; e < 4; ++e) v[e] = tv[e] * kOutScale;
+                            if (a.alpha) {
+                                const f32x4 al4 = *reinterpret_cast<const f32x4*>(a.alpha + co), be4 = *reinterpret_cast<const f32x4*>(a.beta + co);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) a.of32[((size_t)b * a.Cout + co + e) * OHW + rem] = v[e];
-                        } else {
-                            c16x4 oh, ol;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float s8 = v[e] * kActScale;
-                                const _Float16 hh = (_Float16)s8;
-                                oh[e] = hh;
-                                ol[e] = (_Float16)(s8 - (float)hh);
-                                bad |= !(fabsf(s8) <= kSplitPlaneLimit);
+                                for (int e = 0; e < 4; ++e) v[e] = v[e] * al4[e] + be4[e];
                             }
-                            *reinterpret_cast<c16x4*>(a.ohi + o) = oh;
-                            *reinterpret_cast<c16x4*>(a.olo + o) = ol;
+                            const size_t o = (size_t)pix * a.Cout + co;
+                            if (a.rhi) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const c16x4 h4 = __builtin_bit_cast(c16x4, rh[u]), l4 = __builtin_bit_cast(c16x4, rl[u]);
+                                    v[e] = ((float)h4[e] + (float)l4[e]) * (1.0f / kActScale) + v[e];
+                                }
+                            }
+                            if (a.relu)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                            if (a.of32) {  // (B, Cout, OH, OW): the last layer only
+                                const int b = pix / OHW, rem = pix - b * OHW;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) a.of32[((size_t)b * a.Cout + co + e) * OHW + rem] = v[e];
+                            } else {
+                                c16x4 oh, ol;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float s8 = v[e] * kActScale;
+                                    const _Float16 hh = (_Float16)s8;
+                                    oh[e] = hh;
+                                    ol[e] = (_Float16)(s8 - (float)hh);
+                                    bad |= !(fabsf(s8) <= kSplitPlaneLimit);
+                                }
+                                *reinterpret_cast<c16x4*>(a.ohi + o) = oh;
+                                *reinterpret_cast<c16x4*>(a.olo + o) = ol;
+                            }
                         }
                     }
                 }
@@ -340,6 +376,11 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
             if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE);
             __syncthreads();  // LDS buffer 0 is re-staged by the next segment's prologue
         }
+        if (a.trace) { const unsigned long long t = wall_clock64(); tr_tail += t - tr_t0; tr_t0 = t; }
+    }
+    if (a.trace && tid == 0) {
+        unsigned long long* w = a.trace + (size_t)p * 8;
+        w[0] = n_seg; w[1] = tr_steps; w[2] = tr_pro; w[3] = tr_loop; w[4] = tr_tail; w[5] = tr_begin; w[6] = tr_t0;
     }
 }
 
@@ -403,10 +444,13 @@ __global__ __launch_bounds__(256) void resize_stem_planes_kernel(const float* __
 }
 
 unsigned g_epoch_conv = 0;
+unsigned long long* g_conv_trace = nullptr;
 
 }  // namespace
 
 extern "C" {
+
+void gp_conv2d_planes_set_trace(unsigned long long* buf) { g_conv_trace = buf; }  // probe: 256 slots x 8 words, see ConvPArgs
 
 size_t gp_conv2d_planes_workspace_bytes(void) { return kHeaderBytes + sizeof(float) * kFragFloats * kSlots; }
 
@@ -443,6 +487,7 @@ int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const
     GP_REQUIRE(((uintptr_t)x_hi % 16 == 0) && ((uintptr_t)x_lo % 16 == 0) && ((uintptr_t)w_hi % 16 == 0) && ((uintptr_t)w_lo % 16 == 0) &&
                    ((uintptr_t)alpha % 16 == 0) && ((uintptr_t)beta % 16 == 0), "gp_conv2d_planes: misaligned operand");
     a.stem = 0;
+    a.trace = g_conv_trace;
     const int ni = Cout >= 256 ? 4 : Cout / 64;  // 128 -> 2, 192 -> 3, >= 256 -> 4
     a.tiles_i = (int)(npix / CT);
     a.tiles_j = (Cout + 64 * ni - 1) / (64 * ni);
@@ -494,6 +539,7 @@ int gp_conv2d_stem_planes(const void* x_hi, const void* x_lo, const void* w_hi, 
     a.alpha = alpha; a.beta = beta; a.rhi = nullptr; a.rlo = nullptr; a.ohi = (_Float16*)out_hi; a.olo = (_Float16*)out_lo; a.of32 = nullptr;
     a.B = B; a.H = S + 6; a.W = S + 8; a.Cin = 4; a.OH = S / 2; a.OW = S / 2; a.Cout = Cout; a.KH = 7; a.KW = 8; a.stride = 2; a.pad = 0;
     a.relu = relu; a.K = 7 * 32; a.stem = 1;
+    a.trace = g_conv_trace;
     const long long npix = (long long)B * a.OH * a.OW;
     GP_REQUIRE(npix % CT == 0 && (long long)B * a.H * a.W * 8 < (1ll << 31) && npix * Cout < (1ll << 31), "gp_conv2d_stem_planes: B*OH*OW=%lld must be a multiple of 256", npix);
     GP_REQUIRE(x_hi && x_lo && w_hi && w_lo && out_hi && out_lo && (alpha == nullptr) == (beta == nullptr), "gp_conv2d_stem_planes: null pointer");

@@ -284,6 +284,7 @@ int gp_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* w_hi, c
  * gp_conv2d_planes_workspace_bytes() bytes (stream-K hand-overs; zeroed ONCE by the caller at allocation -- launches tag their
  * hand-off flags with a per-launch epoch and never reset them).  gp_planes_from_cm: f32 [C][npix] -> such planes [npix][C]. */
 size_t gp_conv2d_planes_workspace_bytes(void);
+void gp_conv2d_planes_set_trace(unsigned long long* device_buf); /* probe: per slot segments / k-steps / ticks, NULL = off */
 int gp_planes_from_cm(const float* X, int C, int npix, void* hi, void* lo, void* stream);
 int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* alpha, const float* beta,
                      const void* res_hi, const void* res_lo, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,

@@ -210,6 +210,9 @@ def planes8(t, scale=8.0):
 
 @pytest.mark.parametrize("cin,cout,k,stride,pad,hw,B,res", [
     (128, 128, 3, 1, 1, 32, 2, True),     # NI = 2 (layer1 shape), 8 whole tiles on few slots
+    (128, 128, 3, 1, 1, 56, 8, True),     # NI = 2, 98 tiles on 64 slots: stream-K hand-overs, residual
+    (64, 128, 3, 2, 1, 64, 2, False),     # NI = 2, stride 2, Cin = 64
+    (128, 128, 3, 1, 1, 16, 3, False),    # 768 pixels = 3 tiles
     (128, 192, 3, 2, 1, 32, 4, False),    # NI = 3, stride 2 (layer2 entry); 4 tiles
     (128, 192, 1, 2, 0, 32, 4, False),    # 1 x 1 stride-2 shortcut, K = 128 (4 k-steps)
     (256, 512, 3, 2, 1, 32, 4, False),    # two co tiles (NI = 4), K = 2304; 8 tiles x 72 steps: few tiles -> cut into k ranges with hand-overs

@@ -398,34 +398,48 @@ __device__ __forceinline__ void epilogue_f32_lds(const ArgsP& a, f32x16 (&acc)[2
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) wl[frag_row(r, ln) * 128 + 32 * ni + l31] = acc[mi][ni][r];
+        // residual rows of this round in two batches of eight 16-byte loads, all in flight before the first is used: D may be
+        // the residual buffer itself (x += ...), so hipcc keeps every load behind the previous item's store -- one exposed
+        // memory round trip per item, 8-10 us of an 18-22 us tile epilogue (profiles/r02_planes_timeline.txt, proj / fc2).
+        // Safe in place: item `it` reads and writes only its own row piece.
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int row = 2 * it + half;
-            const f32x4 t = *reinterpret_cast<const f32x4*>(wl + row * 128 + 4 * l31);
-            const unsigned i = (unsigned)(i_base + 32 * mi + row);
-            float b = 0.f, sc = 0.f;
-            if (kBiasI) {
-                const float b0 = lane_bcast(bias_l, 32 * mi + 2 * it), b1 = lane_bcast(bias_l, 32 * mi + 2 * it + 1);
-                b = half ? b1 : b0;
-            }
-            f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+        for (int it0 = 0; it0 < 16; it0 += 8) {
+            f32x4 rs[8];
             if (EPI == XEPI_BIAS_I_SCALE_RES) {
-                const float s0 = lane_bcast(scale_l, 32 * mi + 2 * it), s1 = lane_bcast(scale_l, 32 * mi + 2 * it + 1);
-                sc = half ? s1 : s0;
-                rs = *reinterpret_cast<const f32x4*>(a.res + i * (unsigned)a.ldr + j);
-            }
-            f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = t[e] * a.out_scale;
-                if (kBiasI) v = v + b;
-                if (EPI == XEPI_BIAS_J) v = v + bias_j[e];
-                if (EPI == XEPI_BIAS_I_GELU) v = gelu_x(v);
-                if (EPI == XEPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
-                if (EPI == XEPI_BIAS_I_SCALE_RES) v = rs[e] + sc * v;
-                o[e] = v;
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned i = (unsigned)(i_base + 32 * mi + 2 * (it0 + u) + half);
+                    rs[u] = *reinterpret_cast<const f32x4*>(a.res + i * (unsigned)a.ldr + j);
+                }
+                asm volatile("" : "+v"(rs[0]), "+v"(rs[1]), "+v"(rs[2]), "+v"(rs[3]), "+v"(rs[4]), "+v"(rs[5]), "+v"(rs[6]), "+v"(rs[7]));
             }
-            *reinterpret_cast<f32x4*>(a.D + i * (unsigned)a.ldd + j) = o;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int it = it0 + u, row = 2 * it + half;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(wl + row * 128 + 4 * l31);
+                const unsigned i = (unsigned)(i_base + 32 * mi + row);
+                float b = 0.f, sc = 0.f;
+                if (kBiasI) {
+                    const float b0 = lane_bcast(bias_l, 32 * mi + 2 * it), b1 = lane_bcast(bias_l, 32 * mi + 2 * it + 1);
+                    b = half ? b1 : b0;
+                }
+                if (EPI == XEPI_BIAS_I_SCALE_RES) {
+                    const float s0 = lane_bcast(scale_l, 32 * mi + 2 * it), s1 = lane_bcast(scale_l, 32 * mi + 2 * it + 1);
+                    sc = half ? s1 : s0;
+                }
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = t[e] * a.out_scale;
+                    if (kBiasI) v = v + b;
+                    if (EPI == XEPI_BIAS_J) v = v + bias_j[e];
+                    if (EPI == XEPI_BIAS_I_GELU) v = gelu_x(v);
+                    if (EPI == XEPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
+                    if (EPI == XEPI_BIAS_I_SCALE_RES) v = rs[u][e] + sc * v;
+                    o[e] = v;
+                }
+                *reinterpret_cast<f32x4*>(a.D + i * (unsigned)a.ldd + j) = o;
+            }
         }
     }
 }

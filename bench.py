@@ -90,6 +90,9 @@ def main():
                          "chain = f32-input MFMA fmaf chain (bit-exact vs the CPU oracle).  The other mode is timed too "
                          "and reported under `other_numerics` (N=1 only).")
     args = ap.parse_args()
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible -- the hot path is HIP only (no CPU fallback); run it on an MI355X box "
+                 "(tests/test_sharding_gloo.py covers the N > 1 exchange logic on CPU)")
 
     import torch.distributed as dist
 

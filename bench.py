@@ -20,6 +20,11 @@ import os
 import sys
 import time
 
+# kernel arguments in device memory instead of host memory the command processor reads over the fabric: the step has ~210
+# dependent launches, and each starts 1-2 us earlier (measured A/B on one box: 45.95 -> 45.65 ms per step).  A HIP runtime
+# setting, read when the runtime is loaded -- hence before `import torch`; an exported value wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import numpy as np
 import torch
 

@@ -495,6 +495,25 @@ __device__ __forceinline__ void epilogue_planes_lds(const ArgsP& a, f32x16 (&acc
     if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE);
 }
 
+// Strip fragments are handed out on demand: a slot asks for the next fragment when it has finished its tiles.  The per-slot
+// time stamps show slots of different XCDs finishing equal work 8-11 % apart (k-step 2.33 us on the fastest XCD, 2.66 on the
+// slowest, the same order in every launch of a box), and with the static split (fragment f to slot f) the 64 fragments of a
+// ViT-L launch sat on the first 64 slots whatever their speed: a fc2 launch ended with 22 us of strip work on a quarter of
+// the chip.  One counter word per scratch, tagged with the launch's epoch (no reset between launches): count in the low 12 bits.
+constexpr int kStripCtr = 1030;  // header word (after the slot flags and the two error words)
+__device__ __forceinline__ int strip_grab(int* ctr, int tag)
+{
+    // Once the word carries this launch's tag: one fetch-add per request.  The first arrivals of a launch still see the previous
+    // launch's tag: they all compare-and-swap the SAME observed value against tag | 1 -- exactly one wins (and owns fragment 0),
+    // the others re-read and join the fetch-adds.  (Measured on the way: a compare-and-swap per request costs a round per
+    // contender, 450 us with 256 slots; fetch-add first and repair afterwards never settles while others keep adding.)
+    for (;;) {
+        int cur = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((cur & ~0xfff) == tag) return __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xfff;
+        if (__hip_atomic_compare_exchange_strong(ctr, &cur, tag | 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;
+    }
+}
+
 // ---- The ragged edge of J.  257 tokens per crop: J = 257 B is never a multiple of 256, and at B = 64 the 65th column of
 // tiles (64 valid rows of 256) turned a 256-tile problem -- one whole tile per CU, no hand-over at all -- into 260 tiles
 // on 256 slots: half the chip split tiles, published and re-read 256 KB accumulator fragments and finished 40 % later
@@ -506,7 +525,7 @@ __device__ __forceinline__ void epilogue_planes_lds(const ArgsP& a, f32x16 (&acc
 // deterministic) and wave 0 applies the epilogue.  Same three products per k16 block; only the summation order over K
 // differs from the tile path (strip outputs agree with tiled ones to f32 round-off, not bit for bit).
 template <int EPI>
-__device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ red, int slot, int nslots, int tid)
+__device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ red, int* __restrict__ next_f, int tid)
 {
     const int lane = tid & 63, l31 = lane & 31, half = lane >> 5, wave = tid >> 6;
     const int nfi = a.tiles_i * (TB / 32), nfrag = nfi * a.strip_fj;
@@ -519,7 +538,12 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
     constexpr int SP = 264, SPLANE = 32 * SP, SSTEP = 4 * SPLANE;    // halfs: padded row (528 B), plane, super-step (A hi, A lo, B hi, B lo)
     _Float16* sl = reinterpret_cast<_Float16*>(red);
     const bool staged = (a.K & 255) == 0;
-    for (int f = slot; f < nfrag; f += nslots) {                     // uniform over the workgroup (barriers inside)
+    const int tag = (a.epoch & 0x7ffff) << 12;
+    for (;;) {                                                       // uniform over the workgroup (barriers inside)
+        if (tid == 0) *next_f = strip_grab(a.flags + kStripCtr, tag);
+        __syncthreads();
+        const int f = *next_f;
+        if (f >= nfrag) break;
         const int i0 = (f % nfi) * 32, j0 = a.strip_j0 + (f / nfi) * 32;
         const _Float16* pah = a.ahi + (size_t)(i0 + l31) * a.K + 8 * half;
         const _Float16* pal = a.alo + (size_t)(i0 + l31) * a.K + 8 * half;
@@ -673,7 +697,7 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
             }
             if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE);
         }
-        __syncthreads();  // `red` is rewritten by the next fragment
+        __syncthreads();  // `red` and *next_f are rewritten for the next fragment
     }
 }
 
@@ -683,6 +707,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
     unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     const unsigned long long k_c0 = TIMING ? __builtin_readcyclecounter() : 0, k_w0 = TIMING ? wall_clock64() : 0;
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * TBUF + 2048];  // 128 KiB of operand buffers (+ 4 KiB: the strip's padded rows)
+    __shared__ int strip_next;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, grp = wave >> 2;
@@ -908,7 +933,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
         }
         if (TIMING && a.trace && tid == 0 && seg < 7) a.trace[(size_t)p * 32 + 5 + 4 * seg] = wall_clock64();
     }
-    if (a.strip_fj > 0) strip_phase<EPI>(a, reinterpret_cast<float*>(lds), p, gridDim.x, threadIdx.x);
+    if (a.strip_fj > 0) strip_phase<EPI>(a, reinterpret_cast<float*>(lds), &strip_next, threadIdx.x);
     if (TIMING && a.trace && tid == 0) a.trace[(size_t)p * 32 + 31] = wall_clock64();
     if (TIMING && blockIdx.x == 100 && tid == 0) {
         for (int i = 0; i < 6; ++i) g_t256[i] = tc[i];
@@ -999,6 +1024,7 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
                "gp_gemm_planes256: I=%d, J=%d must be multiples of 256 with >= 256 tiles below J_valid=%d, K=%d of 32", I, J, J_valid, K);
     int J_main, strip_fj;
     planes_ragged(J, J_valid, J_main, strip_fj);
+    GP_REQUIRE((long long)(I / 32) * strip_fj + kSlots < 4096, "gp_gemm_planes256: too many strip fragments for the 12-bit counter");
     GP_REQUIRE(ahi && alo && bhi && blo && scratch && ((uintptr_t)ahi % 16 == 0) && ((uintptr_t)alo % 16 == 0) &&
                    ((uintptr_t)bhi % 16 == 0) && ((uintptr_t)blo % 16 == 0) && ((uintptr_t)scratch % 16 == 0),
                "gp_gemm_planes256: null / misaligned operand");

@@ -1,6 +1,6 @@
 """GPU probe: per-slot timeline of the plane GEMM (gp_gemm_planes256_trace) for the five ViT-L GEMM shapes at B = 64:
 where a slot's time goes -- accumulator hand-over waits, k loop, epilogue / publish -- next to the event-timed launch."""
-import sys, os, ctypes
+import os, sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -63,3 +63,8 @@ for (nw, K, name, epi) in [(2048, 1024, "qk", 7), (1024, 1024, "v", 7), (1024, 1
           f"epilogues {np.sum(ep) / 256:5.1f} us ({np.mean(ep) if ep else 0:5.1f} each x {len(ep) / 256:.2f}), publishes {np.sum(pub) / 256:5.1f} us "
           f"({np.mean(pub) if pub else 0:5.1f} each), waits + prologue {np.sum(wait) / 256:5.1f} us (max single {np.max(wait):5.1f}), "
           f"strip mean {np.mean(strip):4.1f} max {np.max(strip):4.1f} us", flush=True)
+    if os.environ.get("PER_XCD"):   # slot p runs on XCD p & 7 (dispatch order): is the spread of lifetimes systematic?
+        e = np.array(ends)
+        print("      lifetime by XCD (us):", " ".join(f"{e[x::8].mean():6.1f}" for x in range(8)), "| by slot-in-XCD quartile:",
+              " ".join(f"{e.reshape(32, 8)[q * 8:(q + 1) * 8].mean():6.1f}" for q in range(4)),
+              "| k-loop us/step by XCD:", " ".join(f"{(kl.reshape(256, -1).sum(1)[x::8].mean() / (steps.sum() / 256)):5.3f}" for x in range(8)) if len(kl) % 256 == 0 else "", flush=True)

@@ -7,6 +7,7 @@
 
 The arithmetic below restates the kernel's index computations line by line (same names); the GPU tests check the
 kernel itself against f64 and bit-for-bit against the lock-step kernel."""
+import numpy as np
 import pytest
 
 
@@ -108,3 +109,58 @@ def test_half_step_offset_loop_has_no_lds_hazard(ns):
                     assert epoch[g][("M", slab)] > epoch[gg][("C", slab - 2)], (ns, slab, g, gg)
     # the offset: group 1 stages while group 0 computes, in the first half of every interval
     assert ev[0][0] == ("C", 0) and ev[1][0] == ("M", 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# strip_grab (gp_split256.hip): the ragged strip's fragments are handed out on demand through ONE word per scratch,
+# [launch tag : 20 | count : 12], never reset between launches.  Host model of the protocol at the granularity of its atomic
+# operations (load / fetch-add / compare-and-swap), run under random interleavings: every fragment goes to exactly one slot,
+# whatever the word held before (zeros, the previous launch's tag and count, garbage).
+def _grab(word, tag):
+    """Generator: yields once per atomic operation (the scheduler may switch slots there); returns the fragment index."""
+    while True:
+        cur = word[0]                                   # atomic load
+        yield
+        if (cur & ~0xfff) == tag:
+            old = word[0]                               # fetch-add
+            word[0] = old + 1
+            yield
+            return old & 0xfff
+        ok = word[0] == cur                             # compare-and-swap(expected = cur, desired = tag | 1)
+        if ok:
+            word[0] = tag | 1
+        yield
+        if ok:
+            return 0
+
+
+def _slot(word, tag, nfrag, got):
+    while True:
+        f = yield from _grab(word, tag)
+        if f >= nfrag:
+            return
+        got.append(f)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("nslots,nfrag", [(256, 64), (256, 128), (8, 1), (3, 40)])
+def test_strip_fragments_are_handed_out_exactly_once(seed, nslots, nfrag):
+    rs = np.random.RandomState(seed)
+    word = [0]
+    for launch in range(4):                             # consecutive launches on the same scratch: tags differ, nothing is reset
+        if launch == 2:
+            word[0] = int(rs.randint(0, 2 ** 31))       # and an arbitrary left-over
+        tag = ((0x40000000 | (7 + launch)) & 0x7ffff) << 12
+        got = [[] for _ in range(nslots)]
+        live = {i: _slot(word, tag, nfrag, got[i]) for i in range(nslots)}
+        order = list(live)
+        while live:
+            i = order[rs.randint(len(order))]
+            try:
+                next(live[i])
+            except StopIteration:
+                del live[i]
+                order.remove(i)
+        allf = sorted(f for g in got for f in g)
+        assert allf == list(range(nfrag))
+        assert (word[0] & ~0xfff) == tag and (word[0] & 0xfff) == nfrag + nslots   # every slot overshoots exactly once

@@ -364,6 +364,7 @@ struct ArgsP {
     unsigned long long* trace;  // TIMING builds: per-block segment time stamps (100 MHz ticks), else null
     int* status;                // guard rails (gp_common.h)
     int strip_j0, strip_fj;     // ragged J: rows [strip_j0, strip_j0 + 32 strip_fj) of B are not tiled, see strip_phase
+    int par;                    // fewer tiles than slots: the slots of a tile split its K in PARALLEL (see the kernel)
 };
 
 __device__ __forceinline__ float lane_bcast(float v, int lane)  // value held by `lane` (compile-time constant) -> SGPR
@@ -701,7 +702,7 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
     }
 }
 
-template <int EPI, bool TIMING = false>
+template <int EPI, bool TIMING = false, bool PAR = false>
 __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
 {
     unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
     // r * slots_x + n -- the 32 slots of an XCD then sit on the same k-step of 32 neighbouring tiles (4 i-panels x 8
     // j-panels) and share their operand slabs in that XCD's L2.  Only the last round + remainder is cut stream-K style
     // (its slots run at staggered k offsets and get no L2 reuse: 1.9 GB fetched per fc1 launch when everything was).
-    const int rounds_dp = ((a.dp & 1) && n_t / slots_x > 1) ? n_t / slots_x - 1 : 0;
+    const int rounds_dp = (!PAR && (a.dp & 1) && n_t / slots_x > 1) ? n_t / slots_x - 1 : 0;
     const int n_dp = rounds_dp * slots_x;
     const long long U = (long long)(n_t - n_dp) * nstep;
     const long long u0 = U * n / slots_x, u1 = U * (n + 1) / slots_x;
@@ -765,7 +766,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
         const int i0 = (first_i + rr % gsz) * TB, j0 = (rr / gsz) * TB;
 
         f32x16 acc[2][4];
-        if (is_rest) {
+        if (!PAR && is_rest) {
             if (tid == 0) {
                 int spins = 0;
                 while (__hip_atomic_load(a.flags + (p - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
@@ -779,14 +780,14 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
-            const f32x4* w = reinterpret_cast<const f32x4*>(a.partial + (size_t)(p - 8) * kFragFloats) + tid * 32;
+            const f32x4* w = reinterpret_cast<const f32x4*>(a.partial + (size_t)(p - 8) * kFragFloats) + tid;   // piece u of thread tid at [u][tid]: a wave instruction covers 1 KB contiguous
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 v = w[(mi * 4 + ni) * 4 + r4];
+                        const f32x4 v = w[((mi * 4 + ni) * 4 + r4) * TNT];
                         acc[mi][ni][r4 * 4 + 0] = v[0]; acc[mi][ni][r4 * 4 + 1] = v[1];
                         acc[mi][ni][r4 * 4 + 2] = v[2]; acc[mi][ni][r4 * 4 + 3] = v[3];
                     }
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
         if (TIMING && a.trace && tid == 0 && seg < 7) a.trace[(size_t)p * 32 + 4 + 4 * seg] = wall_clock64();
 
         if (is_head) {  // publish the fragment for slot n+1 (agent-scope release by one lane)
-            f32x4* w = reinterpret_cast<f32x4*>(a.partial + (size_t)p * kFragFloats) + tid * 32;
+            f32x4* w = reinterpret_cast<f32x4*>(a.partial + (size_t)p * kFragFloats) + tid;   // piece u of thread tid at [u][tid]: a wave instruction covers 1 KB contiguous
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -910,17 +911,61 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
                         f32x4 v;
                         v[0] = acc[mi][ni][r4 * 4 + 0]; v[1] = acc[mi][ni][r4 * 4 + 1];
                         v[2] = acc[mi][ni][r4 * 4 + 2]; v[3] = acc[mi][ni][r4 * 4 + 3];
-                        w[(mi * 4 + ni) * 4 + r4] = v;
+                        // write-through (sc1) stores: the fragment goes to memory as it is written and the flag needs no L2
+                        // write-back behind it (guide, "publish-large": 3.0 vs 8.2 us per 64 KB-per-workgroup publish; here every
+                        // slot of a parallel-split launch publishes 256 KB at the same moment)
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(w + ((mi * 4 + ni) * 4 + r4) * TNT), "v"(v) : "memory");
                     }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (!(a.dp & 2))  // test hook (gp_gemm_planes256_set_dp(.. | 2)): a LOST hand-off -> the waiter must time out and flag it
                     __hip_atomic_store(a.flags + p, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
+            if (PAR && is_rest) {
+                // Parallel split-K (fewer tiles than slots: B < 64 crops at ViT-L).  Every slot of this tile started from a zero
+                // accumulator and ran its own k range at the same time; the slot holding the LAST range owns the tile: it adds
+                // the published partial accumulators of the slots before it -- in slot order, nearest first: a fixed order, the
+                // result depends on the shape only -- and runs the epilogue.  (The serial hand-over above keeps a split tile's
+                // summation order but makes its slots wait for each other: with T < slots every tile is split and a launch
+                // would take as long as one whole tile.)  Predecessor m of this XCD holds units [U m / slots, U (m+1) / slots).
+                // (32-bit, no division: floor(U m / slots) > t  <=>  U m >= (t + 1) slots; U < 2^15 here)
+                const int tile_u0 = ta * nstep, U32 = (int)U;
+                int m_lo = n - 1;
+                while (m_lo > 0 && U32 * m_lo >= (tile_u0 + 1) * slots_x) --m_lo;   // first slot whose range reaches into this tile
+                if (tid == 0) {
+                    for (int m = n - 1; m >= m_lo; --m) {
+                        int spins = 0;
+                        while (__hip_atomic_load(a.flags + (x + 8 * m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+                            __builtin_amdgcn_s_sleep(16);
+                            if (++spins > kSpin) {
+                                __hip_atomic_store(a.flags + kErrWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                gp_raise(a.status, GP_ST_HANDOFF_SPLIT);
+                                break;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                for (int m = n - 1; m >= m_lo; --m) {
+                    const f32x4* w = reinterpret_cast<const f32x4*>(a.partial + (size_t)(x + 8 * m) * kFragFloats) + tid;   // piece u of thread tid at [u][tid]: a wave instruction covers 1 KB contiguous
+#pragma unroll
+                    for (int q8 = 0; q8 < 4; ++q8) {  // eight 16-byte loads in flight, then their 32 adds (more would spill: the kernel sits at 251 VGPRs)
+                        f32x4 v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = w[(q8 * 8 + u) * TNT];
+                        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int f = q8 * 8 + u, mi = f >> 4, ni = (f >> 2) & 3, r4 = f & 3;
+                            acc[mi][ni][r4 * 4 + 0] += v[u][0]; acc[mi][ni][r4 * 4 + 1] += v[u][1];
+                            acc[mi][ni][r4 * 4 + 2] += v[u][2]; acc[mi][ni][r4 * 4 + 3] += v[u][3];
+                        }
+                    }
+                }
+            }
             int tid_ = threadIdx.x;
             asm volatile("" : "+v"(tid_));  // keep the epilogue's address arithmetic inside the segment loop
             __syncthreads();                // every wave has read its last operand fragments: the buffers are free
@@ -1009,11 +1054,22 @@ static void planes_ragged(int J, int J_valid, int& J_main, int& strip_fj)
     J_main = (J_valid >= J || J_valid <= 0) ? J : (J_valid / TB) * TB;
     strip_fj = (J_main == J) ? 0 : (J_valid - J_main + 31) / 32;
 }
+// Fewer tiles than slots (B < 64 crops at ViT-L): the kernel's parallel split-K mode needs at least one tile per XCD and one
+// k-step per slot (every slot's range then lies inside one or two tiles).
+static bool planes_par_usable(int I, int J_main, int K)
+{
+    if (I <= 0 || J_main <= 0 || I % TB || J_main % TB || K % TBK) return false;
+    const long long T = (long long)(I / TB) * (J_main / TB);
+    return T < kSlots && T >= 8 && (T / 8) * (K / TBK) >= kSlots / 8;
+}
+static int g_planes_par = 1;  // 0: shapes with fewer tiles than slots are refused (the caller falls back to the 128 x 128 kernel; A/B hook)
 bool gp_gemm_planes256_usable(int I, int J, int J_valid, int K)
 {
     int J_main, fj;
     planes_ragged(J, J_valid, J_main, fj);
-    return J % TB == 0 && J_valid <= J && gp_gemm_split256_usable(I, J_main, K);
+    if (J % TB || J_valid > J) return false;
+    if ((long long)(I / 32) * fj + kSlots >= 4096) return false;  // strip fragments must fit the 12-bit counter (strip_grab)
+    return gp_gemm_split256_usable(I, J_main, K) || (g_planes_par && planes_par_usable(I, J_main, K));
 }
 
 int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
@@ -1021,7 +1077,7 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
                              const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace)
 {
     GP_REQUIRE(gp_gemm_planes256_usable(I, J, J_valid, K),
-               "gp_gemm_planes256: I=%d, J=%d must be multiples of 256 with >= 256 tiles below J_valid=%d, K=%d of 32", I, J, J_valid, K);
+               "gp_gemm_planes256: I=%d, J=%d must be multiples of 256 with >= 8 tiles below J_valid=%d, K=%d of 32", I, J, J_valid, K);
     int J_main, strip_fj;
     planes_ragged(J, J_valid, J_main, strip_fj);
     GP_REQUIRE((long long)(I / 32) * strip_fj + kSlots < 4096, "gp_gemm_planes256: too many strip fragments for the 12-bit counter");
@@ -1040,10 +1096,20 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
     ArgsP a{(const _Float16*)ahi, (const _Float16*)alo, (const _Float16*)bhi, (const _Float16*)blo, D, ldd, (_Float16*)ohi, (_Float16*)olo, ldo,
             K, bias, scale, res, ldr, I / TB, J_main / TB, 4, reinterpret_cast<int*>(scratch),
             reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, out_scale, g_planes_dp, trace, gp_status_buffer(),
-            J_main, strip_fj};
+            J_main, strip_fj, (long long)(I / TB) * (J_main / TB) < kSlots ? 1 : 0};
     g_epoch256 = (g_epoch256 + 1) & 0x3fffffff;
     a.epoch = (int)(0x40000000u | g_epoch256);
     GpProfScope prof(GP_PROF_GEMM_SPLIT, 2.0 * I * (J_valid > 0 && J_valid < J ? J_valid : J) * K, st);
+    if (trace && a.par) {  // probe build of the parallel split-K kernel
+        switch (epilogue) {
+            case XEPI_BIAS_I_SCALE_RES: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES, true, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case PEPI_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_GELU_PLANES, true, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case PEPI_BIAS_I_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES, true, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            default: GP_REQUIRE(false, "gp_gemm_planes256_trace: epilogue %d has no traced parallel build", epilogue);
+        }
+        GP_CHECK_LAUNCH("gp_gemm_planes256_trace/par");
+        return GP_OK;
+    }
     if (trace) {  // probe build with per-slot time stamps
         switch (epilogue) {
             case XEPI_NONE: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_NONE, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
@@ -1053,6 +1119,21 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
             default: GP_REQUIRE(false, "gp_gemm_planes256_trace: epilogue %d has no traced build", epilogue);
         }
         GP_CHECK_LAUNCH("gp_gemm_planes256_trace");
+        return GP_OK;
+    }
+    if (a.par) {  // fewer tiles than slots: the parallel split-K build (its own instantiation: the serial hand-over kernel keeps its registers)
+        switch (epilogue) {
+            case XEPI_NONE: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_NONE, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case XEPI_BIAS_I: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case XEPI_BIAS_I_GELU: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_GELU, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case XEPI_BIAS_I_SCALE_RES: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case XEPI_BIAS_J: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_J, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case XEPI_BIAS_I_RELU: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_RELU, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case PEPI_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_GELU_PLANES, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case PEPI_BIAS_I_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            default: GP_REQUIRE(false, "gp_gemm_planes256: unknown epilogue %d", epilogue);
+        }
+        GP_CHECK_LAUNCH("gp_gemm_planes256/par");
         return GP_OK;
     }
     switch (epilogue) {
@@ -1176,6 +1257,12 @@ int gp_gemm_planes256_trace(const void* a_hi, const void* a_lo, const void* b_hi
 int gp_gemm_planes256_set_dp(int mode)  // bit 0: data-parallel rounds (default on); bit 1: test hook, head fragments are never published
 {
     g_planes_dp = mode & 3;
+    return GP_OK;
+}
+
+int gp_gemm_planes256_set_par(int on)  // 0: refuse shapes with fewer tiles than slots (A/B hook: the ViT then takes the 128 x 128 kernels)
+{
+    g_planes_par = on ? 1 : 0;
     return GP_OK;
 }
 

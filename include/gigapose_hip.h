@@ -220,11 +220,15 @@ int gp_gemm_planes256(const void* a_hi, const void* a_lo, const void* b_hi, cons
  * epilogue are the same f32 arithmetic in both modes.) */
 int gp_gemm_planes256_set_dp(int mode); /* bit 0 (default 1): data-parallel rounds before the stream-K remainder; bit 1: TEST hook,
                                            head fragments are never published (every waiter times out -> GP_STATUS_HANDOFF_SPLIT) */
+int gp_gemm_planes256_set_par(int on); /* default 1: shapes with 8 <= tiles < 256 (ViT-L below 64 crops) run with the slots of a tile splitting
+                                          its K in parallel (partial accumulators added in a fixed order by the slot holding the last k
+                                          range); 0: such shapes are refused and gp_vit_forward_split falls back to the 128 x 128 kernels */
 /* Ragged J (257 tokens per crop are never a multiple of 256): only rows < J_valid of B carry data (J, the padded row
  * count of the buffers, stays a multiple of 256).  The 256 x 256 tiles cover floor(J_valid / 256) * 256 rows -- at
  * B = 64 crops exactly one / two / four whole tiles per CU, no stream-K hand-over -- and the remaining < 256 rows are
  * computed as 32 x 32 fragments with the same per-accumulator instruction sequence (bit-identical to tiled results).
- * Rows >= round_up(J_valid, 32) of the outputs are not written.  Needs (I / 256) * (J_valid / 256) >= 256. */
+ * Rows >= round_up(J_valid, 32) of the outputs are not written.  Needs (I / 256) * (J_valid / 256) >= 8 tiles, at least one
+ * k-step per slot, and (with fewer than 256 tiles) gp_gemm_planes256_set_par(1). */
 int gp_gemm_planes256_ragged(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
                              void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
                              const float* residual, int ldr, float out_scale, float* scratch, size_t scratch_bytes, void* stream);

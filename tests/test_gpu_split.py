@@ -499,3 +499,40 @@ def test_planes256_ragged_rows(I, J, jv, K):
         v_r = rh[jm:jv].double() + rl[jm:jv].double()
         assert ((v_f - v_r).abs() <= 8.0 * 4e-7 * mag.t() + 1e-5 * v_f.abs()).all(), f"epilogue {epi}: strip rows differ"
         assert not rh[top:].any() and not rl[top:].any()
+
+
+# ViT-L shapes below 64 crops: fewer 256 x 256 tiles than slots -> the slots of a tile split its K in PARALLEL and the slot with
+# the last range adds the published partial accumulators (gp_split256.hip).  (I, J, J_valid, K): proj / fc2 / q|k|v / fc1 at
+# B = 16 (J_valid = 4112), proj at B = 8 and B = 33, a 9-tile problem (one XCD holds two tiles, seven hold one)
+PAR_SHAPES = [(1024, 4352, 4112, 1024), (1024, 4352, 4112, 4096), (3072, 4352, 4112, 1024), (4096, 4352, 4112, 1024),
+              (1024, 2304, 2056, 1024), (1024, 8704, 8481, 1024), (768, 768, 768, 1024)]
+
+
+@pytest.mark.parametrize("I,J,jv,K", PAR_SHAPES)
+def test_planes256_parallel_split_k(I, J, jv, K):
+    """Fewer tiles than slots: every epilogue against float64 on the tiled columns AND the strip, run twice -- the partial
+    accumulators are added in a fixed order, so two launches must agree bit for bit."""
+    torch.manual_seed(I + jv + K)
+    A = torch.randn(I, K, device=DEV) * 0.05
+    Bm = torch.randn(J, K, device=DEV) * 1.3
+    bias, scale = torch.randn(I, device=DEV), torch.randn(I, device=DEV)
+    res = torch.randn(I, J, device=DEV)
+    top = (jv + 31) // 32 * 32
+    ref = A.double() @ Bm[:jv].double().t()
+    mag = A.double().abs() @ Bm[:jv].double().abs().t()
+    d0 = planes256_gemm(A, Bm, 0, bias, scale, torch.zeros_like(res), j_valid=jv)
+    e64 = ((d0[:, :jv].double() - ref).abs() / mag).max().item()
+    print(f"parallel split-K I={I} J_valid={jv} K={K}: max err / sum|a||b| vs f64 = {e64:.2e}")
+    assert e64 < 4e-7
+    assert torch.equal(d0, planes256_gemm(A, Bm, 0, bias, scale, torch.zeros_like(res), j_valid=jv)), "two launches differ"
+    d3 = planes256_gemm(A, Bm, 3, bias, scale, res, j_valid=jv)
+    want = res[:, :jv].double() + scale[:, None].double() * (ref + bias[:, None].double())
+    assert ((d3[:, :jv].double() - want).abs() <= 4e-7 * scale[:, None].abs().double() * (mag + bias[:, None].abs().double()) + 2.4e-7 * want.abs()).all()
+    assert torch.equal(d3[:, top:], res[:, top:]), "columns beyond the strip were written"
+    for epi in (6, 7):
+        oh, ol = planes256_gemm(A, Bm, epi, bias, j_valid=jv)
+        x = ref + bias[:, None].double()
+        want = torch.nn.functional.gelu(x) if epi == 6 else x
+        got = (oh[:jv].double() + ol[:jv].double()).t() / 8.0
+        assert ((got - want).abs() <= 1.5e-6 * (mag + bias[:, None].abs().double()) + 1e-6 * want.abs()).all(), f"epilogue {epi}"
+        assert not oh[top:].any() and not ol[top:].any()

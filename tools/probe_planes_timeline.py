@@ -25,7 +25,7 @@ def timeit(fn, iters=10, warm=3):
 torch.manual_seed(0)
 M = int(os.environ.get("MPAD", 16640))           # padded rows of the token dimension (ViT-L at B = 64)
 MV = int(os.environ.get("MTOK", 16448))          # rows that carry tokens (64 x 257); MTOK=16640 probes the fully tiled launch
-for (nw, K, name, epi) in [(2048, 1024, "qk", 7), (1024, 1024, "v", 7), (1024, 1024, "proj", 3), (4096, 1024, "fc1", 6), (1024, 4096, "fc2", 3)]:
+for (nw, K, name, epi) in [(3072, 1024, "qkv", 7), (1024, 1024, "proj", 3), (4096, 1024, "fc1", 6), (1024, 4096, "fc2", 3)]:
     W = torch.randn(nw, K, device=dev) * 0.03
     Xt = torch.randn(M, K, device=dev) * 1.5
     whi, wlo = planes(W, 64.0); xhi, xlo = planes(Xt, 8.0)
@@ -44,14 +44,14 @@ for (nw, K, name, epi) in [(2048, 1024, "qk", 7), (1024, 1024, "v", 7), (1024, 1
     t = trace.cpu().numpy().reshape(256, 32).astype(np.int64)
     start, nseg = t[:, 0], t[:, 1]
     t0 = start.min()
-    ends, kl, ep, wait, steps, pub, strip = [], [], [], [], [], [], []
+    ends, kl, ep, wait, steps, pub, strip, ep_own = [], [], [], [], [], [], [], []
     for p in range(256):
         prev = start[p]
         for s in range(min(int(nseg[p]), 7)):
             kind, ns = int(t[p, 2 + 4 * s] >> 32), int(t[p, 2 + 4 * s] & 0xffffffff)
             a, b, c = t[p, 3 + 4 * s], t[p, 4 + 4 * s], t[p, 5 + 4 * s]
             wait.append((a - prev) / 100.0); kl.append((b - a) / 100.0); steps.append(ns)
-            (pub if kind == 1 else ep).append((c - b) / 100.0)
+            (pub if kind in (1, 3) else (ep_own if kind == 2 else ep)).append((c - b) / 100.0)
             prev = c
         strip.append((t[p, 31] - prev) / 100.0)
         ends.append((t[p, 31] - t0) / 100.0)
@@ -60,7 +60,7 @@ for (nw, K, name, epi) in [(2048, 1024, "qk", 7), (1024, 1024, "v", 7), (1024, 1
     print(f"{name:5s} I={I} J={J} K={K} epi {epi}: event-timed {t_plain:6.1f} us = {fl / t_plain / 1e6:5.0f} TF-eq | traced slots: start spread "
           f"{(start.max() - t0) / 100.0:5.1f} us, lifetime min/mean/max {min(ends):6.1f}/{np.mean(ends):6.1f}/{max(ends):6.1f} us | per slot: segments "
           f"{nseg.mean():.2f}, k loop {kl.sum() / 256:6.1f} us ({kl.sum() / steps.sum():.3f} us/step, {steps.sum() / 256:.1f} steps), "
-          f"epilogues {np.sum(ep) / 256:5.1f} us ({np.mean(ep) if ep else 0:5.1f} each x {len(ep) / 256:.2f}), publishes {np.sum(pub) / 256:5.1f} us "
+          f"epilogues {np.sum(ep) / 256:5.1f} us ({np.mean(ep) if ep else 0:5.1f} each x {len(ep) / 256:.2f}), owner reduce + epilogue {np.mean(ep_own) if ep_own else 0:5.1f} each x {len(ep_own) / 256:.2f}, publishes {np.sum(pub) / 256:5.1f} us "
           f"({np.mean(pub) if pub else 0:5.1f} each), waits + prologue {np.sum(wait) / 256:5.1f} us (max single {np.max(wait):5.1f}), "
           f"strip mean {np.mean(strip):4.1f} max {np.max(strip):4.1f} us", flush=True)
     if os.environ.get("PER_XCD"):   # slot p runs on XCD p & 7 (dispatch order): is the spread of lifetimes systematic?

@@ -183,6 +183,24 @@ def main():
         return dt, dt_serial, kern, kern_timed
 
     dt, dt_serial, kern, kern_timed = run_mode(args.numerics)
+    # N > 1: the same job once more in the OTHER multi-GPU mode, so that one driver run reports both -- "sharded" (north_star's
+    # template-bank partition: two exchanges per step) and "replicas" (full bank per GPU, no data-path collective).  Weak scaling
+    # either way; in sharded mode every rank still matches all W * B crops against its 1 / W of the bank, so it saves memory,
+    # not matcher work.
+    other_modes = None
+    if world > 1 and mode in ("sharded", "replicas"):
+        alt = "replicas" if mode == "sharded" else "sharded"
+        try:
+            if alt == "replicas":
+                model.template_shard = None
+            else:
+                model.enable_template_sharding()
+            adt, _, akern, _ = run_mode(args.numerics)
+            other_modes = {alt: {"value": round(world * args.batch * args.steps / adt, 2), "unit": "query-crops/sec",
+                                 "ms_per_step": round(1e3 * adt / args.steps, 3), "parallelism": f"{alt}{world}",
+                                 "kernels_ms_per_step": {k: v["ms_per_step"] for k, v in akern.items()}}}
+        except Exception as e:  # never lose the headline line
+            other_modes = {alt: {"error": repr(e)}}
     other = None
     if world == 1 and not dist.is_initialized() and not args.no_other:
         other_mode = "chain" if args.numerics == "split" else "split"
@@ -196,9 +214,11 @@ def main():
     other_configs = None
     if world == 1 and not dist.is_initialized() and not args.no_configs and args.variant == "dinov2_vitl14":
         other_configs = {}
-        for key, n_obj, bank_dtype, text in (
+        extra = [(key, n_obj, bank_dtype, text) for key, n_obj, bank_dtype, text in (
                 ("config3", 8, "f32", "LM-O shape: 8 objects x 162 templates, 64-crop multi-detection batch with mixed labels, 1 GPU"),
-                ("config5", 40, "f16", "HANDAL/HOPE scale: 40 objects x 162 templates, fp16 feature bank resident in HBM, 1 GPU (unsharded replica)")):
+                ("config5", 40, "f16", "HANDAL/HOPE scale: 40 objects x 162 templates, fp16 feature bank resident in HBM, 1 GPU (unsharded replica)"))
+                 if bank_dtype == "f32" or args.numerics == "split"]   # the fp16 (hi-plane-only) bank exists in split numerics only
+        def extra_config(key, n_obj, bank_dtype, text):
             tset_c = factory.TemplateSet(n_obj, args.templates, seed=300 + n_obj)
             model.set_numerics(args.numerics)
             model.testing_metric.bank_dtype = bank_dtype
@@ -221,11 +241,18 @@ def main():
             _lib.check_status()
             bank = model.match_banks[key]
             nbytes = sum(t.numel() * t.element_size() for t in (bank.hi, bank.lo, bank.features) if t is not None)
-            other_configs[key] = {"workload": text, "value": round(args.batch * n_steps / dtc, 2), "unit": "query-crops/sec", "steps": n_steps,
-                                  "ms_per_step": round(1e3 * dtc / n_steps, 3), "numerics": args.numerics, "bank_dtype": bank_dtype,
-                                  "matcher_bank_GB": round(nbytes / 1e9, 3), "onboarding_s_per_object": round(t_onboard / n_obj, 3)}
+            res = {"workload": text, "value": round(args.batch * n_steps / dtc, 2), "unit": "query-crops/sec", "steps": n_steps,
+                   "ms_per_step": round(1e3 * dtc / n_steps, 3), "numerics": args.numerics, "bank_dtype": bank_dtype,
+                   "matcher_bank_GB": round(nbytes / 1e9, 3), "onboarding_s_per_object": round(t_onboard / n_obj, 3)}
             del model.match_banks[key], model.template_datas[key], tset_c
             torch.cuda.empty_cache()
+            return res
+
+        for key, n_obj, bank_dtype, text in extra:
+            try:
+                other_configs[key] = extra_config(key, n_obj, bank_dtype, text)
+            except Exception as e:  # an extra measurement must never cost the headline line
+                other_configs[key] = {"error": repr(e)}
         model.testing_metric.bank_dtype = None
         model.template_datasets = {"syn": tset}
     if rank != 0:
@@ -257,7 +284,7 @@ def main():
                             "product all execute on the matrix core; frac_algorithmic = the 2IJK flops alone against the same "
                             "peak); the f32-input MFMA peak this mode replaces is 157.3. The kernel runs power-limited: 1.60 GHz "
                             "measured in-kernel against the 2.4 GHz the peak assumes, matrix pipe 86 % busy in its k loop "
-                            "(profiles/r02_probe_planes256_fc2.txt)",
+                            "(profiles/r02_probe_planes256.txt)",
                     "traffic": traffic}
     else:
         g = kern.get("gemm_kmajor", {})
@@ -293,6 +320,8 @@ def main():
                                                "disabled for the loop (check_asserts=False); the device status word is read once after it"},
         "roofline": roofline,
     }
+    if other_modes is not None:
+        out["other_modes"] = other_modes
     if other is not None:
         out["other_numerics"] = other
     if other_configs:

@@ -726,7 +726,18 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
     const int rounds_dp = (!PAR && (a.dp & 1) && n_t / slots_x > 1) ? n_t / slots_x - 1 : 0;
     const int n_dp = rounds_dp * slots_x;
     const long long U = (long long)(n_t - n_dp) * nstep;
-    const long long u0 = U * n / slots_x, u1 = U * (n + 1) / slots_x;
+    long long u0 = U * n / slots_x, u1 = U * (n + 1) / slots_x;
+    // PAR (fewer tiles than slots): S = floor(slots / tiles) slots per tile, each an equal share of the tile's k-steps; slot n holds
+    // part n % S of tile n / S, slots beyond S * tiles have no tile (they take strip fragments).  S = 1: whole tiles, no exchange.
+    const int par_S = PAR ? max(1, slots_x / max(n_t, 1)) : 1;
+    if (PAR) {
+        const int tile = n / par_S, part = n - tile * par_S;
+        u0 = u1 = 0;
+        if (tile < n_t) {
+            u0 = (long long)tile * nstep + nstep * part / par_S;
+            u1 = (long long)tile * nstep + nstep * (part + 1) / par_S;
+        }
+    }
     const int ta = (int)(u0 / nstep), sa = (int)(u0 % nstep);
     const int tb = (int)(u1 / nstep), sb = (int)(u1 % nstep);
     const int n_head = sb > 0 ? 1 : 0, n_rest = sa > 0 ? 1 : 0;
@@ -929,11 +940,8 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
                 // the published partial accumulators of the slots before it -- in slot order, nearest first: a fixed order, the
                 // result depends on the shape only -- and runs the epilogue.  (The serial hand-over above keeps a split tile's
                 // summation order but makes its slots wait for each other: with T < slots every tile is split and a launch
-                // would take as long as one whole tile.)  Predecessor m of this XCD holds units [U m / slots, U (m+1) / slots).
-                // (32-bit, no division: floor(U m / slots) > t  <=>  U m >= (t + 1) slots; U < 2^15 here)
-                const int tile_u0 = ta * nstep, U32 = (int)U;
-                int m_lo = n - 1;
-                while (m_lo > 0 && U32 * m_lo >= (tile_u0 + 1) * slots_x) --m_lo;   // first slot whose range reaches into this tile
+                // would take as long as one whole tile.)
+                const int m_lo = n - (par_S - 1);   // the S - 1 slots before this one hold the earlier k ranges of the tile
                 if (tid == 0) {
                     for (int m = n - 1; m >= m_lo; --m) {
                         int spins = 0;

@@ -141,9 +141,13 @@ class GigaPose(_Base):
         for idx in range(len(template_dataset)):
             item = template_dataset[idx]
             templates = item.rgb.to(dev)
-            if self.template_shard is not None:  # AE features only for this rank's template slice
+            if self.template_shard is not None:
+                # This rank KEEPS templates [lo, hi) but computes the features of all of them, in the chunks an unsharded model
+                # uses: in split numerics a feature's round-off depends on the GEMM shapes its chunk selects (tile vs ragged strip,
+                # serial vs parallel split-K), and the sharded path promises results equal to the unsharded one bit for bit
+                # (tests/test_gpu_world2.py).  Onboarding is one-off and outside every timed region (0.13 s per object).
                 lo, hi = shard_bounds(templates.shape[0], world, rank)
-            cols["ae_features"].append(self.ae_net(templates[lo:hi]))
+            cols["ae_features"].append(self.ae_net(templates)[lo:hi].contiguous())
             cols["ist_features"].append(self.ist_net.forward_by_chunk(templates))
             for n in ["mask", "K", "M", "poses"]:
                 cols[n].append(getattr(item, n).to(dev))

@@ -5,8 +5,8 @@ Not present in the reference (its inference is single-GPU): rank r ke
   1. runs the ViT on its own B crops, all-gathers the matcher-normalised query features, patch
      masks and labels                                             (exchange #1, RCCL all-gather)
   2. matches all W*B crops against its shard (gp_match_tiles) and takes a local top-k
-  3. all-gathers the k per-shard candidates per crop -- global template id, score and the 256-patch
-     record (idx u8, score f32, mask f32), packed into one byte row          (exchange #2)
+  3. sends every other rank the k per-shard candidates of THAT rank's crops -- global template id, score and
+     the 256-patch record (idx u8, score f32, mask f32), packed into one byte row   (exchange #2, RCCL all-to-all)
   4. merges the W*k candidates of its own crops: "higher score, then lower global id" -- exactly
      gp_topk's order over all N templates, so results equal the unsharded path bit-for-bit
   5. continues locally (IST regressor, RANSAC, recovery) with the small replicated banks.
@@ -36,17 +36,59 @@ def shard_bounds(n_templates, world, rank):
     return lo, hi
 
 
+def _needs_host_staging(t, group):
+    """gloo moves host memory only: device rows are staged through the host (the world-size-2 GPU test runs two ranks on ONE
+    MI355X, which RCCL refuses -- "duplicate GPU" -- so that test drives the real kernels over gloo; RCCL takes device tensors)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+class _StagedWork:
+    """Handle of a host-staged collective: wait() finishes it and copies the result to the device buffer."""
+
+    def __init__(self, work, host, out):
+        self.work, self.host, self.out = work, host, out
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        self.out.copy_(self.host)
+
+
 def all_gather_rows(rows, group=None, async_op=False):
     """ONE collective: every rank contributes the same number of equal-length u8 rows (n, L); returns ((W*n, L) in rank
-    order, work handle or None).  all_gather_into_tensor = a single RCCL ncclAllGather over the flat buffer (payloads
-    here are a few MB at most: latency-bound, one launch instead of one per tensor)."""
+    order, work handle or None).  all_gather_into_tensor = a single RCCL ncclAllGather over the flat buffer (one launch
+    instead of one per tensor)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1 and not _always_collective():
         return rows, None
     rows = rows.contiguous()
     out = torch.empty((world * rows.shape[0],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    if _needs_host_staging(rows, group):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        work = _StagedWork(dist.all_gather_into_tensor(host, rows.cpu(), group=group, async_op=async_op), host, out)
+        if not async_op:
+            work.wait()
+        return out, (work if async_op else None)
     work = dist.all_gather_into_tensor(out, rows, group=group, async_op=async_op)
     return out, (work if async_op else None)
+
+
+def all_to_all_rows(rows, group=None):
+    """rows (W * n, ...): chunk r (n rows) goes to rank r.  Returns (W, n, ...): chunk s = what rank s sent to this rank.
+    RCCL: one all_to_all_single (each rank receives only what it will use); gloo has no all-to-all, so there (CPU tests, and
+    the two-ranks-on-one-GPU test) the same result is cut out of an all-gather."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    n = rows.shape[0] // world
+    if world == 1 and not _always_collective():
+        return rows.reshape((1, n) + tuple(rows.shape[1:]))
+    rows = rows.contiguous()
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty_like(rows)
+        dist.all_to_all_single(out, rows, group=group)
+        return out.reshape((world, n) + tuple(rows.shape[1:]))
+    rank = dist.get_rank(group)
+    allrows, _ = all_gather_rows(rows, group)                                        # (W * W*n, ...)
+    return allrows.reshape((world, world, n) + tuple(rows.shape[1:]))[:, rank].contiguous()
 
 
 def all_gather_cat(t, group=None):
@@ -56,25 +98,36 @@ def all_gather_cat(t, group=None):
     return all_gather_rows(t, group)[0]
 
 
+def _align16(n):
+    return (n + 15) // 16 * 16
+
+
 def pack_query(q, qmask, labels0):
     """Exchange #1 payload, one byte row per crop: matcher-normalised features (f32 (B,C,256), or the f16 hi / lo planes
-    (B,256,Cp) of the split numerics) | patch mask f32[256] | label i32.  Returns (rows (B, L) u8, layout)."""
+    (B,256,Cp) of the split numerics) | patch mask f32[256] | label i32, every field at a 16-byte aligned offset of a
+    preallocated row (one copy per field, no concatenation temporaries): 1 MB per crop at C = 1024.
+    Returns (rows (B, L) u8, layout)."""
     B = qmask.shape[0]
     feats = list(q) if isinstance(q, (tuple, list)) else [q]
-    parts = [f.contiguous().view(torch.uint8).reshape(B, -1) for f in feats]
-    layout = [(tuple(f.shape[1:]), f.dtype, p.shape[1]) for f, p in zip(feats, parts)]
-    parts += [qmask.contiguous().view(torch.uint8).reshape(B, 4 * P), labels0.to(torch.int32).contiguous().view(torch.uint8).reshape(B, 4)]
-    return torch.cat(parts, dim=1), layout
+    fields = [f.contiguous() for f in feats] + [qmask.contiguous().float(), labels0.to(torch.int32).contiguous()]
+    layout, off = [], 0
+    for f in fields:
+        nbytes = f[0].numel() * f.element_size() if B else 0
+        layout.append((tuple(f.shape[1:]), f.dtype, off, nbytes))
+        off = _align16(off + nbytes)
+    rows = torch.empty(B, off, dtype=torch.uint8, device=qmask.device)
+    for f, (_, _, o, nbytes) in zip(fields, layout):
+        rows[:, o:o + nbytes] = f.view(torch.uint8).reshape(B, nbytes)
+    return rows, layout
 
 
 def unpack_query(rows, layout):
-    """Inverse of pack_query for (n, L) u8 rows: (features or (hi, lo)), qmask (n,256) f32, labels (n,) i32."""
-    n, o, feats = rows.shape[0], 0, []
-    for shape, dtype, nbytes in layout:
-        feats.append(rows[:, o:o + nbytes].contiguous().view(dtype).reshape(n, *shape))
-        o += nbytes
-    qmask = rows[:, o:o + 4 * P].contiguous().view(torch.float32).reshape(n, P)
-    labels = rows[:, o + 4 * P:o + 4 * P + 4].contiguous().view(torch.int32).reshape(n)
+    """Inverse of pack_query for (n, L) u8 rows: (features or (hi, lo)), qmask (n,256) f32, labels (n,) i32 (contiguous
+    copies: the kernels take dense arrays)."""
+    n, out = rows.shape[0], []
+    for shape, dtype, o, nbytes in layout:
+        out.append(rows[:, o:o + nbytes].contiguous().view(dtype).reshape(n, *shape))
+    feats, qmask, labels = out[:-2], out[-2], out[-1]
     return (feats[0] if len(feats) == 1 else tuple(feats)), qmask, labels
 
 
@@ -111,15 +164,13 @@ def merge_topk(ids, scores, k):
 
 
 def exchange_and_merge(local_rows, n_own, k, rank, group=None):
-    """local_rows (W*B, k, REC_BYTES) u8: this rank's candidates for ALL crops (crop order = rank-major).
+    """local_rows (W*B, k, REC_BYTES) u8: this rank's candidates for ALL crops (crop order = rank-major).  Exchange #2 is an
+    all-to-all: rank r receives, from every rank, only the candidates of ITS OWN B crops (W * B * k records instead of the
+    W * W * B * k an all-gather delivers: 5.9 MB instead of 47 MB per rank at W = 8, B = 64).
     Returns merged ids (B,k) i64, scores (B,k), rec_idx/rec_score/rec_mask (B,k,256) for OWN crops."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world > 1 or _always_collective():
-        allrows, _ = all_gather_rows(local_rows, group)                               # (W * W*B, k, REC), one collective
-        allrows = allrows.reshape(world, -1, k, REC_BYTES)
-        mine = allrows[:, rank * n_own:(rank + 1) * n_own].permute(1, 0, 2, 3).reshape(n_own, world * k, REC_BYTES)
-    else:
-        mine = local_rows
+    got = all_to_all_rows(local_rows, group)                                          # (W, B, k, REC): chunk s from rank s
+    world = got.shape[0]
+    mine = got.permute(1, 0, 2, 3).reshape(n_own, world * k, REC_BYTES)
     ids, sc, ridx, rsc, rma = unpack_candidates(mine)
     pos = merge_topk(ids, sc, k)
     pos3 = pos[:, :, None].expand(-1, -1, P)

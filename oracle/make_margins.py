@@ -8,8 +8,10 @@ What is stored, all from GigaPose.eval_retrieval of the reference evaluated in f
   sim_avg (B,N) f64                   the tensor torch.topk ranks (matching.py:274-279), captured at the topk call
   tile_min_margin (B,N) f32           smallest decision margin inside each (detection, template) tile (see below)
   top_ids (B,K) i16                   the K = 12 best templates per detection by (sim_avg desc, id asc)
-  for those K tiles, per patch (matching.py:233-272 restated in numpy float64 on the reference's own float64 features;
-  the restatement is checked against the reference's outputs on its k winners before anything is written):
+  tile_b, tile_n (T,) i16             the tiles whose per-patch records are stored: those K per detection + every tile with a
+                                      decision margin < 4e-6 whose sim_avg is within 0.02 of the detection's k-th best
+  for those T tiles, per patch (T,256) (matching.py:233-272 restated in numpy float64 on the reference's own float64
+  features; the restatement is checked against the reference's outputs on its k winners before anything is written):
     idx_t2s u8                        row argmax of the thresholded similarity, first max (the reference's idx_tar2src)
     ridx_t2s / idx2_t2s u8            argmax and runner-up of the raw (masked, not thresholded) row
     row_margin f32                    top1 - top2 of the raw row, clipped to CLIP
@@ -19,7 +21,7 @@ What is stored, all from GigaPose.eval_retrieval of the reference evaluated in f
     valid u8                          mask_all (matching.py:268)
   relScale / relInplane f64 (B,k,P[,2]) and the hypothesis tensors of the run (sorted order, as the goldens)
 The same capture of the reference's own float32 run is written next to it (<which>_ref32_tiles.npz: valid / idx of the
-K stored tiles and sim_avg of ALL tiles, via LocalSimilarity.test with k = N) -- the CPU test of the explanation checker uses it as
+T stored tiles and sim_avg of ALL tiles, via LocalSimilarity.test with k = N) -- the CPU test of the explanation checker uses it as
 the "other implementation", which also measures what epsilon the reference's own rounding needs.
 """
 import os
@@ -37,6 +39,8 @@ from gigapose_amd import synthetic as syn  # noqa: E402
 P = 256
 CLIP = 1e-3
 K_STORE = 12
+EXTRA_MARGIN = 4e-6
+EXTRA_WINDOW = 0.02
 SIM_THR = 0.5
 PATCH_THR = 3.0
 
@@ -177,8 +181,11 @@ def records_phase(which, scratch="/tmp"):
     assert sim_avg.shape == (B, N) and sim_avg.dtype == np.float64
     K = min(K_STORE, N)
     order = np.lexsort((np.arange(N)[None, :].repeat(B, 0), -sim_avg), axis=1)[:, :K]      # (score desc, id asc)
-    rec = {n: np.zeros((B, K, P), np.uint8) for n in NAMES_U8}
-    rec.update({n: np.zeros((B, K, P), np.float32) for n in NAMES_F32})
+    kth = np.sort(sim_avg, axis=1)[:, -min(k, N)]                                           # the k-th best sim_avg per detection
+    # Tiles whose per-patch records are stored: the K best templates of every detection, plus every tile that holds a near-tied
+    # decision (margin < EXTRA_MARGIN) and whose sim_avg is within EXTRA_WINDOW of the k-th best -- a tie there can move a few
+    # patches (one column decision gates every query patch matched to it) and lift the template into another run's top k.
+    tile_b, tile_n, recs = [], [], {n: [] for n in NAMES_U8 + NAMES_F32}
     tmm = np.zeros((B, N), np.float32)
     my_avg = np.zeros((B, N))
     for b in range(B):
@@ -187,30 +194,34 @@ def records_phase(which, scratch="/tmp"):
             r = tile_records(tq[b], bank[o, n], qmask[b], bmask[o, n])
             my_avg[b, n] = r["sim_avg"]
             tmm[b, n] = tile_min_margin(r)
-            j = np.flatnonzero(order[b] == n)
-            if len(j):
+            if n in order[b] or (tmm[b, n] < EXTRA_MARGIN and sim_avg[b, n] >= kth[b] - EXTRA_WINDOW):
+                tile_b.append(b)
+                tile_n.append(n)
                 for nm in NAMES_U8:
-                    rec[nm][b, j[0]] = r[nm]
+                    recs[nm].append(r[nm].astype(np.uint8))
                 for nm in NAMES_F32:
-                    rec[nm][b, j[0]] = r[nm] if nm.endswith("_max") else np.clip(r[nm], -CLIP, CLIP)
+                    recs[nm].append((r[nm] if nm.endswith("_max") else np.clip(r[nm], -CLIP, CLIP)).astype(np.float32))
         if b % 16 == 0:
             print(f"{which}: tiles of detection {b} done", flush=True)
+    tile_b, tile_n = np.asarray(tile_b, np.int16), np.asarray(tile_n, np.int16)
+    rec = {nm: np.stack(v) for nm, v in recs.items()}
+    print(f"{which}: {len(tile_b)} tiles stored ({B * K} = the {K} best per detection + {len(tile_b) - B * K} near-tied ones near the top-{k} boundary)")
     # the restatement must BE the reference: sim_avg of every tile, and the correspondences of the k winners
     err = np.abs(my_avg - sim_avg).max()
     print(f"{which}: numpy float64 restatement vs the reference's float64 sim_avg: max |diff| {err:.3e}")
     assert err < 1e-12, err
     ids64 = a64["id_src"].astype(np.int64)
+    where = {(int(b), int(n)): i for i, (b, n) in enumerate(zip(tile_b, tile_n))}
     for b in range(B):
         for j in range(k):
-            jj = np.flatnonzero(order[b] == ids64[b, j])
-            assert len(jj), "winner outside the stored tiles"
-            valid = rec["valid"][b, jj[0]].astype(bool)
-            s = rec["idx_t2s"][b, jj[0]].astype(np.int64)
+            i = where[(b, int(ids64[b, j]))]
+            valid = rec["valid"][i].astype(bool)
+            s = rec["idx_t2s"][i].astype(np.int64)
             src = np.where(valid[:, None], np.stack([s % 16, s // 16], -1), -1)
             tar = np.where(valid[:, None], np.stack([np.arange(P) % 16, np.arange(P) // 16], -1), -1)
             assert (src == a64["src_pts"][b, j]).all() and (tar == a64["tar_pts"][b, j]).all(), (b, j)
     print(f"{which}: restated tile records reproduce the reference's float64 correspondences of all {B * k} winners")
-    out = dict(sim_avg=sim_avg, tile_min_margin=tmm, top_ids=order.astype(np.int16), clip=CLIP, **rec,
+    out = dict(sim_avg=sim_avg, tile_min_margin=tmm, top_ids=order.astype(np.int16), tile_b=tile_b, tile_n=tile_n, clip=CLIP, **rec,
                id_src=a64["id_src"], src_pts=a64["src_pts"], tar_pts=a64["tar_pts"], all_scores=a64["all_scores"],
                idx_failed=a64["idx_failed"], score_src=a64["score_src"], relScale=a64["relScale"].astype(np.float64),
                relInplane=a64["relInplane"].astype(np.float64), M=a64["M"].astype(np.float64),
@@ -231,7 +242,8 @@ def records_phase(which, scratch="/tmp"):
     g32 = np.load(os.path.join(mg.GOLD, which + ".npz"))
     assert (r32["a_id_src"] == g32["id_src"]).all() and (r32["a_src_pts"] == g32["src_pts"]).all(), "the float32 re-run is not the golden"
     path = os.path.join(mg.GOLD, which + "_ref32_tiles.npz")
-    np.savez_compressed(path, valid=np.packbits(valid32[bi, order], axis=-1), idx=idx32[bi, order], sim_avg=r32["sim_avg"].astype(np.float32))
+    tb, tn = tile_b.astype(np.int64), tile_n.astype(np.int64)
+    np.savez_compressed(path, valid=np.packbits(valid32[tb, tn], axis=-1), idx=idx32[tb, tn], sim_avg=r32["sim_avg"].astype(np.float32))
     print(which, "ref32 tiles written:", os.path.getsize(path) / 1e6, "MB", flush=True)
 
 

@@ -59,7 +59,7 @@ def pose_rel_err(a, b):
 
 def explain(m, ours, eps_sim=2e-6, eps_px=2e-3, tol_ist=1e-4, tol_pose=1e-4, verbose=False):
     """m: dict of the margins golden.  ours: dict with
-         tiles_valid (B,K,P) bool, tiles_idx (B,K,P) int   -- our records of the K tiles the golden stores (m["top_ids"] order)
+         tiles_valid (T,P) bool, tiles_idx (T,P) int       -- our records of the T tiles the golden stores (m["tile_b"], m["tile_n"])
          sim_avg (B,N)                                      -- our sim_avg of every tile
          id_src (B,k), src_pts / tar_pts (B,k,P,2), inliers (B,k) int, idx_failed (B,k), relScale (B,k,P), relInplane (B,k,P,2),
          M (B,k,3,3), poses (B,k,4,4)                       -- final hypotheses (sorted as eval_retrieval returns them)
@@ -72,7 +72,10 @@ def explain(m, ours, eps_sim=2e-6, eps_px=2e-3, tol_ist=1e-4, tol_pose=1e-4, ver
     A_f = m["sim_avg"]
     A_o = ours["sim_avg"].astype(np.float64)
     N = A_f.shape[1]
-    rep = dict(unexplained=[], tiles=B * K, tiles_with_flips=0, patch_flips=0, set_diff=0, order_diff=0, hyp=B * k, hyp_common=0,
+    tiles_of = [[] for _ in range(B)]
+    for i, b_ in enumerate(m["tile_b"]):
+        tiles_of[int(b_)].append(i)
+    rep = dict(unexplained=[], tiles=len(m["tile_b"]), tiles_with_flips=0, patch_flips=0, set_diff=0, order_diff=0, hyp=B * k, hyp_common=0,
                hyp_same_corr=0, hyp_same_all=0, corr_flip_hyp=0, inlier_diff=0, winner_diff=0, max_avg_dev=0.0, max_ist_dev=0.0,
                max_M_err=0.0, max_t_err=0.0, max_r_err=0.0, unstored_dev=0, notes=[])
     bad = rep["unexplained"].append
@@ -81,14 +84,14 @@ def explain(m, ours, eps_sim=2e-6, eps_px=2e-3, tol_ist=1e-4, tol_pose=1e-4, ver
     for b in range(B):
         E = {}            # template id -> float64 similarity summed over OUR valid patches / 256
         flips = {}        # template id -> number of (explained) patch differences
-        for j in range(K):
-            n = int(top[b, j])
-            vf, vo = m["valid"][b, j].astype(bool), ours["tiles_valid"][b, j].astype(bool)
-            sf, rsf, s2 = m["idx_t2s"][b, j].astype(np.int64), m["ridx_t2s"][b, j].astype(np.int64), m["idx2_t2s"][b, j].astype(np.int64)
-            so = ours["tiles_idx"][b, j].astype(np.int64)
-            f_row = m["row_margin"][b, j] < eps_sim
-            f_rthr = np.abs(m["row_thr"][b, j]) < eps_sim
-            f_col = (m["col_margin"][b, j] < eps_sim) | (np.abs(m["col_thr"][b, j]) < eps_sim)
+        for j in tiles_of[b]:
+            n = int(m["tile_n"][j])
+            vf, vo = m["valid"][j].astype(bool), ours["tiles_valid"][j].astype(bool)
+            sf, rsf, s2 = m["idx_t2s"][j].astype(np.int64), m["ridx_t2s"][j].astype(np.int64), m["idx2_t2s"][j].astype(np.int64)
+            so = ours["tiles_idx"][j].astype(np.int64)
+            f_row = m["row_margin"][j] < eps_sim
+            f_rthr = np.abs(m["row_thr"][j]) < eps_sim
+            f_col = (m["col_margin"][j] < eps_sim) | (np.abs(m["col_thr"][j]) < eps_sim)
             differ = (vo != vf) | (vo & vf & (so != sf))
             nd = int(differ.sum())
             flips[n] = nd
@@ -100,13 +103,13 @@ def explain(m, ours, eps_sim=2e-6, eps_px=2e-3, tol_ist=1e-4, tol_pose=1e-4, ver
                 if vo[t]:
                     fr = fr or f_col[so[t]]
                     if so[t] != rsf[t] and not (f_row[t] and so[t] == s2[t]):
-                        bad(f"det {b} template {n} patch {t}: matched to {so[t]}, float64 best {rsf[t]} / runner-up {s2[t]} (row margin {m['row_margin'][b, j, t]:.2e})")
+                        bad(f"det {b} template {n} patch {t}: matched to {so[t]}, float64 best {rsf[t]} / runner-up {s2[t]} (row margin {m['row_margin'][j, t]:.2e})")
                         continue
                 if not fr:
                     bad(f"det {b} template {n} patch {t}: valid {bool(vo[t])} vs float64 {bool(vf[t])}, match {so[t]} vs {sf[t]}; no decision margin "
-                        f"below {eps_sim:g} (row {m['row_margin'][b, j, t]:.2e}, thr {m['row_thr'][b, j, t]:.2e}, col {m['col_margin'][b, j, rsf[t]]:.2e})")
-            rm = m["row_max"][b, j].astype(np.float64)
-            simf = np.where(so == rsf, rm, np.where(so == s2, rm - m["row_margin"][b, j].astype(np.float64), np.nan))
+                        f"below {eps_sim:g} (row {m['row_margin'][j, t]:.2e}, thr {m['row_thr'][j, t]:.2e}, col {m['col_margin'][j, rsf[t]]:.2e})")
+            rm = m["row_max"][j].astype(np.float64)
+            simf = np.where(so == rsf, rm, np.where(so == s2, rm - m["row_margin"][j].astype(np.float64), np.nan))
             e = np.where(vo, simf, 0.0).sum() / P
             E[n] = e
             dev = abs(A_o[b, n] - e)
@@ -116,7 +119,7 @@ def explain(m, ours, eps_sim=2e-6, eps_px=2e-3, tol_ist=1e-4, tol_pose=1e-4, ver
                 bad(f"det {b} template {n}: sim_avg {A_o[b, n]:.8f} vs the float64 similarities over our valid patches {e:.8f}")
         # tiles the golden does not store: no flips are visible, so our sim_avg must be the float64 one unless the tile holds a tie
         stored = np.zeros(N, bool)
-        stored[top[b]] = True
+        stored[[int(m["tile_n"][j]) for j in tiles_of[b]]] = True
         dev = np.abs(A_o[b] - A_f[b])
         loose = (~stored) & (dev >= eps_sim)
         rep["unstored_dev"] += int(loose.sum())
@@ -134,7 +137,7 @@ def explain(m, ours, eps_sim=2e-6, eps_px=2e-3, tol_ist=1e-4, tol_pose=1e-4, ver
             bad(f"det {b}: hypotheses {sorted(so_set)} are not the top-{k} of our own sim_avg {sorted(own_rank)}")
         for n in mine:
             if n not in E:
-                bad(f"det {b}: template {n} in our top-{k} is outside the float64 run's top-{K}")
+                bad(f"det {b}: template {n} in our top-{k} is not among the tiles the golden stores (float64 top-{K} + near-tied tiles near the boundary)")
         for n in [x for x in mine if x in E]:
             for mm in [x for x in E if x not in so_set]:
                 if not (E[n] > E[mm] - 2 * eps_sim):
@@ -170,24 +173,32 @@ def explain(m, ours, eps_sim=2e-6, eps_px=2e-3, tol_ist=1e-4, tol_pose=1e-4, ver
                 if c_o != 0 or np.abs(M_o - np.eye(3)).max() > 0:
                     bad(f"det {b} template {n}: no correspondences but count {c_o}")
                 continue
-            merr = np.abs(r["M"] - M_o[None]).max(axis=(1, 2)) / np.abs(r["M"]).max(axis=(1, 2))
-            i_o, w = int(np.argmin(merr)), r["winner"]
-            if merr[i_o] > 1e-3:
-                bad(f"det {b} template {n}: M is no float64 candidate's (nearest differs by {merr[i_o]:.2e})")
-                continue
+            # The float64 run's own winner and count are read from ITS outputs, not from this restatement: many-to-one matches put
+            # correspondences at exactly one patch (14 px) from the proposing one, so in ANY precision some errors sit within an ulp of
+            # the threshold and the count depends on the operation order inside torch's einsum (ransac.py:93-95).
+            def nearest(Mx):
+                e = np.abs(r["M"] - Mx[None]).max(axis=(1, 2)) / np.abs(r["M"]).max(axis=(1, 2))
+                i = int(np.argmin(e))
+                return i, float(e[i])
+            (i_o, e_o), (w, e_w) = nearest(M_o), nearest(m["M"][b, jf])
+            c_w = int(round(float(m["all_scores"][b, jf]) * P))
             cf, fg = r["counts"], r["fragile"]
+            assert e_w < 1e-9 and abs(c_w - cf[w]) <= fg[w], f"det {b} template {n}: the RANSAC restatement does not reproduce the float64 golden"
+            if e_o > 1e-3:
+                bad(f"det {b} template {n}: M is no float64 candidate's (nearest differs by {e_o:.2e})")
+                continue
             if i_o != w:
                 rep["winner_diff"] += 1
                 if not (fg[i_o] + fg[w] > 0 and cf[i_o] + fg[i_o] >= cf[w] - fg[w]):
                     bad(f"det {b} template {n}: RANSAC winner {i_o} ({cf[i_o]} inliers, {fg[i_o]} within {eps_px:g} px of 14) vs float64 winner {w} ({cf[w]}, {fg[w]})")
-            if c_o != cf[w]:
+            if c_o != c_w:
                 rep["inlier_diff"] += 1
             if abs(c_o - cf[i_o]) > fg[i_o]:
                 bad(f"det {b} template {n}: {c_o} inliers vs float64 {cf[i_o]} for the same candidate with {fg[i_o]} correspondences within {eps_px:g} px of 14")
-            if i_o == w and c_o == cf[w]:
+            if i_o == w and c_o == c_w:
                 rep["hyp_same_all"] += 1
-                if bool(ours["idx_failed"][b, jo]) != r["failed"]:
-                    bad(f"det {b} template {n}: failed flag {bool(ours['idx_failed'][b, jo])} vs {r['failed']}")
+                if bool(ours["idx_failed"][b, jo]) != bool(m["idx_failed"][b, jf]):
+                    bad(f"det {b} template {n}: failed flag {bool(ours['idx_failed'][b, jo])} vs {bool(m['idx_failed'][b, jf])}")
                 me = float(np.abs(M_o - m["M"][b, jf]).max() / np.abs(m["M"][b, jf]).max())
                 te, re_ = pose_rel_err(ours["poses"][b, jo].astype(np.float64), m["all_poses"][b, jf])
                 rep["max_M_err"], rep["max_t_err"], rep["max_r_err"] = max(rep["max_M_err"], me), max(rep["max_t_err"], float(te)), max(rep["max_r_err"], float(re_))

@@ -156,90 +156,79 @@ def build_e2e_model(cfg, numerics):
     return model, make_batch(q), q
 
 
-def disagreement(a, b):
-    """Detection level: detections whose top-k template SET / ORDER differ.  Hypothesis level, over the hypotheses both runs
-    have (aligned by template id, so that one swapped pair of hypotheses is not counted as 2 x 512 differing entries):
-    differing correspondence entries (src_pts / tar_pts) and differing inlier counts, out of `common` shared hypotheses."""
-    ida, idb = a["id_src"].astype(np.int64), b["id_src"].astype(np.int64)
-    out = dict(set=int((np.sort(ida, 1) != np.sort(idb, 1)).any(1).sum()), order=int((ida != idb).any(1).sum()), common=0, src_pts=0, tar_pts=0, inliers=0)
-    for d in range(len(ida)):
-        for ja, t in enumerate(ida[d]):
-            jb = np.flatnonzero(idb[d] == t)
-            if len(jb):
-                out["common"] += 1
-                out["src_pts"] += int((a["src_pts"][d, ja] != b["src_pts"][d, jb[0]]).sum())
-                out["tar_pts"] += int((a["tar_pts"][d, ja] != b["tar_pts"][d, jb[0]]).sum())
-                out["inliers"] += int(a["all_scores"][d, ja] != b["all_scores"][d, jb[0]])
-    return out
+EPS_SIM = 2e-6   # similarity margin below which a float64 decision counts as a tie.  Yardstick: the reference's OWN float32 run needs
+                 # 1e-6 to have its differences from its float64 run explained (tests/test_parity_explain.py; 5e-7 leaves one)
+EPS_PX = 1e-3    # distance to RANSAC's 14 px threshold below which an inlier decision counts as a tie (the exact 14.000 px ties of
+                 # many-to-one matches + the IST regression's f32 round-off times a 224 px lever arm)
+
+
+def ours_for_checker(model, p, tiles, m):
+    """Our records in the layout tests/parity_explain.py expects: the K tiles per detection the margins golden stores, our sim_avg
+    of every tile, and the final hypotheses."""
+    idx, sc, ma, avg = [t.cpu().numpy() for t in tiles]
+    tb, tn = m["tile_b"].astype(np.int64), m["tile_n"].astype(np.int64)
+    return dict(tiles_valid=ma[tb, tn] > 0, tiles_idx=idx[tb, tn], sim_avg=avg, id_src=p["id_src"].astype(np.int64),
+                src_pts=p["src_pts"], tar_pts=p["tar_pts"], inliers=np.rint(p["scores"] * 256).astype(np.int64), idx_failed=p["idx_failed"],
+                relScale=p["relScale"], relInplane=p["relInplane"], M=p["M"], poses=p["pred_poses"])
 
 
 @pytest.mark.parametrize("numerics", ["chain", "split"])
 @pytest.mark.parametrize("which", ["e2e_cfg2", "e2e_cfg3"])
 def test_eval_retrieval_at_benchmark_size_vs_reference(golden_dir, which, numerics):
-    """End to end through a 24-layer ViT-L at the benchmark size.  Two goldens of the UNMODIFIED reference on the same
-    inputs: its float32 run (`<which>.npz`) and the same code in float64 (`<which>_f64.npz`, make_goldens.py: gen_e2e_f64).
-    The reference's own f32 run does not reproduce its exact-arithmetic evaluation at this depth (config 2: 2681 of
-    163 840 correspondence entries, 4 of 64 hypothesis orders, 7 inlier counts differ -- f32 rounding through 24 random-
-    init transformer blocks moves near-tied argmaxes), so "equal to the f32 golden" is not a property ANY second f32
-    implementation can have.  The bar here: measured against the float64 reference, this implementation must be no
-    further off than the reference's own float32 run is (factor 1.25 + a small absolute slack for counting noise), and
-    wherever a hypothesis' discrete choices agree with the float64 reference its pose must be within the north-star's
-    1e-4.  Feature-level bit-exactness at this size is asserted separately above (matcher on identical inputs: 0
-    differences in both numerics modes)."""
-    from test_gpu_e2e import pose_rel_err
+    """End to end through a 24-layer ViT-L at the benchmark size: EQUAL to the reference evaluated in float64, or the difference
+    is an explained float64 tie -- no counting slack.
+
+    The reference's own float32 run does not reproduce its exact-arithmetic evaluation at this depth (config 2: 4 of 64 hypothesis
+    orders and 7 of 320 inlier counts / RANSAC winners differ: rounding moves near-tied decisions), so equality with the float32
+    golden is not a property any second float32 implementation can have.  `<which>_margins.npz` (oracle/make_margins.py) therefore
+    stores, from the unmodified reference run in float64, every decision of the path with its float64 margin: sim_avg of all
+    B x N tiles, and for the 12 best templates of every detection (+ every near-tied tile near the top-k boundary) the per-patch row / column argmax, runner-up, margins and
+    distances to the 0.5 threshold, plus the IST regressions that feed RANSAC.  tests/parity_explain.py then requires of OUR run:
+    every patch whose (valid, matched patch) differs depends on a float64 decision with margin < EPS_SIM; our sim_avg equals
+    the float64 similarities over our valid patches within EPS_SIM; our top-k is consistent with those; with identical
+    correspondences the inlier count / RANSAC winner equal the float64 run's unless a correspondence sits within EPS_PX of the
+    14 px threshold; and on identical discrete paths M / translation / rotation agree to the north-star's 1e-4.  The same
+    checker, fed the reference's own float32 goldens, is a CPU test (tests/test_parity_explain.py): the yardstick."""
+    import parity_explain as px
 
     g32 = np.load(os.path.join(golden_dir, which + ".npz"))
-    f64_path = os.path.join(golden_dir, which + "_f64.npz")
-    if not os.path.exists(f64_path):
-        pytest.skip(f"{which}_f64.npz not generated")
-    g64 = np.load(f64_path)
+    f64_path, mar_path = os.path.join(golden_dir, which + "_f64.npz"), os.path.join(golden_dir, which + "_margins.npz")
+    if not os.path.exists(mar_path):
+        pytest.skip(f"{which}_margins.npz not generated")
+    m = dict(np.load(mar_path))
     cfg = E2E_CONFIGS[which]
     model, batch, q = build_e2e_model(cfg, numerics)
+    cap = {}
+    match_tiles = model.testing_metric.match_tiles
+
+    def spy(*a, **kw):
+        cap["tiles"] = match_tiles(*a, **kw)
+        return cap["tiles"]
+
+    model.testing_metric.match_tiles = spy
     assert model.test_step(batch, 0) == 0
     p = {n: v.cpu().numpy() for n, v in model.last_predictions.tensors.items()}
-    p["all_scores"] = p["scores"]
     np.testing.assert_allclose(model.template_datas["syn"].ae_features[0, 0].cpu().numpy(), g32["tmpl_ae_feat_sample"], rtol=0, atol=3e-5)
-    if "feat_f64_templates01_crops01" in g64.files:   # unit-norm ViT-L features of 2 templates + 2 crops (every 4th channel) in float64
+    if os.path.exists(f64_path) and "feat_f64_templates01_crops01" in np.load(f64_path).files:
+        # unit-norm ViT-L features of 2 templates + 2 crops (every 4th channel) against the float64 forward, in a batch of 64 so
+        # that the forward takes the plane path the benchmark times
         from test_gpu_e2e import e2e_inputs
 
+        g64 = np.load(f64_path)
         items, qq = e2e_inputs(cfg["seed"], cfg["O"], cfg["N"], cfg["B"])
-        x = torch.cat([items[0].rgb[:2], torch.from_numpy(qq["tar_img"][:2])]).to(DEV)
-        mine = model.ae_net(x).cpu().numpy()[:, ::4].astype(np.float64)
+        x = torch.cat([items[0].rgb[:2], torch.from_numpy(qq["tar_img"][:2]), items[0].rgb[2:62]]).to(DEV)
+        mine = model.ae_net(x).cpu().numpy()[:4, ::4].astype(np.float64)
         t64, r32 = g64["feat_f64_templates01_crops01"], g64["feat_ref32_templates01_crops01"].astype(np.float64)
         e_m, e_r = np.abs(mine - t64), np.abs(r32 - t64)
-        print(f"{which} [{numerics}] ViT-L unit-norm features vs the float64 forward (feature rms {np.sqrt((t64 ** 2).mean()):.3e}): ours max {e_m.max():.2e} rms "
-              f"{np.sqrt((e_m ** 2).mean()):.2e} | the reference's f32 forward max {e_r.max():.2e} rms {np.sqrt((e_r ** 2).mean()):.2e}")
+        print(f"{which} [{numerics}] ViT-L unit-norm features (batch of 64) vs the float64 forward (feature rms {np.sqrt((t64 ** 2).mean()):.3e}): ours max "
+              f"{e_m.max():.2e} rms {np.sqrt((e_m ** 2).mean()):.2e} | the reference's f32 forward max {e_r.max():.2e} rms {np.sqrt((e_r ** 2).mean()):.2e}")
         assert e_m.max() < 2e-6
-    d_ref, d_ours, d_32 = disagreement(g32, g64), disagreement(p, g64), disagreement(p, g32)
-    n = dict(set=len(p["id_src"]), order=len(p["id_src"]), src_pts=p["src_pts"].size, tar_pts=p["tar_pts"].size, inliers=p["scores"].size)
-    print(f"{which} [{numerics}] disagreement with the reference evaluated in float64 -- ours: {d_ours} | the reference's own f32 run: {d_ref} "
-          f"| (ours vs the f32 golden: {d_32}) out of {n}")
-    # detection-level events are few (a handful of 64): small-number statistics, bounded with an absolute slack; the
-    # hypothesis-level counts (thousands of near-tied argmaxes) must be within 1.25 x the reference's own
-    for key in ("set", "order", "inliers"):
-        assert d_ours[key] <= 1.25 * d_ref[key] + 6, f"{key}: {d_ours[key]} vs the reference's own {d_ref[key]}"
-    for key in ("src_pts", "tar_pts"):
-        assert d_ours[key] <= 1.25 * d_ref[key] + 0.0002 * n[key], f"{key}: {d_ours[key]} vs the reference's own {d_ref[key]}"
-    assert d_ours["common"] >= d_ref["common"] - 8
-    # poses: every hypothesis whose template id, correspondences and inlier count equal the float64 reference's AND whose
-    # RANSAC winner is the same candidate (equal inlier COUNTS do not pin the winner: two candidates one inlier apart swap
-    # places under any rounding difference; "same winner" = the 2-D similarity M within 1e-3)
-    def agreeing(a):
-        disc = (a["id_src"] == g64["id_src"]) & (a["src_pts"] == g64["src_pts"]).all((-1, -2)) & (a["tar_pts"] == g64["tar_pts"]).all((-1, -2)) & \
-               (a["all_scores"] == g64["all_scores"])
-        m_err = np.abs(a["M"] - g64["M"]).max(axis=(-1, -2)) / np.abs(g64["M"]).max(axis=(-1, -2))
-        return disc, disc & (m_err < 1e-3), m_err
-
-    p["all_poses"] = p["pred_poses"]
-    disc, same, m_err = agreeing(p)
-    disc32, same32, m32 = agreeing(g32)
-    terr, rerr = pose_rel_err(p["pred_poses"][same].astype(np.float64), g64["all_poses"][same])
-    t32, r32 = pose_rel_err(g32["all_poses"][same32].astype(np.float64), g64["all_poses"][same32])
-    print(f"    hypotheses with the float64 reference's discrete choices: {int(disc.sum())}/{disc.size}, of them with its RANSAC winner {int(same.sum())} "
-          f"(reference f32: {int(disc32.sum())} / {int(same32.sum())}); on those M rel err {m_err[same].max():.2e}, translation rel {terr.max():.2e}, "
-          f"rotation abs {rerr.max():.2e} (reference f32: {m32[same32].max():.2e} / {t32.max():.2e} / {r32.max():.2e})")
-    assert same.sum() >= 0.95 * same32.sum()
-    assert m_err[same].max() < 1e-4 and terr.max() < 1e-4 and rerr.max() < 1e-4   # the north-star tolerance
+    rep = px.explain(m, ours_for_checker(model, p, cap["tiles"], m), eps_sim=EPS_SIM, eps_px=EPS_PX)
+    print(f"{which} [{numerics}] vs the reference in float64 (eps_sim {EPS_SIM:g}, eps_px {EPS_PX:g}): {px.summary(rep)}")
+    for line in rep["unexplained"][:30]:
+        print("   UNEXPLAINED:", line)
+    assert not rep["unexplained"], f"{len(rep['unexplained'])} differences from the float64 reference are not float64 ties"
+    assert rep["hyp_same_all"] >= 0.9 * rep["hyp"]   # the bulk of the hypotheses takes the float64 run's discrete path end to end
     out = np.load(os.path.join(model.log_dir, "predictions", "0.npz"))
     np.testing.assert_array_equal(out["object_id"], g32["object_id"])
     assert out["poses"].shape == g32["poses"].shape and out["poses"].dtype == np.float32

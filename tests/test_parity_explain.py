@@ -39,8 +39,8 @@ def test_checker_rejects_planted_errors(golden_dir):
     base = ref32_as_ours(golden_dir, "e2e")
     assert not px.explain(m, base)["unexplained"]
     o = {k: v.copy() for k, v in base.items()}
-    t = int(np.flatnonzero(o["tiles_valid"][0, 0])[3])
-    o["tiles_valid"][0, 0, t] = False                                   # a robust patch dropped
+    t = int(np.flatnonzero(o["tiles_valid"][0])[3])
+    o["tiles_valid"][0, t] = False                                      # a robust patch dropped (stored tile 0)
     assert any("patch %d" % t in s for s in px.explain(m, o)["unexplained"])
     o = {k: v.copy() for k, v in base.items()}
     o["poses"][1, 0, :3, 3] *= 1.001                                    # a pose 1e-3 off
@@ -49,5 +49,5 @@ def test_checker_rejects_planted_errors(golden_dir):
     o["inliers"][2, 0] -= 1                                             # an inlier count off by one with no 14 px tie
     assert px.explain(m, o)["unexplained"]
     o = {k: v.copy() for k, v in base.items()}
-    o["sim_avg"][0, int(m["top_ids"][0, 0])] += 1e-4                    # a wrong sim_avg
+    o["sim_avg"][int(m["tile_b"][0]), int(m["tile_n"][0])] += 1e-4      # a wrong sim_avg
     assert any("sim_avg" in s for s in px.explain(m, o)["unexplained"])

@@ -190,7 +190,7 @@ def test_pack_unpack_query_roundtrip():
     lab = torch.tensor([2, 0, 1], dtype=torch.int32)
     f32 = torch.from_numpy(rs.standard_normal((3, 48, 256)).astype(np.float32))
     rows, layout = sharding.pack_query(f32, qm, lab)
-    assert rows.shape == (3, 48 * 256 * 4 + 1024 + 4)
+    assert rows.shape == (3, 48 * 256 * 4 + 1024 + 16) and all(o % 16 == 0 for _, _, o, _ in layout)   # fields at 16-byte offsets
     q, m, l = sharding.unpack_query(rows, layout)
     assert torch.equal(q, f32) and torch.equal(m, qm) and torch.equal(l, lab)
     hi = torch.from_numpy(rs.standard_normal((3, 256, 64)).astype(np.float16))

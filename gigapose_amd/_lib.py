@@ -44,9 +44,12 @@ def lib():
 
 STATUS_BITS = {1: "a stream-K accumulator hand-over of the split GEMM timed out (features are garbage)",
                2: "a stream-K accumulator hand-over of the f32 GEMM timed out (features are garbage)",
-               4: "split numerics: an activation left the range of the f16 planes (|x| >= 8190) or is not finite -- "
-                  "use numerics 'chain' or GIGAPOSE_SPLIT_GEMM=128 for this checkpoint",
-               8: "a detection label / template id lies outside the onboarded bank (the reference raises IndexError)"}
+               4: "an activation is not finite, or (split numerics) left the range of the f16 planes (|x| >= 8190; GigaPose falls "
+                  "back to GIGAPOSE_SPLIT_GEMM=128 by itself, a bare ViT call does not)",
+               8: "a detection label / template id lies outside the onboarded bank (the reference raises IndexError)",
+               16: "split numerics: an IST activation left the range of the f16 planes (|x| >= 8190) or is not finite -- "
+                   "use numerics 'chain' or GIGAPOSE_SPLIT_CONV=128 for this checkpoint"}
+SPLIT_RANGE_BITS = 4 | 16
 _status = None
 
 
@@ -60,15 +63,25 @@ def status_word(device=None):
     return _status
 
 
-def check_status():
-    """Read + clear the status word (a host synchronisation: call where one happens anyway) and raise if a bit is set."""
+def take_status():
+    """Read + clear the status word (a host synchronisation: call where one happens anyway); returns the bits."""
     if _status is None:
-        return
+        return 0
     bits = int(_status.item())
     if bits:
         _status.zero_()
+    return bits
+
+
+def raise_status(bits):
+    if bits:
         msgs = [m for b, m in STATUS_BITS.items() if bits & b]
         raise GigaPoseHipError("device status 0x%x: %s" % (bits, "; ".join(msgs)))
+
+
+def check_status():
+    """Read + clear the status word and raise if a bit is set."""
+    raise_status(take_status())
 
 
 def stream_ptr():

@@ -24,7 +24,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 enum { GP_ST_HANDOFF_SPLIT = 1,   // a stream-K accumulator hand-over of the split GEMMs timed out: that tile is garbage
        GP_ST_HANDOFF_CHAIN = 2,   // same, f32 (chain) GEMM
        GP_ST_SPLIT_RANGE = 4,     // an activation left the range of the single-accumulator split planes (|x| >= 8190) or is not finite
-       GP_ST_LABEL_RANGE = 8 };   // a detection label / template id outside the onboarded bank
+       GP_ST_LABEL_RANGE = 8,     // a detection label / template id outside the onboarded bank
+       GP_ST_SPLIT_RANGE_CONV = 16 };  // GP_ST_SPLIT_RANGE raised by the IST planes (conv_planes_kernel and its producers): the host's
+                                  // automatic fallback widens only the network that needs it (gigaPose.py: _widen_split_range)
 int* gp_status_buffer();
 __device__ __forceinline__ void gp_raise(int* status, int bit)
 {

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
                     }
                 }
             }
-            if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE);
+            if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE_CONV);
             __syncthreads();  // LDS buffer 0 is re-staged by the next segment's prologue
         }
         if (a.trace) { const unsigned long long t = wall_clock64(); tr_tail += t - tr_t0; tr_t0 = t; }
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void planes_from_cm_kernel(const float* __rest
             bad |= !(fabsf(v) <= kSplitPlaneLimit);
         }
     }
-    if (bad) gp_raise(status, GP_ST_SPLIT_RANGE);
+    if (bad) gp_raise(status, GP_ST_SPLIT_RANGE_CONV);
 }
 
 // F.interpolate(x, (S, S), mode="bilinear", align_corners=True) (reference resnet.py:366-368; arithmetic of gp_conv.hip's
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void resize_stem_planes_kernel(const float* __
     const size_t o = (((size_t)b * Hp + y + 3) * Wp + x + 3) * 4;
     *reinterpret_cast<c16x4*>(hi + o) = oh;
     *reinterpret_cast<c16x4*>(lo + o) = ol;
-    if (bad) gp_raise(status, GP_ST_SPLIT_RANGE);
+    if (bad) gp_raise(status, GP_ST_SPLIT_RANGE_CONV);
 }
 
 unsigned g_epoch_conv = 0;

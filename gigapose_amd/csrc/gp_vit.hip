@@ -958,7 +958,7 @@ extern "C" void gp_attention_set_nq(int nq) { g_attn_nq = (nq >= 0 && nq <= 2) ?
 
 // ---- x_prenorm[:, 1:] -> (B, C, 256), F.normalize over C (ae_net.py:64-69); fixed fmaf order
 __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__ X, float* __restrict__ out,
-                                                        int C, int Mpad, int normalize)
+                                                        int C, int Mpad, int normalize, int* __restrict__ status)
 {
     // grid (B, nchunk): every block recomputes the full norm of its 256 patches (same sequential fma chain; the nchunk-fold
     // re-read is L2 traffic) and writes its share of the channels -- B blocks alone cannot fill 256 CUs, one block per 32
@@ -982,6 +982,9 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
             ss = __builtin_fmaf(v, v, ss);
         }
         d = fmaxf(__builtin_sqrtf(ss), 1e-12f);
+        // last line of defence of every numerics mode (the plane producers have their own range guard): a NaN / inf anywhere in
+        // this token's residual stream ends up in its norm -- never hand non-finite features to the matcher silently
+        if (blockIdx.y == 0 && !(ss <= 3.0e38f)) gp_raise(status, GP_ST_SPLIT_RANGE);
     }
     float* o = out + (size_t)b * C * GP_P + p;
     for (int c = c0; c < c1; ++c) o[(size_t)c * GP_P] = normalize ? x[(size_t)c * Mpad] / d : x[(size_t)c * Mpad];
@@ -1215,7 +1218,8 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
         else rc = gp_gemm_launch(w[L_FC2_WT], C, F, Mpad, X, Mpad, C, Mpad, mlp_dim, 3, w[L_FC2_B], w[L_LS2], X, Mpad, SK, st);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(features_kernel, dim3(B, B >= 64 ? 4 : (B >= 16 ? 16 : 32)), dim3(256), 0, st, X, out_features, C, Mpad, normalize);
+    hipLaunchKernelGGL(features_kernel, dim3(B, B >= 64 ? 4 : (B >= 16 ? 16 : 32)), dim3(256), 0, st, X, out_features, C, Mpad, normalize,
+                       gp_status_buffer());
     GP_CHECK_LAUNCH("gp_vit_forward/features");
     return GP_OK;
 }

@@ -116,6 +116,30 @@ class GigaPose(_Base):
         self.template_datas, self.match_banks, self.pose_recovery = {}, {}, {}
         return self
 
+    def _widen_split_range(self, bits):
+        """Automatic fallback of the split numerics' range guard.  The single-accumulator plane kernels hold activations x 8 in
+        f16 (|x| < 8190); a checkpoint with larger activations (DINOv2's massive channels) trips the guard -- instead of failing,
+        move the network that tripped it to its two-accumulator 128 x 128 kernels (range 65504) for the rest of this model's life,
+        drop the onboarded banks (they are rebuilt with the same kernels) and let the caller run again.  Returns True if something
+        was widened (False: already wide, or not a range bit -- the caller raises)."""
+        import warnings
+
+        changed = []
+        vit = getattr(self.ae_net, "dinov2_model", None)
+        if bits & 4 and vit is not None and getattr(vit, "numerics", None) == "split" and getattr(vit, "split_gemm", "128") != "128":
+            vit.set_split_gemm("128")
+            changed.append("ViT linear layers -> 128 x 128 two-accumulator kernels (GIGAPOSE_SPLIT_GEMM=128)")
+        ist = getattr(self.ist_net, "backbone", None)
+        if bits & 16 and ist is not None and getattr(ist, "numerics", None) == "split" and getattr(ist, "conv_kernel", "128") != "128":
+            ist.conv_kernel = "128"
+            ist.invalidate()
+            changed.append("IST convolutions -> 128 x 128 two-accumulator kernel (GIGAPOSE_SPLIT_CONV=128)")
+        if changed:
+            warnings.warn("split numerics: an activation left the range of the f16 planes (|x| >= 8190); falling back for this model: "
+                          + "; ".join(changed) + ".  Template banks are rebuilt.", RuntimeWarning)
+            self.template_datas, self.match_banks, self.pose_recovery = {}, {}, {}
+        return bool(changed)
+
     def enable_template_sharding(self, group=None):
         """Shard the template bank over the ranks of `group` (gigapose_amd/sharding.py).  Call
         before set_template_data; every rank must then call predict() with the same batch size."""
@@ -163,7 +187,10 @@ class GigaPose(_Base):
         self.pose_recovery[dataset_name] = ObjectPoseRecovery(template_K=data["K"], template_Ms=data["M"],
                                                               template_poses=data["poses"])
         torch.cuda.synchronize()
-        _lib.check_status()
+        bits = _lib.take_status()
+        if bits & _lib.SPLIT_RANGE_BITS and self._widen_split_range(bits):
+            return self.set_template_data(dataset_name)          # once more with the wide-range kernels (then any bit raises)
+        _lib.raise_status(bits)
         self.onboarding_time = (time.time() - t0) / max(1, len(template_dataset))
 
     # ------------------------------------------------------------------ the hot loop
@@ -229,9 +256,12 @@ class GigaPose(_Base):
         labels = torch.from_numpy(labels_np)
         predictions = self.predict(batch.tar_img, batch.tar_mask, batch.tar_K, batch.tar_M, labels, dataset_name,
                                    sort_pred_by_inliers)
-        predictions.infos = batch.infos
         torch.cuda.synchronize()
-        _lib.check_status()  # guard rails: lost hand-off / split range / label range -> GigaPoseHipError, never silent garbage
+        bits = _lib.take_status()  # guard rails: lost hand-off / split range / label range -> GigaPoseHipError, never silent garbage
+        if bits & _lib.SPLIT_RANGE_BITS and self._widen_split_range(bits):
+            return self.eval_retrieval(batch, idx_batch, dataset_name, sort_pred_by_inliers)   # re-onboards, runs again; a second trip raises
+        _lib.raise_status(bits)
+        predictions.infos = batch.infos
         total_time = time.time() - t0
         self.last_predictions = predictions
         save_path = osp.join(self.log_dir, "predictions", f"{idx_batch}.npz")

@@ -82,6 +82,18 @@ class Dinov2ViT(nn.Module):
         self._packed = None
         self._ws = None
         self.numerics = os.environ.get("GIGAPOSE_NUMERICS", "chain")
+        # split numerics: "256" = single-accumulator plane kernels (activations x 8 in f16 planes: |x| < 8190, guarded);
+        # "128" = every GEMM on the two-accumulator 128 x 128 kernel (range 65504, slower).  GigaPose switches to "128" by itself
+        # when the range guard trips (gigaPose.py: _widen_split_range) -- DINOv2 checkpoints are known for a few massive activations
+        self.split_gemm = os.environ.get("GIGAPOSE_SPLIT_GEMM", "256")
+
+    def set_split_gemm(self, mode):
+        if mode not in ("256", "128"):
+            raise ValueError("split_gemm must be '256' or '128'")
+        if mode != self.split_gemm:
+            self.split_gemm = mode
+            self._packed = None
+        return self
 
     def set_numerics(self, mode):
         if mode not in NUMERICS:
@@ -207,7 +219,7 @@ class Dinov2ViT(nn.Module):
                       blk.mlp.fc2.weight.to(device))
                 for w in ws:                       # entries 0..9: hi + lo * 2^-11 planes (128 x 128 kernel)
                     split += list(split_planes(w))
-                if os.environ.get("GIGAPOSE_SPLIT_GEMM", "256") != "128":
+                if self.split_gemm != "128":
                     # entries 10..19: x64 single-accumulator planes (256 x 256 kernel; needs |activation| < 8190 --
                     # GIGAPOSE_SPLIT_GEMM=128 keeps every GEMM on the two-accumulator kernel, range 65504).  The q|k and v planes are
                     # views of ONE (3C, C) tensor: gp_vit_forward_split then runs q|k|v as a single launch (768 tiles at B = 64)

@@ -32,6 +32,8 @@ const char* gp_last_error(void);
 #define GP_STATUS_HANDOFF_CHAIN 2 /* f32 (chain) GEMM: same */
 #define GP_STATUS_SPLIT_RANGE 4   /* split numerics: plane value out of range / NaN (use numerics "chain" or GIGAPOSE_SPLIT_GEMM=128) */
 #define GP_STATUS_LABEL_RANGE 8   /* label >= O or template id >= N (clamped to 0 so nothing reads out of bounds) */
+#define GP_STATUS_SPLIT_RANGE_CONV 16 /* GP_STATUS_SPLIT_RANGE raised by the IST convolution planes (fallback: the 128 x 128 two-accumulator
+                                         convolution, GIGAPOSE_SPLIT_CONV=128; gigapose_amd/gigaPose.py widens automatically) */
 int gp_set_status_buffer(int* device_word);
 
 /* Optional timing of kernel families with HIP events on the launch stream (used by bench.py for the

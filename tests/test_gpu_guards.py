@@ -126,3 +126,69 @@ def test_labels_outside_the_bank():
             _lib.check_status()
         keep = [0, 2, 3]                                  # the other detections are untouched
         assert torch.equal(out.id_src[keep], good.id_src[keep]) and torch.equal(out.pred_poses[keep], good.pred_poses[keep])
+
+
+def _gigapose_with_vit(vit, k=3):
+    import tempfile
+
+    from gigapose_amd.ae_net import AENet
+    from gigapose_amd.gigaPose import GigaPose
+    from gigapose_amd.ist_net import ISTNet, Regressor, ResNet
+    from gigapose_amd.matching import LocalSimilarity
+
+    ist = syn.fill_state_dict(ISTNet("resnet", ResNet(dict(factory.IST_CFG)), Regressor(256, 256, True, True), 64), 9)
+    model = GigaPose("large", AENet("dinov2_vitl14", vit, 1024, 64), ist, None, LocalSimilarity(k=k, sim_threshold=0.5, patch_threshold=3),
+                     None, 1000, tempfile.mkdtemp(), max_num_dets_per_forward=4).eval().to(DEV)
+    return model.set_numerics("split")
+
+
+def test_range_trip_falls_back_to_the_wide_kernels_automatically():
+    """a checkpoint whose activations leave the x 8 planes' range (|x| >= 8190; planted: one fc1 bias of 1e4)
+    must not make the drop-in fail.  GigaPose notices the guard bit at its synchronisation point, moves the ViT to the
+    two-accumulator 128 x 128 kernels (range 65504), re-onboards and runs again: the result equals a model that was told
+    GIGAPOSE_SPLIT_GEMM=128 from the start, the status word is clean, a warning says what happened.  A NaN still raises."""
+    from test_gpu_e2e import make_batch
+
+    def planted():
+        vit = small_vitl(seed=11)
+        with torch.no_grad():
+            vit.blocks[0].mlp.fc1.bias[7] = 1.0e4
+        vit.invalidate()
+        return vit
+
+    tset = factory.TemplateSet(1, 12, seed=80)
+    q = tset.crops(81, 16, "cpu")
+    batch = make_batch({n: (v.numpy() if torch.is_tensor(v) else v) for n, v in q.items()})
+    want = _gigapose_with_vit(planted().set_split_gemm("128"))
+    want.template_datasets = {"syn": tset}
+    want.eval_retrieval(batch, 0, "syn")
+    ref = {n: v.cpu() for n, v in want.last_predictions.tensors.items()}
+    model = _gigapose_with_vit(planted())
+    assert model.ae_net.dinov2_model.split_gemm == "256"
+    model.template_datasets = {"syn": tset}
+    with pytest.warns(RuntimeWarning, match="falling back"):
+        model.eval_retrieval(batch, 0, "syn")                      # onboarding trips the guard -> widen -> onboard again -> predict
+    assert model.ae_net.dinov2_model.split_gemm == "128"
+    _lib.check_status()                                            # clean afterwards
+    got = {n: v.cpu() for n, v in model.last_predictions.tensors.items()}
+    for n in ref:
+        assert torch.equal(ref[n], got[n]), f"{n} differs from the model built with the wide kernels"
+    # a second batch runs without another fallback
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model.eval_retrieval(batch, 1, "syn")
+    # the trip can also come from a crop (bank onboarded cleanly): a fresh model, clean onboarding, then a huge crop
+    model = _gigapose_with_vit(small_vitl(seed=11))
+    model.template_datasets = {"syn": tset}
+    model.set_template_data("syn")
+    big = {n: (v.numpy().copy() if torch.is_tensor(v) else v) for n, v in q.items()}
+    big["tar_img"][3] *= 1.0e5
+    with pytest.warns(RuntimeWarning, match="falling back"):
+        model.eval_retrieval(make_batch(big), 2, "syn")
+    _lib.check_status()
+    # not a range problem: NaN pixels trip the guard again after the fallback -> raises
+    bad = {n: (v.numpy().copy() if torch.is_tensor(v) else v) for n, v in q.items()}
+    bad["tar_img"][2, 0, 50, 50] = float("nan")
+    with pytest.raises(_lib.GigaPoseHipError):
+        model.eval_retrieval(make_batch(bad), 3, "syn")

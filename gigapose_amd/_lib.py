@@ -50,26 +50,33 @@ STATUS_BITS = {1: "a stream-K accumulator hand-over of the split GEMM timed out 
                16: "split numerics: an IST activation left the range of the f16 planes (|x| >= 8190) or is not finite -- "
                    "use numerics 'chain' or GIGAPOSE_SPLIT_CONV=128 for this checkpoint"}
 SPLIT_RANGE_BITS = 4 | 16
-_status = None
+_status = {}        # device index -> the int32 word on that device
+_status_active = None  # device index whose word the library currently points at
 
 
 def status_word(device=None):
-    """The device int32 the kernels OR their guard-rail bits into (include/gigapose_hip.h: gp_set_status_buffer).
-    Created on first use (the library then holds its address) -- one GPU per process, as everywhere in this package."""
-    global _status
-    if _status is None:
-        _status = torch.zeros(1, dtype=torch.int32, device=device or "cuda")
-        call("gp_set_status_buffer", ctypes.c_void_p(_status.data_ptr()))
-    return _status
+    """The device int32 the kernels OR their guard-rail bits into (include/gigapose_hip.h: gp_set_status_buffer), one per GPU.
+    The library holds ONE pointer: every entry point of the package that launches kernels calls this with the device of its
+    tensors first, so a process driving several GPUs never ORs into another GPU's memory."""
+    global _status_active
+    dev = torch.device(device if device is not None else "cuda")
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _status:
+        _status[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+    if _status_active != idx:
+        call("gp_set_status_buffer", ctypes.c_void_p(_status[idx].data_ptr()))
+        _status_active = idx
+    return _status[idx]
 
 
 def take_status():
-    """Read + clear the status word (a host synchronisation: call where one happens anyway); returns the bits."""
-    if _status is None:
-        return 0
-    bits = int(_status.item())
-    if bits:
-        _status.zero_()
+    """Read + clear the status words (a host synchronisation: call where one happens anyway); returns the OR of their bits."""
+    bits = 0
+    for w in _status.values():
+        b = int(w.item())
+        if b:
+            w.zero_()
+        bits |= b
     return bits
 
 

@@ -55,6 +55,9 @@ def rank_hypotheses(pred, sort=True):
     isc = pred.ransac_scores.contiguous()
     B, k, num_patches = isc.shape
     dev = isc.device
+    if not isc.is_cuda or isc.dtype != torch.int64:
+        # the launch reinterprets the buffer: a float score tensor would rank garbage.  No torch fallback (the hot path is HIP only)
+        raise _lib.GigaPoseHipError(f"rank_hypotheses needs the int64 device tensor gp_ransac writes, got {isc.dtype} on {isc.device}")
     score = torch.empty(B, k, dtype=torch.float32, device=dev)
     order = torch.empty(B, k, dtype=torch.int64, device=dev)
     names = list(pred.tensors) if sort else []

@@ -252,6 +252,8 @@ class Dinov2ViT(nn.Module):
         if images.shape[1:] != (3, 224, 224):
             raise ValueError(f"expected (B,3,224,224) crops, got {tuple(images.shape)}")
         device = images.device
+        if device.type == "cuda":
+            _lib.status_word(device)   # the guard-rail word of THIS GPU (one per device, _lib.py)
         if self._packed is None or self._packed[0] != device:
             self._pack(device)
         B = images.shape[0]

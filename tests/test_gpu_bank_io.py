@@ -38,3 +38,45 @@ def test_bank_file_round_trip_and_shards(tmp_path, numerics):
     with pytest.raises(ValueError):                               # numerics mismatch is refused
         other = factory.build_model("dinov2_vits14", k=4, device=dev, seed=5).set_numerics("chain" if numerics == "split" else "split")
         bank_io.load_bank(other, "syn", path)
+
+
+def test_fp16_bank_file_round_trip_and_8_way_shards(tmp_path):
+    """BASELINE config 5's bank format: the fp16 (hi-plane-only) matcher bank, 162 templates per object, cut 8-way at load time
+    (two ranks with 21, six with 20 templates -- sharding.shard_bounds): the file holds no lo plane (half the matcher bytes), a model
+    started from it predicts bit for bit what the onboarding model predicts, and every rank's slice is the onboarded slice."""
+    from gigapose_amd.sharding import ShardedMatcher, shard_bounds
+
+    dev = torch.device("cuda", 0)
+    tset = factory.TemplateSet(2, 162, seed=72)
+    q = tset.crops(73, 4, dev)
+
+    def build():
+        m = factory.build_model("dinov2_vits14", k=5, device=dev, seed=5).set_numerics("split")
+        m.testing_metric.bank_dtype = "f16"
+        return m
+
+    a = build()
+    a.template_datasets = {"syn": tset}
+    a.set_template_data("syn")
+    full = a.match_banks["syn"]
+    assert full.bank_dtype == "f16" and full.lo is None
+    path = str(tmp_path / "syn16.gpbank")
+    hdr = bank_io.save_bank(a, "syn", path)
+    assert hdr["bank_dtype"] == "f16" and "match_lo" not in hdr["sections"] and hdr["sections"]["match_hi"]["dtype"] == "float16"
+    assert hdr["sections"]["match_hi"]["shape"] == [2, 162, 256, 384]
+    ref = a.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
+    b = build()
+    assert bank_io.load_bank(b, "syn", path)["bank_dtype"] == "f16"
+    got = b.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
+    for n, v in ref.tensors.items():
+        assert torch.equal(v, got.tensors[n]), n
+    sizes = []
+    for rank in range(8):
+        c = build()
+        bank_io.load_bank(c, "syn", path, shard=(rank, 8))
+        sm = c.match_banks["syn"]
+        lo, hi = shard_bounds(162, 8, rank)
+        assert isinstance(sm, ShardedMatcher) and sm.lo == lo and sm.bank.N == hi - lo and sm.bank.lo is None and sm.bank.bank_dtype == "f16"
+        assert torch.equal(sm.bank.hi, full.hi[:, lo:hi]) and torch.equal(sm.bank.masks, full.masks[:, lo:hi])
+        sizes.append(hi - lo)
+    assert sum(sizes) == 162 and sorted(sizes, reverse=True) == [21, 21, 20, 20, 20, 20, 20, 20]

@@ -102,6 +102,8 @@ def test_eval_retrieval_matches_reference_golden(golden_dir, numerics, monkeypat
     model.template_datasets = {"syn": FakeTemplates(items)}
     model.test_dataset_name = "syn"
     batch = make_batch(q)
+    tiles, match_tiles = {}, model.testing_metric.match_tiles
+    model.testing_metric.match_tiles = lambda *a, **kw: tiles.setdefault("out", match_tiles(*a, **kw))   # every tile's record, for the checker
     assert model.test_step(batch, 0) == 0
     p = model.last_predictions
     # onboarding produced the same features as the reference's (ViT-S on CPU)
@@ -123,16 +125,23 @@ def test_eval_retrieval_matches_reference_golden(golden_dir, numerics, monkeypat
     # (3) RANSAC: identical inlier counts, failure flags and winning candidates for ALL hypotheses
     np.testing.assert_array_equal(mine("scores"), g["all_scores"])
     np.testing.assert_array_equal(mine("idx_failed"), g["idx_failed"])
+    # Equal inlier COUNTS do not pin the winning candidate: many-to-one matches put correspondences at exactly one patch (14 px) from
+    # the proposing one, so candidates tie and rounding picks among them.  Every hypothesis must therefore either carry the
+    # reference's similarity M and pose to the north-star's 1e-4, or be an EXPLAINED tie against the reference evaluated in float64
+    # (tests/parity_explain.py with the margins golden of this configuration) -- no hypothesis is exempt.
+    import parity_explain as px
+    from test_gpu_parity_big import EPS_PX, EPS_SIM, ours_for_checker
+
+    m = dict(np.load(os.path.join(golden_dir, "e2e_margins.npz")))
+    p_np = {n: v.cpu().numpy() for n, v in p.tensors.items()}
+    rep = px.explain(m, ours_for_checker(model, p_np, tiles["out"], m), eps_sim=EPS_SIM, eps_px=EPS_PX)
     m_err = np.abs(mine("M") - g["M"]).max(axis=(-1, -2)) / np.abs(g["M"]).max(axis=(-1, -2))
-    # Equal inlier COUNTS do not pin the winning candidate: when a second candidate is one inlier short of the winner, a 1e-7
-    # difference in relScale can lift it level and torch.max's first-maximum rule then prefers the lower index (seen once in 12
-    # hypotheses when the stem moved to split numerics).  At most ONE hypothesis may pick another candidate; every other one must
-    # carry the reference's similarity and pose to 1e-4 (measured ~1e-6).  Stages 5-6 alone are pinned exactly by the next test.
     same = m_err < 1e-4
     terr, rerr = pose_rel_err(mine("pred_poses")[same], g["all_poses"][same])
     print("e2e [%s] vs reference: %d of %d hypotheses with the reference's RANSAC winner; on them M rel err %.2e, translation rel %.2e, "
-          "rotation abs %.2e" % (numerics, same.sum(), same.size, m_err[same].max(), terr.max(), rerr.max()))
-    assert same.sum() >= same.size - 1 and terr.max() < 1e-4 and rerr.max() < 1e-4   # the north-star tolerance
+          "rotation abs %.2e | vs its float64 run: %s" % (numerics, same.sum(), same.size, m_err[same].max(), terr.max(), rerr.max(), px.summary(rep)))
+    assert not rep["unexplained"], rep["unexplained"][:5]
+    assert terr.max() < 1e-4 and rerr.max() < 1e-4   # the north-star tolerance
     # what filter_and_save wrote (the reference's on-disk contract, gigaPose.py:439-448)
     out = np.load(os.path.join(model.log_dir, "predictions", "0.npz"))
     np.testing.assert_array_equal(out["object_id"], g["object_id"])

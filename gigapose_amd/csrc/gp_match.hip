@@ -78,7 +78,13 @@ __device__ __forceinline__ void rowmax_exchange(float (&rv)[32], int (&ri)[32], 
 // Everything after the 256x256 similarity tile sits in the accumulators (8 waves as 4 (t) x 2 (s), wave tile
 // 64 x 128 = acc[2][4]): masks, threshold, bidirectional argmax, cycle check, template score.  Shared by the
 // f32-chain kernel and the split-f16 kernel (gp_match_split below); SM is the kernel's shared-memory struct.
-template <class SM>
+// PERM (split kernel): the tile's rows / columns are the LIVE patches only, compacted and dealt block-cyclically to the waves
+// (match_tiles_split_kernel); sm.t_of / sm.s_of map an LDS row back to its patch (kDeadPatch = none), sm.qmask_p / sm.smask_p hold
+// the masks in that order.  A masked-out patch contributes exact zeros to every maximum in the reference (sim *= mask,
+// matching.py:234-235), and an all-zero row's argmax is index 0 -- so the maxima over the live patches, compared in the
+// (value desc, patch index asc) order and reset to index 0 when the maximum is 0, are the reference's, bit for bit.
+constexpr int kDeadPatch = 0x7fff;
+template <bool PERM = false, class SM>
 __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int b, int n, int N, float thr, float patch_thr,
                                                uint8_t* __restrict__ idx_t2s, float* __restrict__ score_t2s,
                                                float* __restrict__ mask_all, float* __restrict__ sim_avg,
@@ -90,13 +96,24 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
     const int s_lane = 128 * wc + (lane & 31);
     const int t_lane = 64 * wr + 4 * (lane >> 5);
     float sm_s[4];
+    int s_idx[4];  // patch index of this lane's column in block ni
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) sm_s[ni] = sm.smask[s_lane + 32 * ni];
+    for (int ni = 0; ni < 4; ++ni) {
+        if constexpr (PERM) {
+            sm_s[ni] = sm.smask_p[s_lane + 32 * ni];
+            s_idx[ni] = sm.s_of[s_lane + 32 * ni];
+        } else {
+            sm_s[ni] = sm.smask[s_lane + 32 * ni];
+            s_idx[ni] = s_lane + 32 * ni;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float tm = sm.qmask[t_lane + 32 * mi + (r & 3) + 8 * (r >> 2)];
+            float tm;
+            if constexpr (PERM) tm = sm.qmask_p[t_lane + 32 * mi + (r & 3) + 8 * (r >> 2)];
+            else tm = sm.qmask[t_lane + 32 * mi + (r & 3) + 8 * (r >> 2)];
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 float v = acc[mi][ni][r] * sm_s[ni];
@@ -117,13 +134,13 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float bv = acc[mi][0][r];
-            int bi = s_lane;
+            int bi = s_idx[0];
 #pragma unroll
             for (int ni = 1; ni < 4; ++ni) {
                 const float x = acc[mi][ni][r];
-                const bool take = x > bv;
+                const bool take = PERM ? ((x > bv) | ((x == bv) & (s_idx[ni] < bi))) : (x > bv);  // unpermuted: ni ascending == s ascending
                 bv = take ? x : bv;
-                bi = take ? s_lane + 32 * ni : bi;
+                bi = take ? s_idx[ni] : bi;
             }
             rv[mi * 16 + r] = bv;
             ri[mi * 16 + r] = bi;
@@ -135,9 +152,12 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
     rowmax_exchange<1>(rv, ri, lane);
     {
         const int j = lane & 31;  // the row this lane ended up with: mi = j >> 4, r = j & 15
-        const int t = t_lane + 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2);
-        sm.rowv[wc][t] = rv[0];
-        sm.rowi[wc][t] = ri[0];
+        int t = t_lane + 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2);
+        if constexpr (PERM) t = sm.t_of[t];
+        if (!PERM || t != kDeadPatch) {  // rows without a live patch keep the zeros the prologue wrote
+            sm.rowv[wc][t] = rv[0];
+            sm.rowi[wc][t] = ri[0];
+        }
     }
 
     // ---- column maxima (over t, first max wins)   torch.max(sim, dim=2)  (matching.py:241)
@@ -148,16 +168,22 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {  // (mi, r) ascending == t ascending for this lane
+            for (int r = 0; r < 16; ++r) {  // (mi, r) ascending == t ascending for this lane (unpermuted tile)
                 const float x = acc[mi][ni][r];
-                if (x > bv) { bv = x; bi = t_lane + 32 * mi + (r & 3) + 8 * (r >> 2); }
+                const int row = t_lane + 32 * mi + (r & 3) + 8 * (r >> 2);
+                if constexpr (PERM) {  // LDS rows are not in patch order: an exact tie between positive values goes to the lower patch
+                    if (x > bv || (x == bv && x > 0.f && sm.t_of[row] < sm.t_of[bi])) { bv = x; bi = row; }
+                } else {
+                    if (x > bv) { bv = x; bi = row; }
+                }
             }
+        if constexpr (PERM) bi = sm.t_of[bi];
         const float ov = __shfl_xor(bv, 32);
         const int oi = __shfl_xor(bi, 32);
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        if (lane < 32) {
-            sm.colv[wr][s_lane + 32 * ni] = bv;
-            sm.coli[wr][s_lane + 32 * ni] = bi;
+        if (lane < 32 && (!PERM || s_idx[ni] != kDeadPatch)) {
+            sm.colv[wr][s_idx[ni]] = bv;
+            sm.coli[wr][s_idx[ni]] = bi;
         }
     }
     __syncthreads();
@@ -167,7 +193,10 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
     if (tid < GP_P) {
         float bv = sm.rowv[0][tid];
         int bi = sm.rowi[0][tid];
-        if (sm.rowv[1][tid] > bv) { bv = sm.rowv[1][tid]; bi = sm.rowi[1][tid]; }
+        const float v1 = sm.rowv[1][tid];
+        const int i1 = sm.rowi[1][tid];
+        if (v1 > bv || (PERM && v1 == bv && i1 < bi)) { bv = v1; bi = i1; }
+        if (PERM && bv == 0.f) bi = 0;  // an all-zero row: first index (the masked-out patches' zeros are part of the row)
         sm.sc_t2s[tid] = bv;
         sm.id_t2s[tid] = bi;
     } else {
@@ -175,8 +204,12 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
         float bv = sm.colv[0][s];
         int bi = sm.coli[0][s];
 #pragma unroll
-        for (int w = 1; w < 4; ++w)
-            if (sm.colv[w][s] > bv) { bv = sm.colv[w][s]; bi = sm.coli[w][s]; }
+        for (int w = 1; w < 4; ++w) {
+            const float vw = sm.colv[w][s];
+            const int iw = sm.coli[w][s];
+            if (vw > bv || (PERM && vw == bv && iw < bi)) { bv = vw; bi = iw; }
+        }
+        if (PERM && bv == 0.f) bi = 0;
         sm.sc_s2t[s] = bv;
         sm.id_s2t[s] = bi;
     }
@@ -288,6 +321,11 @@ struct alignas(16) MatchSplitSmem {
     _Float16 stage[2 * 4 * MS_PLANE];  // 128 KiB
     float qmask[GP_P];
     float smask[GP_P];
+    float qmask_p[GP_P];  // masks by LDS row of the compacted tile (0 where the row holds no live patch)
+    float smask_p[GP_P];
+    short t_of[GP_P];     // LDS row -> query patch (kDeadPatch: none)
+    short s_of[GP_P];     // LDS row of the B planes -> template patch
+    int cnt[8];           // live patches per 64-patch slice: [0..3] query, [4..7] template
     float rowv[2][GP_P];
     int rowi[2][GP_P];
     float colv[4][GP_P];
@@ -301,12 +339,129 @@ struct alignas(16) MatchSplitSmem {
 };
 
 // Main loop = gemm_planes256_kernel's (gp_split256.hip): the two wave groups of the workgroup (waves 0-3 / 4-7, one of each
-// per SIMD) run half a k-step apart -- one issues its 48 MFMAs from LDS buffer s while the other writes its share of slab
+// per SIMD) run half a k-step apart -- one issues its MFMAs from LDS buffer s while the other writes its share of slab
 // s + 1 and loads slab s + 2 -- with ONE barrier per step; per accumulator the products keep the order hi*hi, hi*lo, lo*hi
-// per k16 block, k ascending: results are bit-identical to the lock-step loop this replaces (60 % -> 84 % matrix-busy in
-// the k loop).  BANK_LO = false: the bank holds only its f16 hi plane (BASELINE config 5's "fp16 feature bank": half the
-// bytes, 2 of the 3 products; the query keeps both planes) -- f16-rounded template features, measured flip rate in DESIGN.md.
+// per k16 block, k ascending.  BANK_LO = false: the bank holds only its f16 hi plane (BASELINE config 5's "fp16 feature bank":
+// half the bytes, 2 of the 3 products; the query keeps both planes) -- f16-rounded template features, flip rate in DESIGN.md.
+//
+// Masked-out patches are not computed (round 3).  The reference multiplies the similarity by both patch masks
+// (matching.py:234-235): a row / column of a masked-out patch is exact zeros whatever the features are -- with the disc masks
+// of the benchmark 39 % of a 256 x 256 tile is live.  The tile is therefore built from the LIVE patches only: the prologue ranks
+// them (ballot + popcount), deals the 32-row blocks round-robin to the four wave rows (query patches) and the two wave columns
+// (template patches) so that every wave gets the same share, stages only those rows (everything else reads as zeros through
+// the buffer descriptor's range check), and the k loop is instantiated for MI = ceil(live row blocks / 4) in {1, 2} and
+// NI = ceil(live column blocks / 2) in {1..4} matrix tiles per wave instead of always 2 x 4.  Each (query patch, template
+// patch) dot product is the same instruction sequence as before, the epilogue maps rows back to patches (match_epilogue<PERM>):
+// outputs are bit-identical to the uncompacted kernel.
 typedef unsigned int mu32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kMatchOob = 0x80000000u;  // beyond every plane: the buffer load returns zeros without touching memory
+
+struct MatchSplitRsrc {
+    __amdgpu_buffer_rsrc_t qh, ql, bh, bl;
+    unsigned va0, va1, vb0, vb1;  // byte offsets of this thread's two query rows / two template rows (kMatchOob: no live patch)
+};
+
+template <bool BANK_LO, int MI, int NI>
+__device__ __forceinline__ void match_split_kloop(MatchSplitSmem& sm, f32x16 (&acc)[2][4], const MatchSplitRsrc& rs, int ns, int tid,
+                                                  int lane, int wr, int wc, int grp)
+{
+    constexpr int P_AHI = 0, P_ALO = MS_PLANE, P_BHI = 2 * MS_PLANE, P_BLO = 3 * MS_PLANE, MS_BUF = 4 * MS_PLANE;
+    constexpr bool kStageA1 = MI > 1 || true;  // rows 128..255 hold wave rows 2, 3 (always) and the second row block
+    const int wofs = (tid >> 2) * MS_BK + (((tid & 3) ^ (((tid >> 2) >> 2) & 3)) << 3);
+    mu32x4 rg[8];
+    auto gload = [&](int slab) {
+        const unsigned so = (unsigned)slab * (MS_BK * 2u);
+        rg[0] = __builtin_amdgcn_raw_buffer_load_b128(rs.qh, rs.va0, so, 0);
+        rg[2] = __builtin_amdgcn_raw_buffer_load_b128(rs.ql, rs.va0, so, 0);
+        if (kStageA1) {
+            rg[1] = __builtin_amdgcn_raw_buffer_load_b128(rs.qh, rs.va1, so, 0);
+            rg[3] = __builtin_amdgcn_raw_buffer_load_b128(rs.ql, rs.va1, so, 0);
+        }
+        rg[4] = __builtin_amdgcn_raw_buffer_load_b128(rs.bh, rs.vb0, so, 0);
+        rg[5] = __builtin_amdgcn_raw_buffer_load_b128(rs.bh, rs.vb1, so, 0);
+        if (BANK_LO) {
+            rg[6] = __builtin_amdgcn_raw_buffer_load_b128(rs.bl, rs.vb0, so, 0);
+            rg[7] = __builtin_amdgcn_raw_buffer_load_b128(rs.bl, rs.vb1, so, 0);
+        }
+    };
+    auto stage = [&](int buf) {
+        _Float16* L = sm.stage + buf * MS_BUF + wofs;
+        *reinterpret_cast<mu32x4*>(L + P_AHI) = rg[0];
+        *reinterpret_cast<mu32x4*>(L + P_ALO) = rg[2];
+        if (kStageA1) {
+            *reinterpret_cast<mu32x4*>(L + P_AHI + 128 * MS_BK) = rg[1];
+            *reinterpret_cast<mu32x4*>(L + P_ALO + 128 * MS_BK) = rg[3];
+        }
+        *reinterpret_cast<mu32x4*>(L + P_BHI) = rg[4];
+        *reinterpret_cast<mu32x4*>(L + P_BHI + 128 * MS_BK) = rg[5];
+        if (BANK_LO) {
+            *reinterpret_cast<mu32x4*>(L + P_BLO) = rg[6];
+            *reinterpret_cast<mu32x4*>(L + P_BLO + 128 * MS_BK) = rg[7];
+        }
+    };
+    // fragment addressing (rows of the wave tile 64 x 128, XOR-swizzled 16-byte chunks)
+    const int ar_ = 64 * wr + (lane & 31), br_ = 128 * wc + (lane & 31), kh_ = lane >> 5;
+    const int arow = ar_ * MS_BK, brow = br_ * MS_BK;
+    const int ak0 = ((kh_ ^ ((ar_ >> 2) & 3)) << 3), ak1 = (((kh_ + 2) ^ ((ar_ >> 2) & 3)) << 3);
+    const int bk0 = ((kh_ ^ ((br_ >> 2) & 3)) << 3), bk1 = (((kh_ + 2) ^ ((br_ >> 2) & 3)) << 3);
+    gload(0);
+    stage(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ns > 1) gload(1);
+    __syncthreads();
+
+#define M_MFMA(A_, B_, mi, ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[mi], B_[ni], acc[mi][ni], 0, 0, 0)
+#define M_ALL(A_, B_)                                       \
+    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)       \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) M_MFMA(A_, B_, mi, ni)
+    auto c_phase = [&](int s) __attribute__((always_inline)) {
+        const _Float16* L = sm.stage + (s & 1) * MS_BUF;
+        __builtin_amdgcn_s_setprio(1);  // before the fragment reads: they must not queue behind the other group's staging
+        h16x8 ah[MI], al[MI], bh[NI], bl[NI], ch[MI], cl[MI], dh[NI], dl[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) ah[mi] = *reinterpret_cast<const h16x8*>(L + P_AHI + arow + mi * 32 * MS_BK + ak0);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bh[ni] = *reinterpret_cast<const h16x8*>(L + P_BHI + brow + ni * 32 * MS_BK + bk0);
+        if (BANK_LO) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bl[ni] = *reinterpret_cast<const h16x8*>(L + P_BLO + brow + ni * 32 * MS_BK + bk0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) al[mi] = *reinterpret_cast<const h16x8*>(L + P_ALO + arow + mi * 32 * MS_BK + ak0);
+        M_ALL(ah, bh);
+        if (BANK_LO) { M_ALL(ah, bl); }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) ch[mi] = *reinterpret_cast<const h16x8*>(L + P_AHI + arow + mi * 32 * MS_BK + ak1);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) dh[ni] = *reinterpret_cast<const h16x8*>(L + P_BHI + brow + ni * 32 * MS_BK + bk1);
+        M_ALL(al, bh);
+        if (BANK_LO) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) dl[ni] = *reinterpret_cast<const h16x8*>(L + P_BLO + brow + ni * 32 * MS_BK + bk1);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) cl[mi] = *reinterpret_cast<const h16x8*>(L + P_ALO + arow + mi * 32 * MS_BK + ak1);
+        M_ALL(ch, dh);
+        if (BANK_LO) { M_ALL(ch, dl); }
+        M_ALL(cl, dh);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto m_phase = [&](int slab) __attribute__((always_inline)) {  // stages `slab`, loads slab + 1
+        if (slab < ns) stage(slab & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        gload(min(slab + 1, ns - 1));  // unconditional (the last ones re-load an L2-hot slab, unused)
+    };
+    //     waves 0-3:  C0 M1 | C1 M2 | ...          waves 4-7:  M1 C0 | M2 C1 | ...        (| = the one barrier per k-step)
+    if (grp) m_phase(1);
+    for (int s = 0; s < ns; ++s) {
+        c_phase(s);
+        if (grp && s + 1 < ns) __syncthreads();
+        m_phase(s + 1 + grp);
+        if (!grp && s + 1 < ns) __syncthreads();
+    }
+#undef M_ALL
+#undef M_MFMA
+}
 
 template <bool BANK_LO, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
@@ -314,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     const _Float16* __restrict__ b_hi, const _Float16* __restrict__ b_lo,  // (O*N, 256, C)
     const float* __restrict__ qmask, const float* __restrict__ bmask, const int* __restrict__ labels, int B, int O, int N, int C,
     float thr, float patch_thr, int* __restrict__ status, uint8_t* __restrict__ idx_t2s, float* __restrict__ score_t2s,
-    float* __restrict__ mask_all, float* __restrict__ sim_avg, unsigned long long* __restrict__ trace_all)
+    float* __restrict__ mask_all, float* __restrict__ sim_avg, unsigned long long* __restrict__ trace_all, int compact)
 {
     __shared__ MatchSplitSmem sm;
     const unsigned long long w_in = TRACE ? wall_clock64() : 0;
@@ -341,46 +496,62 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
         lab = 0;
     }
     const size_t on = (size_t)lab * N + n;
-    if (tid < GP_P) sm.qmask[tid] = qmask[(size_t)b * GP_P + tid];
-    else sm.smask[tid - GP_P] = bmask[on * GP_P + (tid - GP_P)];
+
+    // ---- the live patches of this tile, ranked: threads 0..255 = query patches, 256..511 = template patches
+    const int pidx = tid & 255;
+    const float mv = tid < GP_P ? qmask[(size_t)b * GP_P + pidx] : bmask[on * GP_P + pidx];
+    const bool live = compact ? (mv != 0.f) : true;  // compact = 0 (A/B hook): every patch counts as live = the full 2 x 4 tile
+    const unsigned long long bal = __ballot(live);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) sm.cnt[wave] = __popcll(bal);
+    if (tid < GP_P) {
+        sm.qmask[pidx] = mv;
+        sm.qmask_p[pidx] = 0.f;
+        sm.t_of[pidx] = (short)kDeadPatch;
+        sm.rowv[0][pidx] = 0.f; sm.rowv[1][pidx] = 0.f;
+        sm.rowi[0][pidx] = 0; sm.rowi[1][pidx] = 0;
+    } else {
+        sm.smask[pidx] = mv;
+        sm.smask_p[pidx] = 0.f;
+        sm.s_of[pidx] = (short)kDeadPatch;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { sm.colv[w][pidx] = 0.f; sm.coli[w][pidx] = 0; }
+    }
+    __syncthreads();
+    int rank = before;
+    for (int w = 4 * grp; w < wave; ++w) rank += sm.cnt[w];
+    if (live) {
+        const int blk = rank >> 5, within = rank & 31;
+        if (tid < GP_P) {   // row blocks dealt to the wave rows: block rb -> (wr = rb % 4, mi = rb / 4)
+            const int R = 64 * (blk & 3) + 32 * (blk >> 2) + within;
+            sm.t_of[R] = (short)pidx;
+            sm.qmask_p[R] = mv;
+        } else {            // column blocks dealt to the wave columns: block cb -> (wc = cb % 2, ni = cb / 2)
+            const int R = 128 * (blk & 1) + 32 * (blk >> 1) + within;
+            sm.s_of[R] = (short)pidx;
+            sm.smask_p[R] = mv;
+        }
+    }
+    __syncthreads();
+    const int live_t = sm.cnt[0] + sm.cnt[1] + sm.cnt[2] + sm.cnt[3], live_s = sm.cnt[4] + sm.cnt[5] + sm.cnt[6] + sm.cnt[7];
+    const int MIr = (((live_t + 31) >> 5) + 3) >> 2, NIr = (((live_s + 31) >> 5) + 1) >> 1;  // matrix tiles per wave: 0..2 x 0..4
 
     // staging: thread = (row tid >> 2 [+128], 16-byte k-chunk tid & 3) of each plane; one descriptor per plane of THIS tile
     const unsigned plane_bytes = (unsigned)GP_P * (unsigned)C * 2u;
-    const __amdgpu_buffer_rsrc_t r_qh = __builtin_amdgcn_make_buffer_rsrc((void*)(q_hi + (size_t)b * GP_P * C), 0, plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_ql = __builtin_amdgcn_make_buffer_rsrc((void*)(q_lo + (size_t)b * GP_P * C), 0, plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_bh = __builtin_amdgcn_make_buffer_rsrc((void*)(b_hi + on * GP_P * C), 0, plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_bl = __builtin_amdgcn_make_buffer_rsrc((void*)((BANK_LO ? b_lo : b_hi) + on * GP_P * C), 0, plane_bytes, 0x00020000);
-    const unsigned voff = (unsigned)(tid >> 2) * (unsigned)C * 2u + (unsigned)(tid & 3) * 16u;
-    const unsigned half_rows = 128u * (unsigned)C * 2u;
-    const int wofs = (tid >> 2) * MS_BK + (((tid & 3) ^ (((tid >> 2) >> 2) & 3)) << 3);
-    constexpr int P_AHI = 0, P_ALO = MS_PLANE, P_BHI = 2 * MS_PLANE, P_BLO = 3 * MS_PLANE, MS_BUF = 4 * MS_PLANE;
-    mu32x4 rg[8];
-    auto gload = [&](int slab) {
-        const unsigned so = (unsigned)slab * (MS_BK * 2u);
-        rg[0] = __builtin_amdgcn_raw_buffer_load_b128(r_qh, voff, so, 0);
-        rg[1] = __builtin_amdgcn_raw_buffer_load_b128(r_qh, voff, so + half_rows, 0);
-        rg[2] = __builtin_amdgcn_raw_buffer_load_b128(r_ql, voff, so, 0);
-        rg[3] = __builtin_amdgcn_raw_buffer_load_b128(r_ql, voff, so + half_rows, 0);
-        rg[4] = __builtin_amdgcn_raw_buffer_load_b128(r_bh, voff, so, 0);
-        rg[5] = __builtin_amdgcn_raw_buffer_load_b128(r_bh, voff, so + half_rows, 0);
-        if (BANK_LO) {
-            rg[6] = __builtin_amdgcn_raw_buffer_load_b128(r_bl, voff, so, 0);
-            rg[7] = __builtin_amdgcn_raw_buffer_load_b128(r_bl, voff, so + half_rows, 0);
-        }
-    };
-    auto stage = [&](int buf) {
-        _Float16* L = sm.stage + buf * MS_BUF + wofs;
-        *reinterpret_cast<mu32x4*>(L + P_AHI) = rg[0];
-        *reinterpret_cast<mu32x4*>(L + P_AHI + 128 * MS_BK) = rg[1];
-        *reinterpret_cast<mu32x4*>(L + P_ALO) = rg[2];
-        *reinterpret_cast<mu32x4*>(L + P_ALO + 128 * MS_BK) = rg[3];
-        *reinterpret_cast<mu32x4*>(L + P_BHI) = rg[4];
-        *reinterpret_cast<mu32x4*>(L + P_BHI + 128 * MS_BK) = rg[5];
-        if (BANK_LO) {
-            *reinterpret_cast<mu32x4*>(L + P_BLO) = rg[6];
-            *reinterpret_cast<mu32x4*>(L + P_BLO + 128 * MS_BK) = rg[7];
-        }
-    };
+    MatchSplitRsrc rs;
+    rs.qh = __builtin_amdgcn_make_buffer_rsrc((void*)(q_hi + (size_t)b * GP_P * C), 0, plane_bytes, 0x00020000);
+    rs.ql = __builtin_amdgcn_make_buffer_rsrc((void*)(q_lo + (size_t)b * GP_P * C), 0, plane_bytes, 0x00020000);
+    rs.bh = __builtin_amdgcn_make_buffer_rsrc((void*)(b_hi + on * GP_P * C), 0, plane_bytes, 0x00020000);
+    rs.bl = __builtin_amdgcn_make_buffer_rsrc((void*)((BANK_LO ? b_lo : b_hi) + on * GP_P * C), 0, plane_bytes, 0x00020000);
+    {
+        const int r0 = tid >> 2, r1 = r0 + 128;
+        const unsigned ck = (unsigned)(tid & 3) * 16u, rowb = (unsigned)C * 2u;
+        const int t0 = sm.t_of[r0], t1 = sm.t_of[r1], s0 = sm.s_of[r0], s1 = sm.s_of[r1];
+        rs.va0 = t0 != kDeadPatch ? (unsigned)t0 * rowb + ck : kMatchOob;
+        rs.va1 = t1 != kDeadPatch ? (unsigned)t1 * rowb + ck : kMatchOob;
+        rs.vb0 = s0 != kDeadPatch ? (unsigned)s0 * rowb + ck : kMatchOob;
+        rs.vb1 = s1 != kDeadPatch ? (unsigned)s1 * rowb + ck : kMatchOob;
+    }
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -389,77 +560,18 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    // fragment addressing (rows of the wave tile 64 x 128, XOR-swizzled 16-byte chunks)
-    const int ar_ = 64 * wr + (lane & 31), br_ = 128 * wc + (lane & 31), kh_ = lane >> 5;
-    const int arow = ar_ * MS_BK, brow = br_ * MS_BK;
-    const int ak0 = ((kh_ ^ ((ar_ >> 2) & 3)) << 3), ak1 = (((kh_ + 2) ^ ((ar_ >> 2) & 3)) << 3);
-    const int bk0 = ((kh_ ^ ((br_ >> 2) & 3)) << 3), bk1 = (((kh_ + 2) ^ ((br_ >> 2) & 3)) << 3);
     const int ns = C / MS_BK;
-    gload(0);
-    stage(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (ns > 1) gload(1);
-    __syncthreads();
     if (TRACE && tid == 0) trace[1] = wall_clock64();
-
-#define M_MFMA(A_, B_, mi, ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[mi], B_[ni], acc[mi][ni], 0, 0, 0)
-    auto c_phase = [&](int s) __attribute__((always_inline)) {
-        const _Float16* L = sm.stage + (s & 1) * MS_BUF;
-        __builtin_amdgcn_s_setprio(1);  // before the fragment reads: they must not queue behind the other group's staging
-        h16x8 ah[2], al[2], bh[4], bl[4], ch[2], cl[2], dh[4], dl[4];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) ah[mi] = *reinterpret_cast<const h16x8*>(L + P_AHI + arow + mi * 32 * MS_BK + ak0);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) bh[ni] = *reinterpret_cast<const h16x8*>(L + P_BHI + brow + ni * 32 * MS_BK + bk0);
-        if (BANK_LO) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) bl[ni] = *reinterpret_cast<const h16x8*>(L + P_BLO + brow + ni * 32 * MS_BK + bk0);
+    if (MIr > 0 && NIr > 0) {  // uniform over the workgroup
+        const int sel = MIr * 8 + NIr;
+#define M_CASE(MI_, NI_) case MI_ * 8 + NI_: match_split_kloop<BANK_LO, MI_, NI_>(sm, acc, rs, ns, tid, lane, wr, wc, grp); break
+        switch (sel) {
+            M_CASE(1, 1); M_CASE(1, 2); M_CASE(1, 3); M_CASE(1, 4);
+            M_CASE(2, 1); M_CASE(2, 2); M_CASE(2, 3);
+            default: match_split_kloop<BANK_LO, 2, 4>(sm, acc, rs, ns, tid, lane, wr, wc, grp); break;
         }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) al[mi] = *reinterpret_cast<const h16x8*>(L + P_ALO + arow + mi * 32 * MS_BK + ak0);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) { M_MFMA(ah, bh, 0, ni); M_MFMA(ah, bh, 1, ni); }
-        if (BANK_LO) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) { M_MFMA(ah, bl, 0, ni); M_MFMA(ah, bl, 1, ni); }
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) ch[mi] = *reinterpret_cast<const h16x8*>(L + P_AHI + arow + mi * 32 * MS_BK + ak1);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) dh[ni] = *reinterpret_cast<const h16x8*>(L + P_BHI + brow + ni * 32 * MS_BK + bk1);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) { M_MFMA(al, bh, 0, ni); M_MFMA(al, bh, 1, ni); }
-        if (BANK_LO) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) dl[ni] = *reinterpret_cast<const h16x8*>(L + P_BLO + brow + ni * 32 * MS_BK + bk1);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) cl[mi] = *reinterpret_cast<const h16x8*>(L + P_ALO + arow + mi * 32 * MS_BK + ak1);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) { M_MFMA(ch, dh, 0, ni); M_MFMA(ch, dh, 1, ni); }
-        if (BANK_LO) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) { M_MFMA(ch, dl, 0, ni); M_MFMA(ch, dl, 1, ni); }
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) { M_MFMA(cl, dh, 0, ni); M_MFMA(cl, dh, 1, ni); }
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto m_phase = [&](int slab) __attribute__((always_inline)) {  // stages `slab`, loads slab + 1
-        if (slab < ns) stage(slab & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        gload(min(slab + 1, ns - 1));  // unconditional (the last ones re-load an L2-hot slab, unused)
-    };
-    //     waves 0-3:  C0 M1 | C1 M2 | ...          waves 4-7:  M1 C0 | M2 C1 | ...        (| = the one barrier per k-step)
-    if (grp) m_phase(1);
-    for (int s = 0; s < ns; ++s) {
-        c_phase(s);
-        if (grp && s + 1 < ns) __syncthreads();
-        m_phase(s + 1 + grp);
-        if (!grp && s + 1 < ns) __syncthreads();
+#undef M_CASE
     }
-#undef M_MFMA
     __syncthreads();  // the epilogue reuses nothing of `stage`, but its first LDS writes must follow every wave's mask reads
     if (TRACE && tid == 0) trace[2] = wall_clock64();
 
@@ -470,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= inv;
-    match_epilogue(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg, trace);
+    match_epilogue<true>(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg, trace);
 }
 
 // norms of gp_l2norm_cp (same sequential fma over c), then x / d * 32 split into f16 planes [row][patch][C].
@@ -633,6 +745,8 @@ int gp_l2norm_split(const float* x, void* hi, void* lo, int rows, int C, void* s
     return GP_OK;
 }
 
+static int g_match_compact = 1;  // 0: every patch treated as live = the full 256 x 256 tile (A/B hook: gp_match_split_set_compact)
+
 static int match_tiles_split_launch(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
                                     const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
                                     float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
@@ -649,7 +763,7 @@ static int match_tiles_split_launch(const void* q_hi, const void* q_lo, const vo
     hipLaunchKernelGGL((match_tiles_split_kernel<LO, TR>), dim3(xcd_chunked_grid(B * N)), dim3(512), 0, (hipStream_t)stream,      \
                        (const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)b_hi, (const _Float16*)b_lo, qmask, bmask,  \
                        labels, B, O, N, C, sim_threshold, patch_threshold, gp_status_buffer(), idx_t2s, score_t2s, mask_all,      \
-                       sim_avg, trace)
+                       sim_avg, trace, g_match_compact)
     if (trace) {
         GP_REQUIRE(b_lo, "gp_match_tiles_split_trace: the probe build takes the two-plane bank");
         GP_MATCH_SPLIT_LAUNCH(true, true);
@@ -682,6 +796,12 @@ int gp_match_tiles_split_trace(const void* q_hi, const void* q_lo, const void* b
     GP_REQUIRE(trace, "gp_match_tiles_split_trace: null trace buffer");
     return match_tiles_split_launch(q_hi, q_lo, b_hi, b_lo, qmask, bmask, labels, B, O, N, C, sim_threshold, patch_threshold,
                                     idx_t2s, score_t2s, mask_all, sim_avg, trace, stream);
+}
+
+int gp_match_split_set_compact(int on)
+{
+    g_match_compact = on ? 1 : 0;
+    return GP_OK;
 }
 
 int gp_topk(const float* sim_avg, int B, int N, int k, int* ids, float* scores, void* stream)

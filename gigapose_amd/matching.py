@@ -123,6 +123,8 @@ class LocalSimilarity(torch.nn.Module):
         ma = torch.empty(B, N, P, dtype=torch.float32, device=dev)
         avg = torch.empty(B, N, dtype=torch.float32, device=dev)
         if split:
+            if "GIGAPOSE_MATCH_COMPACT" in os.environ:   # A/B probe: 0 = full 256 x 256 tiles (masked-out patches computed as zeros)
+                _lib.lib().gp_match_split_set_compact(int(os.environ["GIGAPOSE_MATCH_COMPACT"]))
             _lib.call("gp_match_tiles_split", _lib.ptr(query[0]), _lib.ptr(query[1]), _lib.ptr(bank.hi), _lib.ptr(bank.lo),
                       _lib.ptr(qmask), _lib.ptr(bank.masks), _lib.ptr(labels0), _lib.i(B), _lib.i(bank.O), _lib.i(N),
                       _lib.i(C), _lib.f(self.sim_threshold), _lib.f(self.patch_threshold), _lib.ptr(idx), _lib.ptr(sc),

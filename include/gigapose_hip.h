@@ -103,6 +103,9 @@ int gp_match_tiles_split_trace(const void* q_hi, const void* q_lo, const void* b
 
 /* torch.topk(sim_avg, k, dim=1) (matching.py:279); ties: lower template index first.
  * Fails (-1) when k > N, like torch.topk raises. ids int32 (B,k), scores (B,k). */
+/* A/B hook of gp_match_tiles_split: 1 (default) = tiles are built from the live (mask != 0) patches only, block-cyclically dealt
+ * to the waves, 1..2 x 1..4 matrix tiles per wave; 0 = every patch counts as live (the full 2 x 4).  Outputs are bit-identical. */
+int gp_match_split_set_compact(int on);
 int gp_topk(const float* sim_avg, int B, int N, int k, int* ids, float* scores, void* stream);
 
 /* Gather the per-patch records of the selected templates (matching.py:282-285):

@@ -53,10 +53,11 @@ def gen_matcher():
 BIG_MATCHER_CASES = [
     ("match_cfg2", dict(seed=21, B=64, O=1, N=162, C=1024), 5),     # ViT-L width, 1 object x 162 templates, 64 crops
     ("match_cfg3", dict(seed=22, B=64, O=8, N=162, C=1024), 5),     # LM-O shape: 8 objects, labels mixed
+    ("match_cfg5", dict(seed=23, B=64, O=40, N=162, C=1024), 5),    # BASELINE config 5: 40 objects x 162 templates (6.8 GB of f32 features)
 ]
 
 
-def gen_matcher_big():
+def gen_matcher_big(only=None):
     """LocalSimilarity.test of the unmodified reference at the benchmark sizes.  The reference chunks detections
     itself (matching.py:201-214) and concatenates, so calling it on 8 detections at a time (to bound the
     gathered-bank copy, 1.36 GB per 8) gives exactly what one call would."""
@@ -65,6 +66,8 @@ def gen_matcher_big():
 
     torch.set_num_threads(8)
     for name, kw, k in BIG_MATCHER_CASES:
+        if only is not None and name not in only:
+            continue
         case = syn.matcher_case(**kw)
         metric = LocalSimilarity(k=k, sim_threshold=0.5, patch_threshold=3)
         labels = torch.from_numpy(case["labels"]).long()
@@ -386,7 +389,7 @@ def gen_bop_csv():
 
 
 STAGES = {"bop_csv": gen_bop_csv, "val": gen_val, "matcher": gen_matcher, "ist": gen_ist, "pose": gen_pose, "e2e": gen_e2e, "crop": gen_crop,
-          "matcher_big": gen_matcher_big, "e2e_cfg2": lambda: gen_e2e("e2e_cfg2"), "e2e_cfg3": lambda: gen_e2e("e2e_cfg3"),
+          "matcher_big": lambda: gen_matcher_big(["match_cfg2", "match_cfg3"]), "matcher_cfg5": lambda: gen_matcher_big(["match_cfg5"]), "e2e_cfg2": lambda: gen_e2e("e2e_cfg2"), "e2e_cfg3": lambda: gen_e2e("e2e_cfg3"),
           "e2e_cfg2_f64": lambda: gen_e2e_f64("e2e_cfg2"), "e2e_cfg3_f64": lambda: gen_e2e_f64("e2e_cfg3"), "e2e_f64": lambda: gen_e2e_f64("e2e")}
 
 if __name__ == "__main__":

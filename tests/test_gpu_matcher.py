@@ -164,3 +164,57 @@ def test_val_matches_reference_golden_and_oracle(golden_dir, numerics, monkeypat
     if numerics == "chain":
         ref = oracle.local_similarity_val(case["src_feats"][case["labels"], 0], case["tar_feat"], case["src_masks"][case["labels"], 0], case["tar_mask"])
         np.testing.assert_array_equal(out.score.cpu().numpy().view(np.uint32), ref["score"].view(np.uint32))
+
+
+@pytest.mark.parametrize("C", [64, 1024])
+def test_split_matcher_live_patch_compaction_is_bit_identical(C):
+    """The split matcher builds its tile from the live (mask != 0) patches only (gp_match.hip: 1..2 x 1..4 matrix tiles per wave
+    instead of always 2 x 4).  Masks of every size -- empty, a single patch, patch 0 only, 31 / 32 / 33 / 64 / 65 / 127 / 128 / 129 /
+    255 live patches, full, fractional values -- on both sides: every output must equal the uncompacted launch bit for bit
+    (scores and sim_avg included)."""
+    import ctypes  # noqa: F401
+
+    from gigapose_amd import _lib
+    from gigapose_amd.matching import LocalSimilarity, MatchBank, normalize_split
+
+    rs = np.random.RandomState(5)
+    counts = [0, 1, 31, 32, 33, 64, 65, 127, 128, 129, 160, 255, 256]
+    O, N, B = 1, len(counts), len(counts) + 2
+    feats = torch.from_numpy(syn._unit(rs.standard_normal((O * N + B, C, 256)).astype(np.float32), 1)).to(DEV)
+    # planted similar patches so that thresholds pass and exact ties between columns exist (duplicated template patches)
+    feats[O * N:] = feats[:1] * 0.9 + 0.1 * feats[O * N:]
+    feats[1:O * N] = feats[:1] * 0.8 + 0.2 * feats[1:O * N]
+    feats[:O * N, :, 7] = feats[:O * N, :, 200]
+
+    def masks(rows):
+        m = np.zeros((rows, 256), np.float32)
+        for r in range(rows):
+            c = counts[r % len(counts)]
+            m[r, rs.permutation(256)[:c]] = 1.0
+        return m
+
+    bm, qm = masks(O * N), masks(B)
+    bm[2] = 0; bm[2, 0] = 1.0                      # only patch 0 (the "no match" sentinel) live
+    qm[B - 1] = rs.rand(256).astype(np.float32)    # fractional mask values multiply the similarity (matching.py:234-235)
+    qm[B - 2] = 1.0
+    metric = LocalSimilarity(k=5, sim_threshold=0.5, patch_threshold=3)
+    metric.numerics = "split"
+    bank = MatchBank.__new__(MatchBank)
+    bank.numerics, bank.bank_dtype, bank.O, bank.N, bank.C, bank.features = "split", "f32", O, N, C, None
+    hi, lo = normalize_split(feats[:O * N])
+    bank.hi, bank.lo = hi.view(O, N, 256, -1), lo.view(O, N, 256, -1)
+    bank.masks = torch.from_numpy(bm).to(DEV).view(O, N, 256)
+    q = normalize_split(feats[O * N:])
+    qmask = torch.from_numpy(qm).to(DEV)
+    labels0 = torch.zeros(B, dtype=torch.int32, device=DEV)
+    lib = _lib.lib()
+    try:
+        lib.gp_match_split_set_compact(0)
+        full = [t.clone() for t in metric.match_tiles(q, qmask, bank, labels0)]
+    finally:
+        lib.gp_match_split_set_compact(1)
+    comp = metric.match_tiles(q, qmask, bank, labels0)
+    for name, a, b in zip(["idx", "score", "mask", "sim_avg"], full, comp):
+        assert torch.equal(a, b), f"{name} differs between the compacted and the full tile"
+    assert (full[2].sum() > 50) and (full[2].sum(-1) > 0).any(), "the case exercises no valid correspondence"
+    print(f"compaction C={C}: {int(full[2].sum())} valid correspondences over {B * N} tiles, all outputs bit-identical")

@@ -21,6 +21,7 @@ void gp_set_error(const char* fmt, ...)
 namespace {
 struct Rec { hipEvent_t a, b; int kind; double work; };
 bool g_prof = false;
+int g_prof_only = -1, g_prof_stride = 1, g_prof_seen = 0;  // sampled mode: only launches of one kind, one in `stride`
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t get_event()
@@ -37,6 +38,7 @@ const char* kKindNames[GP_PROF_KINDS] = {"gemm_kmajor", "match_tiles", "attentio
 GpProfScope::GpProfScope(int kind, double work, hipStream_t st) : idx_(-1), st_(st)
 {
     if (!g_prof) return;
+    if (g_prof_only >= 0 && (kind != g_prof_only || (g_prof_seen++ % g_prof_stride) != 0)) return;
     Rec r{get_event(), get_event(), kind, work};
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
@@ -52,7 +54,15 @@ void gp_prof_begin(void)
 {
     for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
     g_recs.clear();
+    g_prof_only = -1;
     g_prof = true;
+}
+void gp_prof_begin_sampled(int kind, int stride)
+{
+    gp_prof_begin();
+    g_prof_only = kind;
+    g_prof_stride = stride > 0 ? stride : 1;
+    g_prof_seen = 0;
 }
 int gp_prof_end(int max_kinds, double* ms, double* work, long long* launches)
 {

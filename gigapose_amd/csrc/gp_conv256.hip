@@ -384,6 +384,374 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3 x 3 / stride 1 / pad 1 convolutions with the activation HALO resident in LDS (round 3).
+//
+// conv_planes_kernel gathers its A operand once per k-step (one tap x 32 channels): every input pixel is fetched nine
+// times per output tile and its k loop runs at the round trip of loads issued one step ahead -- 1.3-1.5 us per step
+// against 0.95 us of matrix work at Cout = 128 (profiles/r02_conv_timeline.txt).  Here a tile is a 16 x 16 BLOCK of
+// output pixels and the k order is channel-block major: for each block of 32 input channels the 18 x 18 pixel halo of
+// the tile (324 rows of 64 bytes per plane, zeros outside the image through the descriptor's range check) is staged
+// ONCE and the nine taps are nine k-steps whose A fragments are read from it at shifted rows; only the weights (16-32 KB
+// per step, L2-resident) are staged per step.  The halo of the next channel block arrives during the first taps of the
+// current one (two halo buffers).  Global -> LDS bytes per k-step at Cout = 128: 48 KB -> 20.6 KB.
+// Same wave layout (4 x 2 waves, wave tile 64 pixels x 32 NI channels), same two-group half-step offset with one barrier per
+// step, same epilogue and hand-over scheme as conv_planes_kernel; stream-K units are channel blocks (9 steps each).
+// Per output the products are those of conv_planes_kernel summed in the order (channel block, tap) instead of (tap, channel
+// block): results agree to f32 round-off, not bit for bit (tests: both against float64).
+constexpr int HPX = 18 * 18;                 // halo pixels of a 16 x 16 output block
+constexpr int HPLANE = HPX * CROW;           // halfs per halo plane (64-byte rows)
+constexpr int HBUF = 2 * HPLANE;             // hi + lo
+
+__device__ __forceinline__ int hoff(int hp, int kc) { return hp * CROW + ((kc ^ ((hp >> 2) & 3)) << 3); }
+
+template <int NI>
+__global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
+{
+    constexpr int NIW = NI, JT = 64 * NI;
+    constexpr int BH = NI > 2 ? 2 : 1;             // weight rows each thread stages per step (rows srow + 128 h of 64 NI)
+    constexpr int WROWS = 64 * NI;
+    constexpr int WPLANE = WROWS * CROW, WBUF = 2 * WPLANE;   // halfs
+    constexpr int LDS_HALFS = 2 * HBUF + 2 * WBUF;            // 2 halo + 2 weight buffers
+    constexpr int EPI_STRIDE = 32 * 32 * NI * 4;              // bytes of a wave's epilogue region (32 rows x 32 NI f32)
+    static_assert(LDS_HALFS * 2 >= 8 * EPI_STRIDE, "the epilogue regions must fit the operand buffers");
+    __shared__ __attribute__((aligned(16))) _Float16 lds[LDS_HALFS];
+    _Float16* const Hb = lds;
+    _Float16* const Wb = lds + 2 * HBUF;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, grp = wave >> 2;
+
+    // ---- this slot's range of (tile, channel-block) units inside its XCD's tile chunk (conv_planes_kernel's scheme)
+    const int p = blockIdx.x, x = p & 7, n = p >> 3, slots_x = gridDim.x >> 3;
+    const int T = a.tiles_i * a.tiles_j;
+    const int t_lo = (int)((long long)T * x / 8), n_t = (int)((long long)T * (x + 1) / 8) - t_lo;
+    const int ncb = a.Cin / CBK;
+    const int rounds_dp = (n_t / slots_x > 1) ? n_t / slots_x - 1 : 0;
+    const int n_dp = rounds_dp * slots_x;
+    const long long U = (long long)(n_t - n_dp) * ncb;
+    const long long u0 = U * n / slots_x, u1 = U * (n + 1) / slots_x;
+    const int ta = (int)(u0 / ncb), sa = (int)(u0 % ncb);
+    const int tb = (int)(u1 / ncb), sb = (int)(u1 % ncb);
+    const int n_head = sb > 0 ? 1 : 0, n_rest = sa > 0 ? 1 : 0;
+    const int first_whole = ta + n_rest;
+    const int n_seg = rounds_dp + n_head + (tb - first_whole) + n_rest;
+
+    const unsigned x_bytes = (unsigned)a.B * a.H * a.W * a.Cin * 2u, w_bytes = (unsigned)a.Cout * a.K * 2u;
+    const __amdgpu_buffer_rsrc_t r_xhi = __builtin_amdgcn_make_buffer_rsrc((void*)a.xhi, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_xlo = __builtin_amdgcn_make_buffer_rsrc((void*)a.xlo, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_whi = __builtin_amdgcn_make_buffer_rsrc((void*)a.whi, 0, w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_wlo = __builtin_amdgcn_make_buffer_rsrc((void*)a.wlo, 0, w_bytes, 0x00020000);
+    const unsigned r_bytes = a.rhi ? (unsigned)a.B * a.OH * a.OW * a.Cout * 2u : 0u;
+    const __amdgpu_buffer_rsrc_t r_rhi = __builtin_amdgcn_make_buffer_rsrc((void*)a.rhi, 0, r_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rlo = __builtin_amdgcn_make_buffer_rsrc((void*)a.rlo, 0, r_bytes, 0x00020000);
+    const int srow = tid >> 2, schunk = tid & 3;
+    const int wofs = toff(srow, schunk);
+    const int nbx = a.OW >> 4, nby = a.OH >> 4, OHW = a.OH * a.OW;
+    cu32x4 rb_h[BH], rb_l[BH], rh_h, rh_l;
+    // fragment addressing: A rows = halo pixels of this lane's two output pixels, B rows as conv_planes_kernel
+    const int br_ = 32 * NIW * wc + (lane & 31), kh_ = lane >> 5;
+    const int brow = br_ * CROW;
+    const int bk0 = ((kh_ ^ ((br_ >> 2) & 3)) << 3), bk1 = (((kh_ + 2) ^ ((br_ >> 2) & 3)) << 3);
+    int hbase[2];  // halo index of output pixel (py, px) at tap (0, 0): py * 18 + px
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int pl = 64 * wr + 32 * mi + (lane & 31);
+        hbase[mi] = (pl >> 4) * 18 + (pl & 15);
+    }
+
+    unsigned long long tr_pro = 0, tr_loop = 0, tr_tail = 0, tr_steps = 0, tr_t0 = a.trace ? wall_clock64() : 0;
+    const unsigned long long tr_begin = tr_t0;
+    for (int seg = 0; seg < n_seg; ++seg) {
+        const bool is_dp = seg < rounds_dp;
+        const bool is_head = !is_dp && seg - rounds_dp < n_head;
+        const bool is_rest = !is_dp && n_rest && seg == n_seg - 1;
+        const int t = is_dp ? seg * slots_x + n : n_dp + (is_head ? tb : (is_rest ? ta : first_whole + seg - rounds_dp - n_head));
+        const int c0 = is_rest ? sa : 0, c1 = is_head ? sb : ncb;  // channel blocks [c0, c1)
+        const int q = t_lo + t;
+        const int ti = q / a.tiles_j, j0 = (q % a.tiles_j) * JT;    // j fastest: the co tiles of one pixel block are neighbours
+        const int b = ti / (nby * nbx), rb_ = ti - b * (nby * nbx);
+        const int by = rb_ / nbx, bx = rb_ - by * nbx;
+        const int pix00 = (b * a.OH + by * 16) * a.OW + bx * 16;    // output pixel (0, 0) of the block; (py, px) adds py * OW + px
+
+        // ---- halo items of this thread: item i = tid + 512 u (u < 3, i < 1296) = (halo pixel i >> 2, 16-byte chunk i & 3)
+        unsigned hvoff[3];
+        int hlds[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int i = tid + 512 * u, hp = i >> 2, ck = i & 3;
+            const int iy = by * 16 - 1 + hp / 18, ix = bx * 16 - 1 + hp % 18;
+            const bool ok = i < 4 * HPX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            hvoff[u] = ok ? (unsigned)(((b * a.H + iy) * a.W + ix) * a.Cin) * 2u + (unsigned)ck * 16u : kOob;
+            hlds[u] = i < 4 * HPX ? hoff(hp, ck) : -1;
+        }
+        // weights: rows j0 + srow (+128) of (Cout, K); rows past Cout read as zeros
+        unsigned wvoff[BH];
+#pragma unroll
+        for (int h = 0; h < BH; ++h) {
+            const int co = j0 + srow + 128 * h;
+            wvoff[h] = (srow + 128 * h < JT && co < a.Cout) ? (unsigned)co * (unsigned)a.K * 2u + (unsigned)schunk * 16u : kOob;
+        }
+
+        f32x16 acc[2][NIW];
+        if (is_rest) {
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(a.flags + (p - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > kSpin) {
+                        __hip_atomic_store(a.flags + kErrWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gp_raise(a.status, GP_ST_HANDOFF_SPLIT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            const f32x4* w = reinterpret_cast<const f32x4*>(a.partial + (size_t)(p - 8) * kFragFloats) + tid;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 v = w[((mi * 4 + ni) * 4 + r4) * CNT];
+                        acc[mi][ni][r4 * 4 + 0] = v[0]; acc[mi][ni][r4 * 4 + 1] = v[1];
+                        acc[mi][ni][r4 * 4 + 2] = v[2]; acc[mi][ni][r4 * 4 + 3] = v[3];
+                    }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
+
+        // ---- k loop: steps s = (cb - c0) * 9 + tap
+        const int ns = 9 * (c1 - c0);
+        auto wload = [&](int slab) {   // weights of step `slab` -> registers
+            const int cb = c0 + slab / 9, tap = slab - (slab / 9) * 9;
+            const unsigned sw = (unsigned)(tap * a.Cin + cb * CBK) * 2u;
+#pragma unroll
+            for (int h = 0; h < BH; ++h) {
+                rb_h[h] = __builtin_amdgcn_raw_buffer_load_b128(r_whi, wvoff[h], sw, 0);
+                rb_l[h] = __builtin_amdgcn_raw_buffer_load_b128(r_wlo, wvoff[h], sw, 0);
+            }
+        };
+        auto wstage = [&](int buf) {
+            _Float16* L = Wb + buf * WBUF + wofs;
+#pragma unroll
+            for (int h = 0; h < BH; ++h) {
+                if (BH == 1 || h == 0 || srow + 128 * h < WROWS) {
+                    *reinterpret_cast<cu32x4*>(L + 128 * h * CROW) = rb_h[h];
+                    *reinterpret_cast<cu32x4*>(L + WPLANE + 128 * h * CROW) = rb_l[h];
+                }
+            }
+        };
+        auto hload = [&](int cb, int u) {   // halo item u of channel block cb -> registers
+            const unsigned so = (unsigned)cb * (CBK * 2u);
+            rh_h = __builtin_amdgcn_raw_buffer_load_b128(r_xhi, hvoff[u], so, 0);
+            rh_l = __builtin_amdgcn_raw_buffer_load_b128(r_xlo, hvoff[u], so, 0);
+        };
+        auto hstage = [&](int buf, int u) {
+            if (hlds[u] >= 0) {
+                _Float16* L = Hb + buf * HBUF + hlds[u];
+                *reinterpret_cast<cu32x4*>(L) = rh_h;
+                *reinterpret_cast<cu32x4*>(L + HPLANE) = rh_l;
+            }
+        };
+        // prologue: the whole halo of channel block c0 and the weights of step 0
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            hload(c0, u);
+            hstage(c0 & 1, u);
+        }
+        wload(0);
+        wstage(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ns > 1) wload(1);
+        __syncthreads();
+        if (a.trace) { const unsigned long long t_ = wall_clock64(); tr_pro += t_ - tr_t0; tr_t0 = t_; tr_steps += ns; }
+
+#define C_MFMA(A_, B_, mi, ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[mi], B_[ni], acc[mi][ni], 0, 0, 0)
+        auto c_phase = [&](int s) __attribute__((always_inline)) {
+            const int cbr = s / 9, tap = s - cbr * 9;                  // wave-uniform
+            const int dy = tap / 3, tofs = dy * 18 + (tap - dy * 3);
+            const _Float16* LH = Hb + ((c0 + cbr) & 1) * HBUF;
+            const _Float16* LW = Wb + (s & 1) * WBUF;
+            __builtin_amdgcn_s_setprio(1);
+            int a0[2], a1[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int hp = hbase[mi] + tofs;
+                a0[mi] = hoff(hp, kh_);
+                a1[mi] = hoff(hp, kh_ + 2);
+            }
+            c16x8 ah[2], al[2], bh[NIW], bl[NIW], ch[2], cl[2], dh[NIW], dl[NIW];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) ah[mi] = *reinterpret_cast<const c16x8*>(LH + a0[mi]);
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni) bh[ni] = *reinterpret_cast<const c16x8*>(LW + brow + ni * 32 * CROW + bk0);
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni) bl[ni] = *reinterpret_cast<const c16x8*>(LW + WPLANE + brow + ni * 32 * CROW + bk0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) al[mi] = *reinterpret_cast<const c16x8*>(LH + HPLANE + a0[mi]);
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni) { C_MFMA(ah, bh, 0, ni); C_MFMA(ah, bh, 1, ni); }
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni) { C_MFMA(ah, bl, 0, ni); C_MFMA(ah, bl, 1, ni); }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) ch[mi] = *reinterpret_cast<const c16x8*>(LH + a1[mi]);
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni) dh[ni] = *reinterpret_cast<const c16x8*>(LW + brow + ni * 32 * CROW + bk1);
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni) { C_MFMA(al, bh, 0, ni); C_MFMA(al, bh, 1, ni); }
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni) dl[ni] = *reinterpret_cast<const c16x8*>(LW + WPLANE + brow + ni * 32 * CROW + bk1);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) cl[mi] = *reinterpret_cast<const c16x8*>(LH + HPLANE + a1[mi]);
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni) { C_MFMA(ch, dh, 0, ni); C_MFMA(ch, dh, 1, ni); }
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni) { C_MFMA(ch, dl, 0, ni); C_MFMA(ch, dl, 1, ni); }
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni) { C_MFMA(cl, dh, 0, ni); C_MFMA(cl, dh, 1, ni); }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // m_phase(slab): stages the weights of `slab` (loaded one phase earlier) and requests those of slab + 1; the halo of the NEXT
+        // channel block rides on the phases of taps 1..3 of the current one: item u requested in the phase of tap u + 1 (after the
+        // weights: vector-memory results return in order) and written to LDS in the phase of tap u + 2.  The halo buffer it goes
+        // to was last read in the previous channel block, whose final barrier every wave has passed.
+        auto m_phase = [&](int slab) __attribute__((always_inline)) {
+            const int cbr = slab / 9, tap = slab - cbr * 9;            // of the step being staged (wave-uniform)
+            const bool more = c0 + cbr + 1 < c1;                       // is there a next channel block to prefetch
+            if (slab < ns) {
+                if (more && tap >= 2 && tap <= 4) hstage((c0 + cbr + 1) & 1, tap - 2);
+                wstage(slab & 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            wload(min(slab + 1, ns - 1));
+            if (slab < ns && more && tap >= 1 && tap <= 3) hload(c0 + cbr + 1, tap - 1);
+        };
+        //     waves 0-3:  C0 M1 | C1 M2 | ...          waves 4-7:  M1 C0 | M2 C1 | ...        (| = the one barrier per k-step)
+        if (grp) m_phase(1);
+        for (int s = 0; s < ns; ++s) {
+            c_phase(s);
+            if (grp && s + 1 < ns) __syncthreads();
+            m_phase(s + 1 + grp);
+            if (!grp && s + 1 < ns) __syncthreads();
+        }
+#undef C_MFMA
+        if (a.trace) { const unsigned long long t_ = wall_clock64(); tr_loop += t_ - tr_t0; tr_t0 = t_; }
+
+        if (is_head) {  // publish the fragment for slot n + 1 (write-through stores, then the flag)
+            f32x4* w = reinterpret_cast<f32x4*>(a.partial + (size_t)p * kFragFloats) + tid;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        f32x4 v;
+                        v[0] = acc[mi][ni][r4 * 4 + 0]; v[1] = acc[mi][ni][r4 * 4 + 1];
+                        v[2] = acc[mi][ni][r4 * 4 + 2]; v[3] = acc[mi][ni][r4 * 4 + 3];
+                        w[((mi * 4 + ni) * 4 + r4) * CNT] = v;
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(a.flags + p, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();  // the next segment's prologue rewrites the operand buffers
+        } else {
+            // ---- epilogue through LDS (conv_planes_kernel's, with the block's pixel order)
+            int tid_ = threadIdx.x;
+            asm volatile("" : "+v"(tid_));
+            __syncthreads();  // every wave has read its last operand fragments
+            const int ln = tid_ & 63, l31 = ln & 31;
+            float* wl = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + (tid_ >> 6) * EPI_STRIDE);
+            constexpr int WC = 32 * NIW, QPR = 8 * NIW;
+            int bad = 0;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) wl[frag_row(r, ln) * WC + 32 * ni + l31] = acc[mi][ni][r];
+                constexpr int RG = NIW == 2 ? 8 : (NIW == 3 ? 6 : 4);
+#pragma unroll
+                for (int it0 = 0; it0 < 4 * NIW; it0 += RG) {
+                    cu32x2 rh[RG], rl[RG];
+                    if (a.rhi) {
+#pragma unroll
+                        for (int u = 0; u < RG; ++u) {
+                            const int f = (it0 + u) * 64 + ln, row = f / QPR, qd = f - row * QPR;
+                            const int pl = 64 * wr + 32 * mi + row, pix = pix00 + (pl >> 4) * a.OW + (pl & 15), co = j0 + WC * wc + 4 * qd;
+                            const unsigned ob = co < a.Cout ? ((unsigned)pix * (unsigned)a.Cout + (unsigned)co) * 2u : kOob;
+                            rh[u] = __builtin_amdgcn_raw_buffer_load_b64(r_rhi, ob, 0, 0);
+                            rl[u] = __builtin_amdgcn_raw_buffer_load_b64(r_rlo, ob, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < RG; ++u) {
+                        const int f = (it0 + u) * 64 + ln, row = f / QPR, qd = f - row * QPR;
+                        const f32x4 tv = *reinterpret_cast<const f32x4*>(wl + row * WC + 4 * qd);
+                        const int pl = 64 * wr + 32 * mi + row, pix = pix00 + (pl >> 4) * a.OW + (pl & 15), co = j0 + WC * wc + 4 * qd;
+                        if (co < a.Cout) {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = tv[e] * kOutScale;
+                            if (a.alpha) {
+                                const f32x4 al4 = *reinterpret_cast<const f32x4*>(a.alpha + co), be4 = *reinterpret_cast<const f32x4*>(a.beta + co);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = v[e] * al4[e] + be4[e];
+                            }
+                            const size_t o = (size_t)pix * a.Cout + co;
+                            if (a.rhi) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const c16x4 h4 = __builtin_bit_cast(c16x4, rh[u]), l4 = __builtin_bit_cast(c16x4, rl[u]);
+                                    v[e] = ((float)h4[e] + (float)l4[e]) * (1.0f / kActScale) + v[e];
+                                }
+                            }
+                            if (a.relu)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                            if (a.of32) {  // (B, Cout, OH, OW)
+                                const int bb = pix / OHW, rem = pix - bb * OHW;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) a.of32[((size_t)bb * a.Cout + co + e) * OHW + rem] = v[e];
+                            } else {
+                                c16x4 oh, ol;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float s8 = v[e] * kActScale;
+                                    const _Float16 hh = (_Float16)s8;
+                                    oh[e] = hh;
+                                    ol[e] = (_Float16)(s8 - (float)hh);
+                                    bad |= !(fabsf(s8) <= kSplitPlaneLimit);
+                                }
+                                *reinterpret_cast<c16x4*>(a.ohi + o) = oh;
+                                *reinterpret_cast<c16x4*>(a.olo + o) = ol;
+                            }
+                        }
+                    }
+                }
+            }
+            if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE_CONV);
+            __syncthreads();  // the operand buffers are re-staged by the next segment's prologue
+        }
+        if (a.trace) { const unsigned long long t_ = wall_clock64(); tr_tail += t_ - tr_t0; tr_t0 = t_; }
+    }
+    if (a.trace && tid == 0) {
+        unsigned long long* w = a.trace + (size_t)p * 8;
+        w[0] = n_seg; w[1] = tr_steps; w[2] = tr_pro; w[3] = tr_loop; w[4] = tr_tail; w[5] = tr_begin; w[6] = tr_t0;
+    }
+}
+
 // [C][npix] f32 (the f32 stem's channel-major output) -> planes [npix][C] of 8 x (hi + lo, unscaled lo).  32 x 32 tiles through LDS.
 __global__ __launch_bounds__(256) void planes_from_cm_kernel(const float* __restrict__ X, int C, int npix, _Float16* __restrict__ hi,
                                                               _Float16* __restrict__ lo, int* __restrict__ status)
@@ -463,6 +831,43 @@ int gp_planes_from_cm(const float* X, int C, int npix, void* hi, void* lo, void*
     return GP_OK;
 }
 
+static int g_conv_halo = 1;  // 0: gp_conv2d_planes never takes the halo kernel (A/B hook)
+int gp_conv2d_planes_set_halo(int on)
+{
+    g_conv_halo = on ? 1 : 0;
+    return GP_OK;
+}
+
+// 3 x 3 / stride 1 / pad 1 on 16 x 16 pixel blocks with the halo resident in LDS (conv_halo_kernel); same arguments and results
+// (to f32 round-off) as gp_conv2d_planes.  Needs H, W multiples of 16.
+static bool conv_halo_usable(int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad)
+{
+    return g_conv_halo && KH == 3 && KW == 3 && stride == 1 && pad == 1 && H % 16 == 0 && W % 16 == 0 && Cin % 32 == 0 && Cout % 64 == 0;
+}
+
+static int conv_halo_launch(ConvPArgs& a, float* scratch, hipStream_t st)
+{
+    const int ni = a.Cout >= 256 ? 4 : a.Cout / 64;
+    a.tiles_i = a.B * (a.OH / 16) * (a.OW / 16);
+    a.tiles_j = (a.Cout + 64 * ni - 1) / (64 * ni);
+    const int ncb = a.Cin / CBK;
+    const long long n_tiles = (long long)a.tiles_i * a.tiles_j, units = n_tiles * ncb * 9;
+    int slots_x = 32;
+    while (slots_x > 1 && n_tiles < 8 * slots_x && units / (8 * slots_x) < 32) slots_x >>= 1;
+    a.flags = reinterpret_cast<int*>(scratch);
+    a.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes);
+    g_epoch_conv = (g_epoch_conv + 1) & 0x3fffffff;
+    a.epoch = (int)(0x20000000u | g_epoch_conv);
+    a.status = gp_status_buffer();
+    const long long npix = (long long)a.B * a.OH * a.OW;
+    GpProfScope prof(GP_PROF_CONV, 2.0 * a.Cout * (double)npix * a.K, st);
+    if (ni == 2) hipLaunchKernelGGL(conv_halo_kernel<2>, dim3(8 * slots_x), dim3(CNT), 0, st, a);
+    else if (ni == 3) hipLaunchKernelGGL(conv_halo_kernel<3>, dim3(8 * slots_x), dim3(CNT), 0, st, a);
+    else hipLaunchKernelGGL(conv_halo_kernel<4>, dim3(8 * slots_x), dim3(CNT), 0, st, a);
+    GP_CHECK_LAUNCH("gp_conv2d_planes/halo");
+    return GP_OK;
+}
+
 int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* alpha, const float* beta,
                      const void* res_hi, const void* res_lo, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                      int relu, void* out_hi, void* out_lo, float* out_f32_nchw, float* scratch, size_t scratch_bytes, void* stream)
@@ -488,6 +893,7 @@ int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const
                    ((uintptr_t)alpha % 16 == 0) && ((uintptr_t)beta % 16 == 0), "gp_conv2d_planes: misaligned operand");
     a.stem = 0;
     a.trace = g_conv_trace;
+    if (conv_halo_usable(H, W, Cin, Cout, KH, KW, stride, pad)) return conv_halo_launch(a, scratch, (hipStream_t)stream);
     const int ni = Cout >= 256 ? 4 : Cout / 64;  // 128 -> 2, 192 -> 3, >= 256 -> 4
     a.tiles_i = (int)(npix / CT);
     a.tiles_j = (Cout + 64 * ni - 1) / (64 * ni);

@@ -169,6 +169,8 @@ class ResNet(nn.Module):
         need = lib.gp_conv2d_planes_workspace_bytes()
         if self._conv_scratch is None or self._conv_scratch.device != dev:
             self._conv_scratch = torch.zeros((need + 3) // 4, dtype=torch.float32, device=dev)
+        if "GIGAPOSE_CONV_HALO" in os.environ:   # A/B probe: 0 = every convolution through the per-tap gather kernel
+            lib.gp_conv2d_planes_set_halo(int(os.environ["GIGAPOSE_CONV_HALO"]))
         _lib.call("gp_conv2d_planes", _lib.ptr(x[0]), _lib.ptr(x[1]), _lib.ptr(w[0]), _lib.ptr(w[1]),
                   _lib.ptr(cv["alpha"]), _lib.ptr(cv["beta"]), _lib.ptr(None if residual is None else residual[0]),
                   _lib.ptr(None if residual is None else residual[1]), _lib.i(B), _lib.i(H), _lib.i(W), _lib.i(cv["cin"]),

@@ -299,6 +299,10 @@ int gp_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* w_hi, c
 size_t gp_conv2d_planes_workspace_bytes(void);
 void gp_conv2d_planes_set_trace(unsigned long long* device_buf); /* probe: per slot segments / k-steps / ticks, NULL = off */
 int gp_planes_from_cm(const float* X, int C, int npix, void* hi, void* lo, void* stream);
+/* 3 x 3 / stride 1 / pad 1 convolutions on images whose sides are multiples of 16 run conv_halo_kernel (16 x 16 pixel blocks whose
+ * 18 x 18 halo is staged in LDS once per 32 input channels; the nine taps read it at shifted rows) -- same arguments, results equal
+ * to conv_planes_kernel's to f32 round-off (summation order (channel block, tap) instead of (tap, channel block)).  0 = A/B hook. */
+int gp_conv2d_planes_set_halo(int on);
 int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* alpha, const float* beta,
                      const void* res_hi, const void* res_lo, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                      int relu, void* out_hi, void* out_lo, float* out_f32_nchw, float* scratch, size_t scratch_bytes, void* stream);

@@ -217,7 +217,11 @@ def planes8(t, scale=8.0):
     (128, 192, 1, 2, 0, 32, 4, False),    # 1 x 1 stride-2 shortcut, K = 128 (4 k-steps)
     (256, 512, 3, 2, 1, 32, 4, False),    # two co tiles (NI = 4), K = 2304; 8 tiles x 72 steps: few tiles -> cut into k ranges with hand-overs
     (512, 256, 1, 1, 0, 16, 4, False),    # the head: 1 x 1, f32 NCHW output too
-    (192, 192, 3, 1, 1, 64, 16, True),    # 256 tiles = one whole tile per slot, residual
+    (192, 192, 3, 1, 1, 64, 16, True),    # 256 tiles = one whole tile per slot, residual (halo kernel: 3 x 3 / stride 1 / multiples of 16)
+    (256, 256, 3, 1, 1, 32, 4, True),     # halo kernel, NI = 4, 8 channel blocks, residual
+    (512, 512, 3, 1, 1, 16, 8, False),    # halo kernel, two co tiles: 16 tiles x 16 channel blocks cut into ranges with hand-overs (layer4)
+    (128, 128, 3, 1, 1, 128, 1, True),    # halo kernel, one 128 x 128 image = 64 blocks: halo rows cross block borders, zeros at the image border
+    (32, 64, 3, 1, 1, 16, 2, False),      # halo kernel, a single channel block (no halo prefetch), Cout = 64 (one matrix column block)
 ])
 def test_conv_planes_vs_f64(cin, cout, k, stride, pad, hw, B, res):
     """gp_conv2d_planes (gp_conv256.hip) against an f64 convolution + BN + residual + ReLU: both outputs (planes, f32 NCHW)."""
@@ -255,6 +259,39 @@ def test_conv_planes_vs_f64(cin, cout, k, stride, pad, hw, B, res):
     print(f"conv planes {cin}->{cout} k{k} s{stride} {hw}x{hw} B={B}: max err / max|y| f32 out {np.abs(of32.cpu().numpy() - t).max() / tol:.2e}, planes {np.abs(got_planes - t).max() / tol:.2e}")
     np.testing.assert_allclose(of32.cpu().numpy(), t, rtol=0, atol=2e-6 * tol)
     np.testing.assert_allclose(got_planes, t, rtol=0, atol=3e-6 * tol)
+
+
+def test_conv_halo_kernel_matches_the_gather_kernel():
+    """3 x 3 / stride 1 convolutions take conv_halo_kernel (16 x 16 pixel blocks, halo in LDS, k order channel-block major); the
+    same launch through conv_planes_kernel (gp_conv2d_planes_set_halo(0): one gather per tap) must agree to f32 round-off."""
+    rs = np.random.RandomState(77)
+    lib = _lib.lib()
+    lib.gp_conv2d_planes_workspace_bytes.restype = ctypes.c_size_t
+    nb = lib.gp_conv2d_planes_workspace_bytes()
+    ws = torch.zeros(nb // 4, device=DEV)
+    for (cin, cout, hw, B) in [(128, 128, 64, 4), (192, 192, 32, 8), (512, 512, 16, 16)]:
+        X = torch.from_numpy(rs.standard_normal((B, hw, hw, cin)).astype(np.float32)).to(DEV)
+        Wt = torch.from_numpy((rs.standard_normal((cout, 9 * cin)) / np.sqrt(9 * cin)).astype(np.float32)).to(DEV)
+        al, be = torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV)
+        R = torch.randn(B, hw, hw, cout, device=DEV)
+        (xh, xl), (wh, wl), (rh, rl) = planes8(X), planes8(Wt, 64.0), planes8(R)
+        outs = []
+        for halo in (0, 1):
+            lib.gp_conv2d_planes_set_halo(halo)
+            of32 = torch.zeros(B, cout, hw, hw, device=DEV)
+            oh_, ol_ = torch.zeros(B, hw, hw, cout, dtype=torch.float16, device=DEV), torch.zeros(B, hw, hw, cout, dtype=torch.float16, device=DEV)
+            for o32 in (None, of32):
+                _lib.call("gp_conv2d_planes", _lib.ptr(xh), _lib.ptr(xl), _lib.ptr(wh), _lib.ptr(wl), _lib.ptr(al), _lib.ptr(be), _lib.ptr(rh), _lib.ptr(rl),
+                          _lib.i(B), _lib.i(hw), _lib.i(hw), _lib.i(cin), _lib.i(cout), _lib.i(3), _lib.i(3), _lib.i(1), _lib.i(1), _lib.i(1),
+                          _lib.ptr(oh_), _lib.ptr(ol_), _lib.ptr(o32), _lib.ptr(ws), ctypes.c_size_t(nb), _lib.stream_ptr())
+            outs.append((of32, oh_.float() + ol_.float()))
+        lib.gp_conv2d_planes_set_halo(1)
+        torch.cuda.synchronize()
+        _lib.check_status()
+        scale = outs[0][0].abs().max().item()
+        d32, dpl = (outs[0][0] - outs[1][0]).abs().max().item() / scale, (outs[0][1] - outs[1][1]).abs().max().item() / (8 * scale)
+        print(f"halo vs gather kernel {cin}->{cout} {hw}x{hw} B={B}: max |diff| / max|y| f32 {d32:.2e}, planes {dpl:.2e}")
+        assert d32 < 4e-6 and dpl < 4e-6   # each kernel is within 2e-6 / 3e-6 of float64 (test above)
 
 
 def test_ist_backbone_split_vs_chain_and_torch():

@@ -65,11 +65,15 @@ def run(cin, cout, k, stride, pad, hw, B, res, tall):
           f"k loop {loop.mean():7.1f} us = {loop.mean() / steps.mean():5.3f} us/step (matrix-only {nstep_mfma_us:5.3f}) | tail {tail.mean():6.1f} us ({tail.mean() / seg.mean():5.2f} each)")
 
 
-run(128, 128, 3, 1, 1, 112, 64, True, False)
-run(128, 128, 3, 1, 1, 112, 64, False, False)
-run(128, 192, 3, 2, 1, 112, 64, False, False)
-run(192, 192, 3, 1, 1, 56, 64, True, False)
-run(192, 256, 3, 2, 1, 56, 64, False, False)
-run(256, 256, 3, 1, 1, 28, 64, True, False)
-run(256, 512, 3, 2, 1, 28, 64, False, False)
-run(512, 512, 3, 1, 1, 14, 64, True, False)
+# IST ResNet layer shapes at B = 64 (resize to 256 x 256, stem stride 2 -> 128 x 128; reference resnet.py:364-381).  3 x 3 / stride 1 layers
+# run conv_halo_kernel unless HALO=0 (then, like the stride-2 layers, conv_planes_kernel: one gather per tap).
+lib.gp_conv2d_planes_set_halo(int(os.environ.get("HALO", "1")))
+print("# halo kernel for 3 x 3 / stride 1:", os.environ.get("HALO", "1"))
+run(128, 128, 3, 1, 1, 128, 64, True, False)
+run(128, 128, 3, 1, 1, 128, 64, False, False)
+run(128, 192, 3, 2, 1, 128, 64, False, False)
+run(192, 192, 3, 1, 1, 64, 64, True, False)
+run(192, 256, 3, 2, 1, 64, 64, False, False)
+run(256, 256, 3, 1, 1, 32, 64, True, False)
+run(256, 512, 3, 2, 1, 32, 64, False, False)
+run(512, 512, 3, 1, 1, 16, 64, True, False)

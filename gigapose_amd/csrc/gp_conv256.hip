@@ -508,16 +508,19 @@ __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
-            const f32x4* w = reinterpret_cast<const f32x4*>(a.partial + (size_t)(p - 8) * kFragFloats) + tid;
+            // piece u of thread tid at [u][tid]; buffer loads: one lane offset + a scalar offset per piece (no address pair per piece)
+            const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.partial + (size_t)(p - 8) * kFragFloats), 0,
+                                                                                 (int)(kFragFloats * sizeof(float)), 0x00020000);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 v = w[((mi * 4 + ni) * 4 + r4) * CNT];
-                        acc[mi][ni][r4 * 4 + 0] = v[0]; acc[mi][ni][r4 * 4 + 1] = v[1];
-                        acc[mi][ni][r4 * 4 + 2] = v[2]; acc[mi][ni][r4 * 4 + 3] = v[3];
+                        const cu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rf, (unsigned)tid * 16u, (unsigned)(((mi * 4 + ni) * 4 + r4) * CNT) * 16u, 0);
+                        const f32x4 vf = __builtin_bit_cast(f32x4, v);  // whole-vector cast (element-wise __builtin_bit_cast of vector lanes miscompiles: every r4 got lane group 0)
+                        acc[mi][ni][r4 * 4 + 0] = vf[0]; acc[mi][ni][r4 * 4 + 1] = vf[1];
+                        acc[mi][ni][r4 * 4 + 2] = vf[2]; acc[mi][ni][r4 * 4 + 3] = vf[3];
                     }
         } else {
 #pragma unroll
@@ -646,17 +649,19 @@ __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
         if (a.trace) { const unsigned long long t_ = wall_clock64(); tr_loop += t_ - tr_t0; tr_t0 = t_; }
 
         if (is_head) {  // publish the fragment for slot n + 1 (write-through stores, then the flag)
-            f32x4* w = reinterpret_cast<f32x4*>(a.partial + (size_t)p * kFragFloats) + tid;
+            const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.partial + (size_t)p * kFragFloats), 0,
+                                                                                 (int)(kFragFloats * sizeof(float)), 0x00020000);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
-                        f32x4 v;
-                        v[0] = acc[mi][ni][r4 * 4 + 0]; v[1] = acc[mi][ni][r4 * 4 + 1];
-                        v[2] = acc[mi][ni][r4 * 4 + 2]; v[3] = acc[mi][ni][r4 * 4 + 3];
-                        w[((mi * 4 + ni) * 4 + r4) * CNT] = v;
+                        f32x4 vf;
+                        vf[0] = acc[mi][ni][r4 * 4 + 0]; vf[1] = acc[mi][ni][r4 * 4 + 1];
+                        vf[2] = acc[mi][ni][r4 * 4 + 2]; vf[3] = acc[mi][ni][r4 * 4 + 3];
+                        const cu32x4 v = __builtin_bit_cast(cu32x4, vf);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rf, (unsigned)tid * 16u, (unsigned)(((mi * 4 + ni) * 4 + r4) * CNT) * 16u, 0);
                     }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();

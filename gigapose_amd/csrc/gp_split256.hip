@@ -729,7 +729,10 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
     long long u0 = U * n / slots_x, u1 = U * (n + 1) / slots_x;
     // PAR (fewer tiles than slots): S = floor(slots / tiles) slots per tile, each an equal share of the tile's k-steps; slot n holds
     // part n % S of tile n / S, slots beyond S * tiles have no tile (they take strip fragments).  S = 1: whole tiles, no exchange.
-    const int par_S = PAR ? max(1, slots_x / max(n_t, 1)) : 1;
+    // (the GELU build keeps whole tiles, S = 1: with the partial-sum loop next to its epilogue hipcc spills 273 registers, and a
+    // launch of T < 256 whole tiles on T slots is within 10 % of the split one at the sizes where it occurs -- fc1 below 16 crops)
+    constexpr bool kParSplit = PAR && EPI != PEPI_GELU_PLANES;
+    const int par_S = kParSplit ? max(1, slots_x / max(n_t, 1)) : 1;
     if (PAR) {
         const int tile = n / par_S, part = n - tile * par_S;
         u0 = u1 = 0;
@@ -791,16 +794,20 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
-            const f32x4* w = reinterpret_cast<const f32x4*>(a.partial + (size_t)(p - 8) * kFragFloats) + tid;   // piece u of thread tid at [u][tid]: a wave instruction covers 1 KB contiguous
+            // piece u of thread tid at [u][tid] (a wave instruction covers 1 KB contiguous); buffer loads: one 32-bit lane offset + a
+            // scalar offset per piece (64-bit flat addresses 8 KB apart cost an address pair per piece: 100 spilled registers)
+            const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.partial + (size_t)(p - 8) * kFragFloats), 0,
+                                                                                 (int)(kFragFloats * sizeof(float)), 0x00020000);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 v = w[((mi * 4 + ni) * 4 + r4) * TNT];
-                        acc[mi][ni][r4 * 4 + 0] = v[0]; acc[mi][ni][r4 * 4 + 1] = v[1];
-                        acc[mi][ni][r4 * 4 + 2] = v[2]; acc[mi][ni][r4 * 4 + 3] = v[3];
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rf, (unsigned)tid * 16u, (unsigned)(((mi * 4 + ni) * 4 + r4) * TNT) * 16u, 0);
+                        const f32x4 vf = __builtin_bit_cast(f32x4, v);  // whole-vector cast (element-wise __builtin_bit_cast of vector lanes miscompiles: every r4 got lane group 0)
+                        acc[mi][ni][r4 * 4 + 0] = vf[0]; acc[mi][ni][r4 * 4 + 1] = vf[1];
+                        acc[mi][ni][r4 * 4 + 2] = vf[2]; acc[mi][ni][r4 * 4 + 3] = vf[3];
                     }
         } else {
 #pragma unroll
@@ -912,29 +919,32 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
         if (TIMING && a.trace && tid == 0 && seg < 7) a.trace[(size_t)p * 32 + 4 + 4 * seg] = wall_clock64();
 
         if (is_head) {  // publish the fragment for slot n+1 (agent-scope release by one lane)
-            f32x4* w = reinterpret_cast<f32x4*>(a.partial + (size_t)p * kFragFloats) + tid;   // piece u of thread tid at [u][tid]: a wave instruction covers 1 KB contiguous
+            const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.partial + (size_t)p * kFragFloats), 0,
+                                                                                 (int)(kFragFloats * sizeof(float)), 0x00020000);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
-                        f32x4 v;
-                        v[0] = acc[mi][ni][r4 * 4 + 0]; v[1] = acc[mi][ni][r4 * 4 + 1];
-                        v[2] = acc[mi][ni][r4 * 4 + 2]; v[3] = acc[mi][ni][r4 * 4 + 3];
-                        // write-through (sc1) stores: the fragment goes to memory as it is written and the flag needs no L2
-                        // write-back behind it (guide, "publish-large": 3.0 vs 8.2 us per 64 KB-per-workgroup publish; here every
-                        // slot of a parallel-split launch publishes 256 KB at the same moment)
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(w + ((mi * 4 + ni) * 4 + r4) * TNT), "v"(v) : "memory");
+                        f32x4 vf;
+                        vf[0] = acc[mi][ni][r4 * 4 + 0]; vf[1] = acc[mi][ni][r4 * 4 + 1];
+                        vf[2] = acc[mi][ni][r4 * 4 + 2]; vf[3] = acc[mi][ni][r4 * 4 + 3];
+                        const u32x4 v = __builtin_bit_cast(u32x4, vf);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rf, (unsigned)tid * 16u, (unsigned)(((mi * 4 + ni) * 4 + r4) * TNT) * 16u, 0);
                     }
+            // (write-through `sc1` stores through inline asm, which the guide prices at 3.0 us against 8.2 us per 64 KB-per-workgroup
+            // publish, measured 17 -> 14 us per 256 KB here: all slots publish at once and the 48 MB are bandwidth -- not kept)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (!(a.dp & 2))  // test hook (gp_gemm_planes256_set_dp(.. | 2)): a LOST hand-off -> the waiter must time out and flag it
                     __hip_atomic_store(a.flags + p, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
-            if (PAR && is_rest) {
+            if (kParSplit && is_rest) {
                 // Parallel split-K (fewer tiles than slots: B < 64 crops at ViT-L).  Every slot of this tile started from a zero
                 // accumulator and ran its own k range at the same time; the slot holding the LAST range owns the tile: it adds
                 // the published partial accumulators of the slots before it -- in slot order, nearest first: a fixed order, the
@@ -958,18 +968,20 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
                 }
                 __syncthreads();
                 for (int m = n - 1; m >= m_lo; --m) {
-                    const f32x4* w = reinterpret_cast<const f32x4*>(a.partial + (size_t)(x + 8 * m) * kFragFloats) + tid;   // piece u of thread tid at [u][tid]: a wave instruction covers 1 KB contiguous
+                    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.partial + (size_t)(x + 8 * m) * kFragFloats), 0,
+                                                                                         (int)(kFragFloats * sizeof(float)), 0x00020000);
+                    constexpr int RQ = 4;  // 16-byte loads in flight per lane (then their 16 adds); more spills in the GELU build
 #pragma unroll
-                    for (int q8 = 0; q8 < 4; ++q8) {  // eight 16-byte loads in flight, then their 32 adds (more would spill: the kernel sits at 251 VGPRs)
-                        f32x4 v[8];
+                    for (int q0 = 0; q0 < 32; q0 += RQ) {
+                        u32x4 v[RQ];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = w[(q8 * 8 + u) * TNT];
-                        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+                        for (int u = 0; u < RQ; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rf, (unsigned)tid * 16u, (unsigned)((q0 + u) * TNT) * 16u, 0);
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int f = q8 * 8 + u, mi = f >> 4, ni = (f >> 2) & 3, r4 = f & 3;
-                            acc[mi][ni][r4 * 4 + 0] += v[u][0]; acc[mi][ni][r4 * 4 + 1] += v[u][1];
-                            acc[mi][ni][r4 * 4 + 2] += v[u][2]; acc[mi][ni][r4 * 4 + 3] += v[u][3];
+                        for (int u = 0; u < RQ; ++u) {
+                            const int f = q0 + u, mi = f >> 4, ni = (f >> 2) & 3, r4 = f & 3;
+                            const f32x4 vf = __builtin_bit_cast(f32x4, v[u]);
+                            acc[mi][ni][r4 * 4 + 0] += vf[0]; acc[mi][ni][r4 * 4 + 1] += vf[1];
+                            acc[mi][ni][r4 * 4 + 2] += vf[2]; acc[mi][ni][r4 * 4 + 3] += vf[3];
                         }
                     }
                 }

@@ -405,7 +405,12 @@ constexpr int HBUF = 2 * HPLANE;             // hi + lo
 
 __device__ __forceinline__ int hoff(int hp, int kc) { return hp * CROW + ((kc ^ ((hp >> 2) & 3)) << 3); }
 
-template <int NI>
+// PAR (fewer tiles than slots: layer3 / layer4 below 64 crops, layer4 always): S = floor(slots / tiles) slots per tile, each an equal
+// share of the tile's channel blocks from a zero accumulator, all at once; all but the last publish their partial accumulator, the
+// slot holding the last range adds them in slot order (deterministic) and runs the epilogue -- gemm_planes256_kernel's scheme.  The
+// serial hand-over (PAR = false) keeps a split tile's summation order but serialises its slots: layer4's 128 tiles on 256 slots
+// took as long as whole tiles.
+template <int NI, bool PAR>
 __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
 {
     constexpr int NIW = NI, JT = 64 * NI;
@@ -427,10 +432,19 @@ __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
     const int T = a.tiles_i * a.tiles_j;
     const int t_lo = (int)((long long)T * x / 8), n_t = (int)((long long)T * (x + 1) / 8) - t_lo;
     const int ncb = a.Cin / CBK;
-    const int rounds_dp = (n_t / slots_x > 1) ? n_t / slots_x - 1 : 0;
+    const int rounds_dp = (!PAR && n_t / slots_x > 1) ? n_t / slots_x - 1 : 0;
     const int n_dp = rounds_dp * slots_x;
     const long long U = (long long)(n_t - n_dp) * ncb;
-    const long long u0 = U * n / slots_x, u1 = U * (n + 1) / slots_x;
+    long long u0 = U * n / slots_x, u1 = U * (n + 1) / slots_x;
+    const int par_S = PAR ? min(max(1, slots_x / max(n_t, 1)), ncb) : 1;
+    if (PAR) {
+        const int tile = n / par_S, part = n - tile * par_S;
+        u0 = u1 = 0;
+        if (tile < n_t) {
+            u0 = (long long)tile * ncb + ncb * part / par_S;
+            u1 = (long long)tile * ncb + ncb * (part + 1) / par_S;
+        }
+    }
     const int ta = (int)(u0 / ncb), sa = (int)(u0 % ncb);
     const int tb = (int)(u1 / ncb), sb = (int)(u1 % ncb);
     const int n_head = sb > 0 ? 1 : 0, n_rest = sa > 0 ? 1 : 0;
@@ -494,7 +508,7 @@ __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
         }
 
         f32x16 acc[2][NIW];
-        if (is_rest) {
+        if (!PAR && is_rest) {
             if (tid == 0) {
                 int spins = 0;
                 while (__hip_atomic_load(a.flags + (p - 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
@@ -672,6 +686,43 @@ __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
             }
             __syncthreads();  // the next segment's prologue rewrites the operand buffers
         } else {
+            if (PAR && is_rest) {  // the owner of the tile: add the partial accumulators of the par_S - 1 slots before it, nearest first
+                const int m_lo = n - (par_S - 1);
+                if (tid == 0) {
+                    for (int m = n - 1; m >= m_lo; --m) {
+                        int spins = 0;
+                        while (__hip_atomic_load(a.flags + (x + 8 * m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+                            __builtin_amdgcn_s_sleep(16);
+                            if (++spins > kSpin) {
+                                __hip_atomic_store(a.flags + kErrWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                gp_raise(a.status, GP_ST_HANDOFF_SPLIT);
+                                break;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                for (int m = n - 1; m >= m_lo; --m) {
+                    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)(a.partial + (size_t)(x + 8 * m) * kFragFloats), 0,
+                                                                                         (int)(kFragFloats * sizeof(float)), 0x00020000);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NIW; ++ni) {
+                            cu32x4 v[4];
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; ++r4)
+                                v[r4] = __builtin_amdgcn_raw_buffer_load_b128(rf, (unsigned)tid * 16u, (unsigned)(((mi * 4 + ni) * 4 + r4) * CNT) * 16u, 0);
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; ++r4) {
+                                const f32x4 vf = __builtin_bit_cast(f32x4, v[r4]);
+                                acc[mi][ni][r4 * 4 + 0] += vf[0]; acc[mi][ni][r4 * 4 + 1] += vf[1];
+                                acc[mi][ni][r4 * 4 + 2] += vf[2]; acc[mi][ni][r4 * 4 + 3] += vf[3];
+                            }
+                        }
+                }
+            }
             // ---- epilogue through LDS (conv_planes_kernel's, with the block's pixel order)
             int tid_ = threadIdx.x;
             asm volatile("" : "+v"(tid_));
@@ -836,10 +887,12 @@ int gp_planes_from_cm(const float* X, int C, int npix, void* hi, void* lo, void*
     return GP_OK;
 }
 
-static int g_conv_halo = 1;  // 0: gp_conv2d_planes never takes the halo kernel (A/B hook)
+static int g_conv_halo = 1;  // bit 0: 3 x 3 / stride 1 layers take the halo kernel; bit 1 (with it): its parallel split below 256 tiles (A/B hook)
+static int g_conv_par = 1;
 int gp_conv2d_planes_set_halo(int on)
 {
-    g_conv_halo = on ? 1 : 0;
+    g_conv_halo = (on & 1) ? 1 : 0;
+    g_conv_par = (on == 1 || (on & 2)) ? 1 : 0;   // 1 = both (default), 0 = neither, 5 = halo without the parallel split
     return GP_OK;
 }
 
@@ -858,7 +911,8 @@ static int conv_halo_launch(ConvPArgs& a, float* scratch, hipStream_t st)
     const int ncb = a.Cin / CBK;
     const long long n_tiles = (long long)a.tiles_i * a.tiles_j, units = n_tiles * ncb * 9;
     int slots_x = 32;
-    while (slots_x > 1 && n_tiles < 8 * slots_x && units / (8 * slots_x) < 32) slots_x >>= 1;
+    const bool par = g_conv_par && n_tiles < 8 * slots_x && n_tiles >= 8 && ncb >= 2;  // fewer tiles than slots: parallel split over channel blocks
+    while (!par && slots_x > 1 && n_tiles < 8 * slots_x && units / (8 * slots_x) < 32) slots_x >>= 1;
     a.flags = reinterpret_cast<int*>(scratch);
     a.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes);
     g_epoch_conv = (g_epoch_conv + 1) & 0x3fffffff;
@@ -866,9 +920,15 @@ static int conv_halo_launch(ConvPArgs& a, float* scratch, hipStream_t st)
     a.status = gp_status_buffer();
     const long long npix = (long long)a.B * a.OH * a.OW;
     GpProfScope prof(GP_PROF_CONV, 2.0 * a.Cout * (double)npix * a.K, st);
-    if (ni == 2) hipLaunchKernelGGL(conv_halo_kernel<2>, dim3(8 * slots_x), dim3(CNT), 0, st, a);
-    else if (ni == 3) hipLaunchKernelGGL(conv_halo_kernel<3>, dim3(8 * slots_x), dim3(CNT), 0, st, a);
-    else hipLaunchKernelGGL(conv_halo_kernel<4>, dim3(8 * slots_x), dim3(CNT), 0, st, a);
+    if (par) {
+        if (ni == 2) hipLaunchKernelGGL((conv_halo_kernel<2, true>), dim3(8 * slots_x), dim3(CNT), 0, st, a);
+        else if (ni == 3) hipLaunchKernelGGL((conv_halo_kernel<3, true>), dim3(8 * slots_x), dim3(CNT), 0, st, a);
+        else hipLaunchKernelGGL((conv_halo_kernel<4, true>), dim3(8 * slots_x), dim3(CNT), 0, st, a);
+    } else {
+        if (ni == 2) hipLaunchKernelGGL((conv_halo_kernel<2, false>), dim3(8 * slots_x), dim3(CNT), 0, st, a);
+        else if (ni == 3) hipLaunchKernelGGL((conv_halo_kernel<3, false>), dim3(8 * slots_x), dim3(CNT), 0, st, a);
+        else hipLaunchKernelGGL((conv_halo_kernel<4, false>), dim3(8 * slots_x), dim3(CNT), 0, st, a);
+    }
     GP_CHECK_LAUNCH("gp_conv2d_planes/halo");
     return GP_OK;
 }

@@ -3,7 +3,7 @@
 set -u
 O=gpurun_out/final_check
 mkdir -p $O
-( time python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
+( time python -m pytest tests -m gpu -q -s ) > $O/pytest_gpu.log 2>&1   # -s: every test prints its measured differences
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 python bench.py > $O/bench.log 2>&1
 grep '^{"metric' $O/bench.log > $O/bench.json

@@ -196,7 +196,7 @@ def main():
     # either way; in sharded mode every rank still matches all W * B crops against its 1 / W of the bank, so it saves memory,
     # not matcher work.
     other_modes = None
-    if world > 1 and mode in ("sharded", "replicas"):
+    if (world > 1 or os.environ.get("GIGAPOSE_BENCH_BOTH_MODES") == "1") and mode in ("sharded", "replicas"):   # env: exercise the block at world 1
         alt = "replicas" if mode == "sharded" else "sharded"
         try:
             if alt == "replicas":

@@ -3,19 +3,23 @@
 // (src/utils/batch.py:46-73), Regressor (ist_net.py:123-162).
 //
 // The reference compacts valid correspondences, runs the MLPs, and scatters the results into
-// (B,P)/(B,P,2) tensors pre-filled with -1000.  Here every (detection, hypothesis, patch) row is
-// evaluated (rows are independent, so results for valid rows are identical) and invalid rows get
-// -1000 in the head kernel: no data-dependent sizes, no host sync.  The two hidden layers are the
-// k-major f32 MFMA GEMM of gp_gemm.hip on the transposed feature matrix X^T [2D][rows].
+// (B,P)/(B,P,2) tensors pre-filled with -1000.  So does this file since round 3, without a host sync: the
+// gather kernel ranks the valid rows of its (detection, hypothesis) block (ballot + popcount), reserves a
+// range of compact rows with one atomic add on a device counter and writes only those; the hidden-layer GEMMs
+// are launched over the worst-case row count and tiles beyond the counter return at once (split numerics; the
+// f32 stream-K GEMM of the chain mode computes the whole range as before); the head kernel maps a row to its
+// compact position.  Rows are independent, so a row's result does not depend on where the atomics put it.
+// (Typically 35-60 % of the 256 patches of a hypothesis carry a correspondence: 0.70 -> 0.3x ms per step.)
+// The two hidden layers are GEMMs on the transposed feature matrix X^T [2D][rows].
 #include "gp_common.h"
 
 int gp_gemm_launch(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J,
                    int K, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
                    float* sk_ws, hipStream_t st);
 
-int gp_gemm_split_launch(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J,
-                         int K, int act_is_b, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
-                         hipStream_t st);
+int gp_gemm_split_launch_limited(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J,
+                                 int K, int act_is_b, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
+                                 const int* j_limit, hipStream_t st);
 
 namespace {
 
@@ -26,9 +30,11 @@ __global__ __launch_bounds__(256) void ist_gather_kernel(
     const float* __restrict__ src_bank,  // (O, N, D, 256)
     const int* __restrict__ labels, const long long* __restrict__ id_src,  // (B), (B,k)
     const long long* __restrict__ tar_pts, const long long* __restrict__ src_pts,  // (B,k,256,2)
-    int O, int N, int k, int D, size_t R, float* __restrict__ X, int* __restrict__ status)
+    int O, int N, int k, int D, size_t R, float* __restrict__ X, int* __restrict__ pos, int* __restrict__ count,
+    int* __restrict__ status)
 {
-    const int bk = blockIdx.x, b = bk / k, t = threadIdx.x;
+    __shared__ int wcnt[4], base;
+    const int bk = blockIdx.x, b = bk / k, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int lab = labels[b];
     long long view = id_src[bk];
     if ((unsigned)lab >= (unsigned)O || (unsigned long long)view >= (unsigned long long)N) {  // the reference's index would raise
@@ -40,12 +46,24 @@ __global__ __launch_bounds__(256) void ist_gather_kernel(
     const long long tx = tar_pts[2 * r], ty = tar_pts[2 * r + 1];
     const long long sx = src_pts[2 * r], sy = src_pts[2 * r + 1];
     const bool valid = (tx != -1) && (ty != -1) && (sx != -1) && (sy != -1);
-    const int ti = valid ? (int)(ty * GP_G + tx) : 0;  // index = y * W + x   (batch.py:63)
-    const int si = valid ? (int)(sy * GP_G + sx) : 0;
+    // compact row of this correspondence: rank inside the block + a range reserved with ONE atomic add per block
+    const unsigned long long bal = __ballot(valid);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    if (t == 0) base = atomicAdd(count, wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
+    __syncthreads();
+    int rank = before;
+    for (int w = 0; w < wave; ++w) rank += wcnt[w];
+    const int rc = valid ? base + rank : -1;
+    pos[r] = rc;
+    if (!valid) return;
+    const int ti = (int)(ty * GP_G + tx);  // index = y * W + x   (batch.py:63)
+    const int si = (int)(sy * GP_G + sx);
     const float* tf = tar_feat + (size_t)b * D * GP_P + ti;
     const float* sf = src_bank + (((size_t)lab * N + (size_t)view) * D) * GP_P + si;
-    for (int c = 0; c < D; ++c) X[(size_t)c * R + r] = tf[(size_t)c * GP_P];
-    for (int c = 0; c < D; ++c) X[(size_t)(D + c) * R + r] = sf[(size_t)c * GP_P];
+    for (int c = 0; c < D; ++c) X[(size_t)c * R + rc] = tf[(size_t)c * GP_P];
+    for (int c = 0; c < D; ++c) X[(size_t)(D + c) * R + rc] = sf[(size_t)c * GP_P];
 }
 
 // Final Linear(H -> nout) (+ tanh) and the -1000 fill of invalid rows (ist_net.py:109-119).
@@ -55,15 +73,17 @@ __global__ __launch_bounds__(256) void ist_head_kernel(const float* __restrict__
                                                         const float* __restrict__ W3 /*[NOUT][H]*/,
                                                         const float* __restrict__ b3,
                                                         const long long* __restrict__ tar_pts,
-                                                        const long long* __restrict__ src_pts, int H, size_t R,
+                                                        const long long* __restrict__ src_pts, const int* __restrict__ pos, int H, size_t R,
                                                         int use_tanh, float* __restrict__ out)
 {
     const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
     float acc[NOUT];
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) acc[o] = 0.f;
+    const int rc = pos[r];  // compact row (-1: no correspondence -> -1000 below; row 0 is read, finite or not, and discarded)
+    const size_t rr = rc >= 0 ? (size_t)rc : 0;
     for (int h = 0; h < H; ++h) {
-        const float x = Hid[(size_t)h * R + r];
+        const float x = Hid[(size_t)h * R + rr];
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) acc[o] = __builtin_fmaf(W3[o * H + h], x, acc[o]);
     }
@@ -74,7 +94,7 @@ __global__ __launch_bounds__(256) void ist_head_kernel(const float* __restrict__
     for (int o = 0; o < NOUT; ++o) {
         float v = acc[o] + b3[o];
         if (use_tanh) v = tanhf(v);
-        out[r * NOUT + o] = (sv && tv) ? v : -1000.0f;
+        out[r * NOUT + o] = (sv && tv && rc >= 0) ? v : -1000.0f;
     }
 }
 
@@ -86,7 +106,7 @@ size_t gp_ist_workspace_bytes(int B, int k, int D, int H)
 {
     if (B <= 0 || k <= 0) return 0;
     const size_t R = (size_t)B * k * GP_P;
-    return sizeof(float) * R * ((size_t)2 * D + 2 * H + H);  // X, H1, H2
+    return sizeof(float) * R * ((size_t)2 * D + 2 * H + H) + sizeof(int) * (R + 64);  // X, H1, H2, compact positions, row counter
 }
 
 int gp_ist_regress(const float* tar_feat, const float* src_bank, const int* labels, const long long* id_src,
@@ -111,17 +131,20 @@ int gp_ist_regress(const float* tar_feat, const float* src_bank, const int* labe
     float* X = workspace;
     float* H1 = X + (size_t)2 * D * R;
     float* H2 = H1 + (size_t)2 * H * R;
+    int* pos = reinterpret_cast<int*>(H2 + (size_t)H * R);
+    int* count = pos + R;
+    if (hipMemsetAsync(count, 0, sizeof(int), st) != hipSuccess) return GP_ELAUNCH;
     hipLaunchKernelGGL(ist_gather_kernel, dim3(B * k), dim3(256), 0, st, tar_feat, src_bank, labels, id_src,
-                       tar_pts, src_pts, O, N, k, D, R, X, gp_status_buffer());
+                       tar_pts, src_pts, O, N, k, D, R, X, pos, count, gp_status_buffer());
     GP_CHECK_LAUNCH("gp_ist_regress/gather");
     int rc;
     for (int head = 0; head < 2; ++head) {  // 0: scale_predictor, 1: inplane_predictor (ist_net.py:140-155)
         const float* const* w = weights + head * 6;  // W1^T [2D][2H], b1, W2^T [2H][H], b2, W3 [nout][H], b3
         if (split) {  // split numerics (3 x f16 MFMA, gp_split.hip): the two hidden layers = 99 % of the head's flops
             const float* const* sp = weights + 12 + head * 4;
-            if ((rc = gp_gemm_split_launch(X, (int)R, sp[0], sp[1], H1, (int)R, 2 * H, (int)R, 2 * D, 1, 5, w[1], nullptr, nullptr, 0, st)))
+            if ((rc = gp_gemm_split_launch_limited(X, (int)R, sp[0], sp[1], H1, (int)R, 2 * H, (int)R, 2 * D, 1, 5, w[1], nullptr, nullptr, 0, count, st)))
                 return rc;
-            if ((rc = gp_gemm_split_launch(H1, (int)R, sp[2], sp[3], H2, (int)R, H, (int)R, 2 * H, 1, 5, w[3], nullptr, nullptr, 0, st)))
+            if ((rc = gp_gemm_split_launch_limited(H1, (int)R, sp[2], sp[3], H2, (int)R, H, (int)R, 2 * H, 1, 5, w[3], nullptr, nullptr, 0, count, st)))
                 return rc;
         } else {
             if ((rc = gp_gemm_launch(w[0], 2 * H, X, (int)R, H1, (int)R, 2 * H, (int)R, 2 * D, 5, w[1], nullptr, nullptr,
@@ -133,10 +156,10 @@ int gp_ist_regress(const float* tar_feat, const float* src_bank, const int* labe
         }
         if (head == 0)
             hipLaunchKernelGGL(ist_head_kernel<1>, dim3((unsigned)(R / 256)), dim3(256), 0, st, H2, w[4], w[5],
-                               tar_pts, src_pts, H, R, 0, scales);
+                               tar_pts, src_pts, pos, H, R, 0, scales);
         else
             hipLaunchKernelGGL(ist_head_kernel<2>, dim3((unsigned)(R / 256)), dim3(256), 0, st, H2, w[4], w[5],
-                               tar_pts, src_pts, H, R, use_tanh, cos_sin);
+                               tar_pts, src_pts, pos, H, R, use_tanh, cos_sin);
         GP_CHECK_LAUNCH("gp_ist_regress/head");
     }
     return GP_OK;

@@ -366,17 +366,14 @@ __device__ __forceinline__ void match_split_kloop(MatchSplitSmem& sm, f32x16 (&a
                                                   int lane, int wr, int wc, int grp)
 {
     constexpr int P_AHI = 0, P_ALO = MS_PLANE, P_BHI = 2 * MS_PLANE, P_BLO = 3 * MS_PLANE, MS_BUF = 4 * MS_PLANE;
-    constexpr bool kStageA1 = MI > 1 || true;  // rows 128..255 hold wave rows 2, 3 (always) and the second row block
     const int wofs = (tid >> 2) * MS_BK + (((tid & 3) ^ (((tid >> 2) >> 2) & 3)) << 3);
     mu32x4 rg[8];
     auto gload = [&](int slab) {
         const unsigned so = (unsigned)slab * (MS_BK * 2u);
         rg[0] = __builtin_amdgcn_raw_buffer_load_b128(rs.qh, rs.va0, so, 0);
         rg[2] = __builtin_amdgcn_raw_buffer_load_b128(rs.ql, rs.va0, so, 0);
-        if (kStageA1) {
-            rg[1] = __builtin_amdgcn_raw_buffer_load_b128(rs.qh, rs.va1, so, 0);
-            rg[3] = __builtin_amdgcn_raw_buffer_load_b128(rs.ql, rs.va1, so, 0);
-        }
+        rg[1] = __builtin_amdgcn_raw_buffer_load_b128(rs.qh, rs.va1, so, 0);   // rows 128..255: wave rows 2, 3 (rows without a live patch
+        rg[3] = __builtin_amdgcn_raw_buffer_load_b128(rs.ql, rs.va1, so, 0);   // carry the out-of-range offset: zeros, no memory traffic)
         rg[4] = __builtin_amdgcn_raw_buffer_load_b128(rs.bh, rs.vb0, so, 0);
         rg[5] = __builtin_amdgcn_raw_buffer_load_b128(rs.bh, rs.vb1, so, 0);
         if (BANK_LO) {
@@ -388,10 +385,8 @@ __device__ __forceinline__ void match_split_kloop(MatchSplitSmem& sm, f32x16 (&a
         _Float16* L = sm.stage + buf * MS_BUF + wofs;
         *reinterpret_cast<mu32x4*>(L + P_AHI) = rg[0];
         *reinterpret_cast<mu32x4*>(L + P_ALO) = rg[2];
-        if (kStageA1) {
-            *reinterpret_cast<mu32x4*>(L + P_AHI + 128 * MS_BK) = rg[1];
-            *reinterpret_cast<mu32x4*>(L + P_ALO + 128 * MS_BK) = rg[3];
-        }
+        *reinterpret_cast<mu32x4*>(L + P_AHI + 128 * MS_BK) = rg[1];
+        *reinterpret_cast<mu32x4*>(L + P_ALO + 128 * MS_BK) = rg[3];
         *reinterpret_cast<mu32x4*>(L + P_BHI) = rg[4];
         *reinterpret_cast<mu32x4*>(L + P_BHI + 128 * MS_BK) = rg[5];
         if (BANK_LO) {

@@ -66,6 +66,7 @@ struct SplitArgs {
     float* D; int ldd; int K;
     const float* bias; const float* scale; const float* res; int ldr;
     int tiles_i, tiles_j, group;
+    const int* j_limit;  // optional device word: tiles whose first column is >= *j_limit have nothing to compute and return (gp_ist.hip: compacted rows)
 };
 
 // GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) without libm's erff (which costs 0.15 ms of the 0.66 ms fc1 launch at ViT-L, B=64):
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
     const int first_i = band * a.group;
     const int gsz = min(a.group, a.tiles_i - first_i);
     const int i0 = (first_i + rr % gsz) * SBM, j0 = (rr / gsz) * SBN;
+    if (a.j_limit && j0 >= *a.j_limit) return;  // workgroup-uniform
     const int n_act0 = ACT_IS_B ? j0 : i0, n_w0 = ACT_IS_B ? i0 : j0;
     // plane offsets (halfs) inside one buffer
     constexpr int P_AHI = 0, P_ALO = SPLANE, P_BHI = 2 * SPLANE, P_BLO = 3 * SPLANE;
@@ -485,9 +487,21 @@ __global__ __launch_bounds__(512, 4) void conv_split_kernel(const ConvSplitArgs 
 
 // internal entry (gp_vit.hip).  act: f32 k-major activations [K][ld_act]; whi/wlo: pre-split weights [n_w][K].
 // act_is_b: D[i][j] = sum_k W[i][k] X[k][j]  (weights index i); else D[i][j] = sum_k X[k][i] W[j][k].
+int gp_gemm_split_launch_limited(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J,
+                                 int K, int act_is_b, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
+                                 const int* j_limit, hipStream_t st);
+
 int gp_gemm_split_launch(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J,
                          int K, int act_is_b, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
                          hipStream_t st)
+{
+    return gp_gemm_split_launch_limited(act, ld_act, whi, wlo, D, ldd, I, J, K, act_is_b, epilogue, bias, scale, res, ldr, nullptr, st);
+}
+
+// j_limit (device int, may be null): only columns j < *j_limit carry data -- whole tiles beyond it exit at once
+int gp_gemm_split_launch_limited(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J,
+                                 int K, int act_is_b, int epilogue, const float* bias, const float* scale, const float* res, int ldr,
+                                 const int* j_limit, hipStream_t st)
 {
     GP_REQUIRE(I > 0 && J > 0 && K > 0 && I % SBM == 0 && J % SBN == 0 && K % SBK == 0,
                "gp_gemm_split: I=%d, J=%d must be multiples of 128 and K=%d of 32", I, J, K);
@@ -495,7 +509,7 @@ int gp_gemm_split_launch(const float* act, int ld_act, const void* whi, const vo
                    ((uintptr_t)wlo % 16 == 0),
                "gp_gemm_split: null / misaligned operand");
     GP_REQUIRE((long long)I * ldd < (1ll << 31) && (long long)I * (ldr > 0 ? ldr : 1) < (1ll << 31), "gp_gemm_split: output too large");
-    SplitArgs a{act, ld_act, (const _Float16*)whi, (const _Float16*)wlo, D, ldd, K, bias, scale, res, ldr, I / SBM, J / SBN, 8};
+    SplitArgs a{act, ld_act, (const _Float16*)whi, (const _Float16*)wlo, D, ldd, K, bias, scale, res, ldr, I / SBM, J / SBN, 8, j_limit};
     GpProfScope prof(GP_PROF_GEMM_SPLIT, 2.0 * I * J * K, st);  // algorithmic flops (the kernel executes 3x as f16 MFMAs)
     switch (epilogue) {
         case SEPI_NONE: launch_split<SEPI_NONE>(a, act_is_b != 0, st); break;

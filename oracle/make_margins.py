@@ -123,9 +123,6 @@ def run_captured(which, double, k_all=False):
         cap["sim_avg"].append(x.detach().clone().numpy())
         return orig_topk(x, k, dim=dim, **kw)
 
-    class _Stop(Exception):
-        pass
-
     def test_spy(self, src_feats, tar_feat, src_masks, tar_mask, max_batch_size=None):
         cap["tar_feat"].append(tar_feat.detach().clone().numpy())
         torch.topk = topk_spy

@@ -105,7 +105,9 @@ __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, 64 x 64 each
-    const int q = xcd_chunked_tile(blockIdx.x, a.tiles_i * a.tiles_j);
+    // with a column limit only the first tiles carry work: deal them round-robin over the XCDs (block id % 8) instead of giving each XCD one
+    // contiguous chunk of the tile list -- chunked, 40 % live columns kept 3 of 8 XCDs busy and the launch took as long as the full one
+    const int q = a.j_limit ? ((int)blockIdx.x < a.tiles_i * a.tiles_j ? (int)blockIdx.x : -1) : xcd_chunked_tile(blockIdx.x, a.tiles_i * a.tiles_j);
     if (q < 0) return;
     const int per_band = a.group * a.tiles_j;
     const int band = q / per_band, rr = q - band * per_band;

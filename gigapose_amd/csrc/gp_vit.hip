@@ -8,7 +8,7 @@
 // L2-normalises over C (ae_net.py:64-69) straight into the (B, C, 16, 16) layout the matcher reads.
 //
 // Token column of image b, token t:  m = b * T + t   (T = 257, no per-image padding);
-// all activation matrices have Mpad = round_up(B*T, 128) columns.
+// all activation matrices have Mpad = round_up(B*T, 256) columns.
 #include "gp_common.h"
 
 int gp_gemm_launch(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J,

@@ -247,9 +247,10 @@ class ResNet(nn.Module):
         return (st["cin"], st["k"], st["stride"], st["pad"]) == (3, 7, 2, 3) and st["cout"] in (128, 192, 256) and self.input_size % 2 == 0
 
     def _forward_split(self, pk, stem_out, out, B, H, W, f32_bufs, images=None):
-        """Everything after the stem in split numerics: channel-last f16 planes, gp_conv2d_nhwc_split.  The stem
-        (7x7/2 on 3 channels, 1.6 % of the FLOPs) stays the f32 kernel; its channel-major output is split + transposed
-        once.  The plane buffers alias the f32 ping-pong buffers (same bytes: 2 planes x f16 = f32)."""
+        """The ResNet in split numerics on channel-last f16 planes.  conv_kernel "256" (default): gp_conv2d_planes for every layer (3 x 3 /
+        stride 1 layers run its halo kernel) and, when `images` is given, the stem too (resize -> framed 4-channel planes ->
+        gp_conv2d_stem_planes).  conv_kernel "128" (the wide-range fallback): gp_conv2d_nhwc_split after an f32 stem whose channel-major
+        output `stem_out` is split + transposed once.  The plane buffers alias the f32 ping-pong buffers (2 planes x f16 = f32)."""
         dev = stem_out.device if stem_out is not None else images.device
         c0 = pk["stem"]["cout"]
         npix = B * H * W

@@ -191,3 +191,31 @@ def test_attention_variants_are_bit_identical():
     finally:
         lib.gp_attention_set_nq(1)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_vit_large_width_every_batch_size_split_vs_chain():
+    """ViT-L width (4 blocks) at batch sizes on both sides of every path switch of the split numerics: 1-7 crops (fewer than 8 plane
+    tiles: 128 x 128 kernels), 8-63 (plane GEMMs with the parallel split-K, S = 16 ... 1 slots per tile, strips of B rows), 64 and
+    65 (serial kernel, ragged strip) -- the unit-norm features must agree with the bit-exact chain mode to f32 round-off at every
+    size, and a crop's features must not depend on the batch it is in beyond that."""
+    import numpy as np
+
+    from gigapose_amd import _lib
+    from gigapose_amd import synthetic as syn
+    from gigapose_amd.vit import Dinov2ViT
+
+    vit = syn.fill_state_dict(Dinov2ViT(1024, 4, 16), 21).eval().to(DEV)
+    x = torch.from_numpy(np.random.RandomState(4).standard_normal((65, 3, 224, 224)).astype(np.float32)).to(DEV)
+    ref = vit.set_numerics("chain").patch_features(x[:16]).clone()          # chain: independent of the batch composition, bit for bit
+    assert torch.equal(vit.patch_features(x[:3]), ref[:3])
+    vit.set_numerics("split")
+    worst = 0.0
+    for B in (1, 2, 3, 5, 7, 8, 9, 12, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65):
+        f = vit.patch_features(x[:B])
+        torch.cuda.synchronize()
+        _lib.check_status()
+        n = min(B, 16)
+        d = (f[:n] - ref[:n]).abs().max().item()
+        worst = max(worst, d)
+        assert torch.isfinite(f).all() and d < 2e-6, f"B={B}: split vs chain {d:.2e}"
+    print(f"ViT-L width, B = 1 .. 65: max |split - chain| over unit-norm features {worst:.2e}")

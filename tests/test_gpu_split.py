@@ -543,7 +543,7 @@ def test_planes256_ragged_rows(I, J, jv, K):
 # B = 16 (J_valid = 4112), proj at B = 8 and B = 33, a 9-tile problem (one XCD holds two tiles, seven hold one)
 PAR_SHAPES = [(1024, 4352, 4112, 1024), (1024, 4352, 4112, 4096), (3072, 4352, 4112, 1024), (4096, 4352, 4112, 1024),
               (1024, 2304, 2056, 1024), (1024, 8704, 8481, 1024), (768, 768, 768, 1024),
-              (1024, 8448, 8224, 1024), (1024, 8448, 8224, 4096)]   # proj / fc2 at B = 32: two slots per tile (reduce-scatter halves)
+              (1024, 8448, 8224, 1024), (1024, 8448, 8224, 4096)]   # proj / fc2 at B = 32: two slots per tile
 
 
 @pytest.mark.parametrize("I,J,jv,K", PAR_SHAPES)

@@ -324,7 +324,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: {args.variant} random-init, {args.objects} object(s) x {args.templates} templates, "
                                f"batch={args.batch} crops per GPU, k={args.k}, full path ViT->match->IST->RANSAC->pose",
-                   "numerics": args.numerics, "global_batch": world * args.batch, "parallelism": "single" if world == 1 else f"{mode}{world}",
+                   "numerics": args.numerics, "global_batch": world * args.batch, "parallelism": f"{mode}{world}" if (world > 1 or (mode == "sharded" and dist.is_initialized())) else "single",
                    "streams": "ViT+match on stream 0, IST backbone on stream 1" if model.overlap_ist else "single stream",
                    "rccl_ranks": world if dist.is_initialized() else 0,
                    "host_syncs_in_timed_loop": "none: pose recovery's crop-transform assert readback (reference lib3d/torch.py:54-55) is "

@@ -23,8 +23,6 @@ def timeit(fn, iters=10, warm=3):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 torch.manual_seed(0)
-M = int(os.environ.get("MPAD", 16640))           # padded rows of the token dimension (ViT-L at B = 64)
-MV = int(os.environ.get("MTOK", 16448))          # rows that carry tokens (64 x 257); MTOK=16640 probes the fully tiled launch
 for (nw, K, name, epi) in [(3072, 1024, "qkv", 7), (1024, 1024, "proj", 3), (4096, 1024, "fc1", 6), (1024, 4096, "fc2", 3)]:
     W = torch.randn(nw, K, device=dev) * 0.03
     Xt = torch.randn(M, K, device=dev) * 1.5
@@ -45,6 +43,7 @@ for (nw, K, name, epi) in [(3072, 1024, "qkv", 7), (1024, 1024, "proj", 3), (409
     start, nseg = t[:, 0], t[:, 1]
     t0 = start.min()
     ends, kl, ep, wait, steps, pub, strip, ep_own = [], [], [], [], [], [], [], []
+    by_seg = {}                                   # SEGSTAT=1: epilogue durations by segment index (aligned whole-tile rounds vs staggered stream-K ones)
     for p in range(256):
         prev = start[p]
         for s in range(min(int(nseg[p]), 7)):
@@ -52,6 +51,7 @@ for (nw, K, name, epi) in [(3072, 1024, "qkv", 7), (1024, 1024, "proj", 3), (409
             a, b, c = t[p, 3 + 4 * s], t[p, 4 + 4 * s], t[p, 5 + 4 * s]
             wait.append((a - prev) / 100.0); kl.append((b - a) / 100.0); steps.append(ns)
             (pub if kind in (1, 3) else (ep_own if kind == 2 else ep)).append((c - b) / 100.0)
+            if kind in (0, 2): by_seg.setdefault((s, kind), []).append(((c - b) / 100.0, (b - t0) / 100.0))
             prev = c
         strip.append((t[p, 31] - prev) / 100.0)
         ends.append((t[p, 31] - t0) / 100.0)
@@ -68,3 +68,8 @@ for (nw, K, name, epi) in [(3072, 1024, "qkv", 7), (1024, 1024, "proj", 3), (409
         print("      lifetime by XCD (us):", " ".join(f"{e[x::8].mean():6.1f}" for x in range(8)), "| by slot-in-XCD quartile:",
               " ".join(f"{e.reshape(32, 8)[q * 8:(q + 1) * 8].mean():6.1f}" for q in range(4)),
               "| k-loop us/step by XCD:", " ".join(f"{(kl.reshape(256, -1).sum(1)[x::8].mean() / (steps.sum() / 256)):5.3f}" for x in range(8)) if len(kl) % 256 == 0 else "", flush=True)
+    if os.environ.get("SEGSTAT"):
+        for (sidx, kind), v in sorted(by_seg.items()):
+            d, at = np.array([x[0] for x in v]), np.array([x[1] for x in v])
+            print(f"      segment {sidx} ({'whole tile' if kind == 0 else 'continued tile'}): {len(v):3d} epilogues, duration min/mean/max {d.min():5.1f}/{d.mean():5.1f}/{d.max():5.1f} us, "
+                  f"starting {at.min():6.1f} .. {at.max():6.1f} us after the launch (spread {at.std():5.1f})", flush=True)

@@ -6,6 +6,8 @@ import numpy as np
 import torch
 from gigapose_amd import _lib
 dev = "cuda"
+if os.environ.get("GP_LIB"):   # a library built with other macros (e.g. -DGP_EPI_PROBE=.., tools/patches/epi_probe.diff)
+    _lib.LIB_PATH = os.path.abspath(os.environ["GP_LIB"])
 lib = _lib.lib()
 lib.gp_gemm_split256_workspace_bytes.restype = ctypes.c_size_t
 NB = lib.gp_gemm_split256_workspace_bytes()
@@ -23,6 +25,8 @@ def timeit(fn, iters=10, warm=3):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 torch.manual_seed(0)
+M = int(os.environ.get("MPAD", 16640))           # padded rows of the token dimension (ViT-L at B = 64)
+MV = int(os.environ.get("MTOK", 16448))          # rows that carry tokens (64 x 257); MTOK=16640 probes the fully tiled launch
 for (nw, K, name, epi) in [(3072, 1024, "qkv", 7), (1024, 1024, "proj", 3), (4096, 1024, "fc1", 6), (1024, 4096, "fc2", 3)]:
     W = torch.randn(nw, K, device=dev) * 0.03
     Xt = torch.randn(M, K, device=dev) * 1.5

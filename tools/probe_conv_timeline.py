@@ -12,6 +12,8 @@ import torch
 from gigapose_amd import _lib
 
 dev = "cuda"
+if os.environ.get("GP_LIB"):   # a library built with other macros (tools/patches/conv_epi_probe.diff, -DGP_CONV_PROBE=..)
+    _lib.LIB_PATH = os.path.abspath(os.environ["GP_LIB"])
 lib = _lib.lib()
 lib.gp_conv2d_planes_workspace_bytes.restype = ctypes.c_size_t
 nb = lib.gp_conv2d_planes_workspace_bytes()

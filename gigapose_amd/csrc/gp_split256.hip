@@ -732,7 +732,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
     // (the GELU build keeps whole tiles, S = 1: with the partial-sum loop next to its epilogue hipcc spills 273 registers, and a
     // launch of T < 256 whole tiles on T slots is within 10 % of the split one at the sizes where it occurs -- fc1 below 16 crops)
     constexpr bool kParSplit = PAR && EPI != PEPI_GELU_PLANES;
-    const int par_S = kParSplit ? max(1, slots_x / max(n_t, 1)) : 1;
+    const int par_S = kParSplit ? max(1, min(a.par, slots_x / max(n_t, 1))) : 1;  // a.par: the host's cap (k-steps per slot, see the launch)
     if (PAR) {
         const int tile = n / par_S, part = n - tile * par_S;
         u0 = u1 = 0;
@@ -1083,6 +1083,11 @@ static bool planes_par_usable(int I, int J_main, int K)
     return T < kSlots && T >= 8 && (T / 8) * (K / TBK) >= kSlots / 8;
 }
 static int g_planes_par = 1;  // 0: shapes with fewer tiles than slots are refused (the caller falls back to the 128 x 128 kernel; A/B hook)
+// A tile is split over at most K / 32 / kParMinSteps slots: below 16 k-steps per slot the partial accumulators (256 KB each, published by
+// all non-owners at once, then read by the owner) cost more than the shorter k loop saves -- proj (K = 1024) at 16 crops 69 -> 62 us with
+// two instead of four slots per tile, at 8 crops 74 -> 55 us with two or four instead of eight (PAR_MIN_STEPS=.. tools/probe_planes_timeline.py).
+constexpr int kParMinSteps = 16;
+static int g_planes_par_min_steps = kParMinSteps;
 bool gp_gemm_planes256_usable(int I, int J, int J_valid, int K)
 {
     int J_main, fj;
@@ -1116,7 +1121,7 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
     ArgsP a{(const _Float16*)ahi, (const _Float16*)alo, (const _Float16*)bhi, (const _Float16*)blo, D, ldd, (_Float16*)ohi, (_Float16*)olo, ldo,
             K, bias, scale, res, ldr, I / TB, J_main / TB, 4, reinterpret_cast<int*>(scratch),
             reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, out_scale, g_planes_dp, trace, gp_status_buffer(),
-            J_main, strip_fj, (long long)(I / TB) * (J_main / TB) < kSlots ? 1 : 0};
+            J_main, strip_fj, (long long)(I / TB) * (J_main / TB) < kSlots ? max(1, (K / TBK) / g_planes_par_min_steps) : 0};
     g_epoch256 = (g_epoch256 + 1) & 0x3fffffff;
     a.epoch = (int)(0x40000000u | g_epoch256);
     GpProfScope prof(GP_PROF_GEMM_SPLIT, 2.0 * I * (J_valid > 0 && J_valid < J ? J_valid : J) * K, st);
@@ -1283,6 +1288,7 @@ int gp_gemm_planes256_set_dp(int mode)  // bit 0: data-parallel rounds (default 
 int gp_gemm_planes256_set_par(int on)  // 0: refuse shapes with fewer tiles than slots (A/B hook: the ViT then takes the 128 x 128 kernels)
 {
     g_planes_par = on ? 1 : 0;
+    g_planes_par_min_steps = on > 1 ? on : kParMinSteps;   // on >= 2 (A/B hook): at least `on` k-steps per slot of a split tile
     return GP_OK;
 }
 

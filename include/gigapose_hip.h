@@ -231,7 +231,8 @@ int gp_gemm_planes256_set_dp(int mode); /* bit 0 (default 1): data-parallel roun
                                            head fragments are never published (every waiter times out -> GP_STATUS_HANDOFF_SPLIT) */
 int gp_gemm_planes256_set_par(int on); /* default 1: shapes with 8 <= tiles < 256 (ViT-L below 64 crops) run with the slots of a tile splitting
                                           its K in parallel (partial accumulators added in a fixed order by the slot holding the last k
-                                          range); 0: such shapes are refused and gp_vit_forward_split falls back to the 128 x 128 kernels */
+                                          range, at least 16 k-steps per slot); 0: such shapes are refused and gp_vit_forward_split falls back to the 128 x 128
+                                          kernels; n >= 2 (probe hook): at least n k-steps per slot of a split tile */
 /* Ragged J (257 tokens per crop are never a multiple of 256): only rows < J_valid of B carry data (J, the padded row
  * count of the buffers, stays a multiple of 256).  The 256 x 256 tiles cover floor(J_valid / 256) * 256 rows -- at
  * B = 64 crops exactly one / two / four whole tiles per CU, no stream-K hand-over -- and the remaining < 256 rows are

@@ -25,6 +25,8 @@ def timeit(fn, iters=10, warm=3):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 torch.manual_seed(0)
+if os.environ.get("PAR_MIN_STEPS"):   # parallel split-K (fewer tiles than slots): at least this many k-steps per slot of a split tile
+    lib.gp_gemm_planes256_set_par(int(os.environ["PAR_MIN_STEPS"]))
 M = int(os.environ.get("MPAD", 16640))           # padded rows of the token dimension (ViT-L at B = 64)
 MV = int(os.environ.get("MTOK", 16448))          # rows that carry tokens (64 x 257); MTOK=16640 probes the fully tiled launch
 for (nw, K, name, epi) in [(3072, 1024, "qkv", 7), (1024, 1024, "proj", 3), (4096, 1024, "fc1", 6), (1024, 4096, "fc2", 3)]:

@@ -184,6 +184,31 @@ def test_sharded_matcher_class_world2_uneven_shards():
             np.testing.assert_array_equal(r[name].view(np.uint32), full[name][own].view(np.uint32), err_msg=name)
 
 
+@pytest.mark.timeout(300)
+def test_sharded_matcher_class_world4_uneven_shards():
+    """World size 4 (the driver's N = 4 run; the all-to-all's chunking by rank and the merge of four candidate lists are not exercised
+    with two ranks): 22 templates -> shards of 6, 5, 6, 5, two crops per rank, labels over two objects."""
+    world, k = 4, 5
+    case = syn.matcher_case(seed=79, B=8, O=2, N=22, C=32)
+    assert sorted(sharding.shard_bounds(22, world, r)[1] - sharding.shard_bounds(22, world, r)[0] for r in range(world)) == [5, 5, 6, 6]
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_class_worker, args=(world, _free_port(), case, k, ret), nprocs=world, join=True)
+    full = oracle.local_similarity_test(case["src_feats"], case["tar_feat"], case["src_masks"], case["tar_mask"], case["labels"], k)
+    winners = set()
+    for rank in range(world):
+        own = slice(rank * 2, rank * 2 + 2)
+        r = ret[rank]
+        assert ret[f"reject{rank}"]
+        for name in ["id_src", "tar_pts", "src_pts"]:
+            np.testing.assert_array_equal(r[name], full[name][own], err_msg=f"rank {rank}: {name}")
+        for name in ["score_src", "score_pts"]:
+            np.testing.assert_array_equal(r[name].view(np.uint32), full[name][own].view(np.uint32), err_msg=f"rank {rank}: {name}")
+        winners.update(int(t) for t in r["id_src"].ravel())
+    owners = {next(w for w in range(world) if sharding.shard_bounds(22, world, w)[0] <= t < sharding.shard_bounds(22, world, w)[1]) for t in winners}
+    assert len(owners) >= 3, "the winners come from fewer than three shards: the four-way merge was not exercised"
+
+
 def test_pack_unpack_query_roundtrip():
     rs = np.random.RandomState(1)
     qm = torch.from_numpy(rs.rand(3, 256).astype(np.float32))

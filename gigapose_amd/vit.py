@@ -230,7 +230,7 @@ class Dinov2ViT(nn.Module):
             split_table = (ctypes.c_void_p * len(split))(*[t.data_ptr() for t in split])
             if "GIGAPOSE_VIT_PLANES" in os.environ:  # A/B probes (csrc/gp_vit.hip): 0 f32 activations, 1 f32 attention, 2 default
                 _lib.lib().gp_vit_set_planes(int(os.environ["GIGAPOSE_VIT_PLANES"]))
-            if "GIGAPOSE_PLANES_PAR" in os.environ:  # A/B probe: 0 = fewer tiles than slots (B < 64 at ViT-L) -> 128 x 128 kernels
+            if "GIGAPOSE_PLANES_PAR" in os.environ:  # A/B probe: 0 = fewer tiles than slots (B < 64 at ViT-L) -> 128 x 128 kernels; n >= 2: >= n k-steps per slot of a split tile
                 _lib.lib().gp_gemm_planes256_set_par(int(os.environ["GIGAPOSE_PLANES_PAR"]))
             if "GIGAPOSE_PLANES_DP" in os.environ:   # A/B probe: 0 = every plane-GEMM tile cut stream-K style
                 _lib.lib().gp_gemm_planes256_set_dp(int(os.environ["GIGAPOSE_PLANES_DP"]))

@@ -164,3 +164,49 @@ def test_strip_fragments_are_handed_out_exactly_once(seed, nslots, nfrag):
         allf = sorted(f for g in got for f in g)
         assert allf == list(range(nfrag))
         assert (word[0] & ~0xfff) == tag and (word[0] & 0xfff) == nfrag + nslots   # every slot overshoots exactly once
+
+
+# ---- the parallel split-K plan (fewer tiles than slots: gemm_planes256_kernel<.., PAR = true>) with the host's cap of at least
+# kParMinSteps k-steps per slot of a split tile (gp_gemm_planes256_launch: a.par = max(1, nstep / kParMinSteps)).
+def par_plan(T, nstep, min_steps=16, slots=256):
+    """-> ({slot: (tile, s0, s1, part, S)} for slots that hold a tile, S per XCD chunk); tile is the global chunk-ordered index."""
+    cap = max(1, nstep // min_steps)
+    plan, S_of = {}, {}
+    for p in range(slots):
+        x, n, slots_x = p & 7, p >> 3, slots >> 3
+        t_lo = T * x // 8
+        n_t = T * (x + 1) // 8 - t_lo
+        par_S = max(1, min(cap, slots_x // max(n_t, 1)))
+        S_of[x] = par_S
+        tile, part = n // par_S, n % par_S
+        if tile < n_t:
+            u0 = tile * nstep + nstep * part // par_S
+            u1 = tile * nstep + nstep * (part + 1) // par_S
+            assert u0 // nstep == tile and (u1 - 1) // nstep == tile
+            plan[p] = (t_lo + tile, u0 - tile * nstep, u1 - tile * nstep, part, par_S)
+    return plan, S_of
+
+
+@pytest.mark.parametrize("T,nstep", [(64, 32), (64, 128), (128, 32), (192, 32), (32, 32), (32, 128), (8, 32), (96, 32), (255, 32), (40, 4),
+                                      (24, 2048), (100, 48)])
+@pytest.mark.parametrize("min_steps", [1, 16])
+def test_parallel_split_plan_covers_every_unit_once_with_the_owner_last(T, nstep, min_steps):
+    plan, S_of = par_plan(T, nstep, min_steps)
+    seen, parts = {}, {}
+    for p, (tile, s0, s1, part, S) in plan.items():
+        assert s0 < s1, "a slot of a split tile without k-steps"
+        for s in range(s0, s1):
+            assert (tile, s) not in seen
+            seen[(tile, s)] = p
+        parts.setdefault(tile, []).append((part, p, s0, s1, S))
+    assert len(seen) == T * nstep
+    for tile, ps in parts.items():
+        ps.sort()
+        S = ps[0][4]
+        assert [q[0] for q in ps] == list(range(S))                       # parts 0 .. S - 1, the owner (epilogue) holds the LAST k range
+        assert ps[-1][3] == nstep and ps[0][2] == 0
+        assert all(b[1] == a[1] + 8 for a, b in zip(ps, ps[1:]))          # neighbouring slots of ONE XCD (flags / partials of slot p - 8 m)
+        if min_steps > 1 and S > 1:
+            assert min(q[3] - q[2] for q in ps) >= min(min_steps, nstep // S), "a split tile's slot fell below the k-step floor"
+    if min_steps == 16 and nstep == 32:
+        assert max(S_of.values()) <= 2                                     # K = 1024: at most two slots per tile (proj / v below 64 crops)

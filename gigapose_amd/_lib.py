@@ -18,6 +18,21 @@ class GigaPoseHipError(RuntimeError):
     pass
 
 
+NUMERICS = ("split", "chain")
+
+
+def default_numerics():
+    """Numerics of the contraction kernels when nothing else is said: "split" -- every f32 operand as two
+    f16 planes, 3 x f16 MFMA per k-block, f32 accumulate; f32-class accuracy (error vs float64 at or below a sequential f32
+    chain's) at ~3x the speed -- is what the drop-in selects and what bench.py measures.  "chain" (env GIGAPOSE_NUMERICS=chain,
+    `numerics: chain` in the model YAML, or model.set_numerics("chain")) is the verification mode: f32-input MFMA, every dot
+    product the k-ordered fmaf chain the CPU oracle restates, bit-exact against it."""
+    mode = os.environ.get("GIGAPOSE_NUMERICS", "split")
+    if mode not in NUMERICS:
+        raise ValueError(f"GIGAPOSE_NUMERICS must be one of {NUMERICS}, got {mode!r}")
+    return mode
+
+
 def build(verbose=False):
     """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
     import subprocess

@@ -88,7 +88,8 @@ template <bool PERM = false, class SM>
 __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int b, int n, int N, float thr, float patch_thr,
                                                uint8_t* __restrict__ idx_t2s, float* __restrict__ score_t2s,
                                                float* __restrict__ mask_all, float* __restrict__ sim_avg,
-                                               unsigned long long* trace = nullptr)  // probe build only: 8 stamps per tile
+                                               unsigned long long* trace = nullptr,  // probe build only: 8 stamps per tile
+                                               int src2tar = 0)  // search_direction == "src2tar" (matching.py:242-244)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -217,22 +218,33 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
     if (trace && tid == 0) trace[4] = wall_clock64();
 
     // ---- masks + per-patch outputs   (matching.py:247-271, find_consistency_patches :80-113)
+    // "A" is what the reference calls tar2src and "B" its src2tar: with search_direction == "tar2src" A = the row maxima (over s,
+    // per query patch t) and B = the column maxima; "src2tar" (matching.py:242-244) exchanges them and every later step keeps
+    // indexing by POSITION p = 0..255 -- tar_mask at p, src_mask at the matched index (:260-261), whatever p stands for.
     if (tid < GP_P) {
         const int t = tid;
-        const int js = sm.id_t2s[t];
-        const float sc = sm.sc_t2s[t];
+        const float* sc_a = src2tar ? sm.sc_s2t : sm.sc_t2s;
+        const int* id_a = src2tar ? sm.id_s2t : sm.id_t2s;
+        const float* sc_b = src2tar ? sm.sc_t2s : sm.sc_s2t;
+        const int* id_b = src2tar ? sm.id_t2s : sm.id_s2t;
+        const int js = id_a[t];
+        const float sc = sc_a[t];
         const bool mask_sim = sc >= thr;
-        const int t2 = sm.id_s2t[js];
-        const float dx = (float)(t2 % GP_G) - (float)(t % GP_G);
-        const float dy = (float)(t2 / GP_G) - (float)(t / GP_G);
-        const float dist = __builtin_sqrtf(dx * dx + dy * dy);
-        const bool mask_dist = dist <= patch_thr;
-        const bool mask_sim2 = sm.sc_s2t[js] >= thr;
+        bool mask_cycle = true;  // patch_threshold <= 0: the reference skips the cycle check (matching.py:256-257)
+        if (patch_thr > 0.f) {
+            const int t2 = id_b[js];
+            const float dx = (float)(t2 % GP_G) - (float)(t % GP_G);
+            const float dy = (float)(t2 / GP_G) - (float)(t / GP_G);
+            const float dist = __builtin_sqrtf(dx * dx + dy * dy);
+            const bool mask_dist = dist <= patch_thr;
+            const bool mask_sim2 = sc_b[js] >= thr;
+            mask_cycle = mask_dist && mask_sim2;
+        }
         // reference quirk: (idx_src2tar != 0) is applied at POSITION t, not at the matched s
         float nz = sm.qmask[t] * sm.smask[js];
-        nz = nz * (float)(sm.id_s2t[t] != 0);
+        nz = nz * (float)(id_b[t] != 0);
         nz = nz * (float)(js != 0);
-        const float m = (float)(mask_sim && mask_dist && mask_sim2) * nz;
+        const float m = (float)(mask_sim && mask_cycle) * nz;
         const size_t o = ((size_t)b * N + n) * GP_P + t;
         idx_t2s[o] = (uint8_t)js;
         score_t2s[o] = sc;
@@ -275,7 +287,8 @@ __global__ __launch_bounds__(512, 2) void match_tiles_kernel(
     uint8_t* __restrict__ idx_t2s,    // (B, N, 256)
     float* __restrict__ score_t2s,    // (B, N, 256)
     float* __restrict__ mask_all,     // (B, N, 256)
-    float* __restrict__ sim_avg)      // (B, N)
+    float* __restrict__ sim_avg,      // (B, N)
+    int src2tar)
 {
     __shared__ MatchSmem sm;
     const int q = xcd_chunked_tile(blockIdx.x, B * N);
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void match_tiles_kernel(
     f32x16 acc[2][4];
     MM::run(A, GP_P, Bm, GP_P, C, sm.stage, acc);  // ends with __syncthreads(): masks visible
 
-    match_epilogue(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg);
+    match_epilogue(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg, nullptr, src2tar);
 }
 
 // ------------------------------------------------------------------ split-f16 matcher (opt-in numerics)
@@ -464,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     const _Float16* __restrict__ b_hi, const _Float16* __restrict__ b_lo,  // (O*N, 256, C)
     const float* __restrict__ qmask, const float* __restrict__ bmask, const int* __restrict__ labels, int B, int O, int N, int C,
     float thr, float patch_thr, int* __restrict__ status, uint8_t* __restrict__ idx_t2s, float* __restrict__ score_t2s,
-    float* __restrict__ mask_all, float* __restrict__ sim_avg, unsigned long long* __restrict__ trace_all, int compact)
+    float* __restrict__ mask_all, float* __restrict__ sim_avg, unsigned long long* __restrict__ trace_all, int compact, int src2tar)
 {
     __shared__ MatchSplitSmem sm;
     const unsigned long long w_in = TRACE ? wall_clock64() : 0;
@@ -577,7 +590,7 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= inv;
-    match_epilogue<true>(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg, trace);
+    match_epilogue<true>(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg, trace, src2tar);
 }
 
 // norms of gp_l2norm_cp (same sequential fma over c), then x / d * 32 split into f16 planes [row][patch][C].
@@ -710,11 +723,12 @@ int gp_l2norm_cp(const float* x, float* out, int rows, int C, void* stream)
     return GP_OK;
 }
 
-int gp_match_tiles(const float* query, const float* bank, const float* qmask, const float* bmask,
-                   const int* labels, int B, int O, int N, int C, float sim_threshold,
-                   float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
-                   float* sim_avg, void* stream)
+int gp_match_tiles_dir(const float* query, const float* bank, const float* qmask, const float* bmask,
+                       const int* labels, int B, int O, int N, int C, float sim_threshold,
+                       float patch_threshold, int search_direction, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
+                       float* sim_avg, void* stream)
 {
+    GP_REQUIRE(search_direction == 0 || search_direction == 1, "gp_match_tiles: search_direction must be 0 (tar2src) or 1 (src2tar)");
     GP_REQUIRE(B >= 0 && O > 0 && N > 0, "gp_match_tiles: bad sizes B=%d O=%d N=%d", B, O, N);
     GP_REQUIRE(C > 0 && C % 16 == 0, "gp_match_tiles: C=%d must be a positive multiple of 16", C);
     if (B == 0) return GP_OK;
@@ -723,9 +737,18 @@ int gp_match_tiles(const float* query, const float* bank, const float* qmask, co
     GpProfScope prof(GP_PROF_MATCH, 2.0 * B * N * 256.0 * 256.0 * C, (hipStream_t)stream);
     hipLaunchKernelGGL(match_tiles_kernel, dim3(xcd_chunked_grid(B * N)), dim3(512), 0,
                        (hipStream_t)stream, query, bank, qmask, bmask, labels, B, O, N, C, sim_threshold,
-                       patch_threshold, gp_status_buffer(), idx_t2s, score_t2s, mask_all, sim_avg);
+                       patch_threshold, gp_status_buffer(), idx_t2s, score_t2s, mask_all, sim_avg, search_direction);
     GP_CHECK_LAUNCH("gp_match_tiles");
     return GP_OK;
+}
+
+int gp_match_tiles(const float* query, const float* bank, const float* qmask, const float* bmask,
+                   const int* labels, int B, int O, int N, int C, float sim_threshold,
+                   float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
+                   float* sim_avg, void* stream)
+{
+    return gp_match_tiles_dir(query, bank, qmask, bmask, labels, B, O, N, C, sim_threshold, patch_threshold, 0, idx_t2s, score_t2s,
+                              mask_all, sim_avg, stream);
 }
 
 int gp_l2norm_split(const float* x, void* hi, void* lo, int rows, int C, void* stream)
@@ -745,8 +768,13 @@ static int g_match_compact = 1;  // 0: every patch treated as live = the full 25
 static int match_tiles_split_launch(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
                                     const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
                                     float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
-                                    unsigned long long* trace, void* stream)
+                                    unsigned long long* trace, void* stream, int search_direction = 0)
 {
+    GP_REQUIRE(search_direction == 0 || search_direction == 1, "gp_match_tiles_split: search_direction must be 0 (tar2src) or 1 (src2tar)");
+    // Live-patch compaction is bit-identical to the full tile only when every surviving similarity is >= 0 (match_epilogue<PERM>: a
+    // row maximum of 0 then means an all-zero row, argmax 0).  With a negative threshold live values in [thr, 0) survive and the
+    // masked-out patches' exact zeros win the reference's maximum: such calls run the full 256 x 256 tile.
+    const int compact = (g_match_compact && sim_threshold >= 0.f) ? 1 : 0;
     GP_REQUIRE(B >= 0 && O > 0 && N > 0, "gp_match_tiles_split: bad sizes B=%d O=%d N=%d", B, O, N);
     GP_REQUIRE(C > 0 && C % 32 == 0, "gp_match_tiles_split: C=%d must be a positive multiple of 32", C);
     if (B == 0) return GP_OK;
@@ -758,7 +786,7 @@ static int match_tiles_split_launch(const void* q_hi, const void* q_lo, const vo
     hipLaunchKernelGGL((match_tiles_split_kernel<LO, TR>), dim3(xcd_chunked_grid(B * N)), dim3(512), 0, (hipStream_t)stream,      \
                        (const _Float16*)q_hi, (const _Float16*)q_lo, (const _Float16*)b_hi, (const _Float16*)b_lo, qmask, bmask,  \
                        labels, B, O, N, C, sim_threshold, patch_threshold, gp_status_buffer(), idx_t2s, score_t2s, mask_all,      \
-                       sim_avg, trace, g_match_compact)
+                       sim_avg, trace, compact, search_direction)
     if (trace) {
         GP_REQUIRE(b_lo, "gp_match_tiles_split_trace: the probe build takes the two-plane bank");
         GP_MATCH_SPLIT_LAUNCH(true, true);
@@ -779,6 +807,15 @@ int gp_match_tiles_split(const void* q_hi, const void* q_lo, const void* b_hi, c
 {
     return match_tiles_split_launch(q_hi, q_lo, b_hi, b_lo, qmask, bmask, labels, B, O, N, C, sim_threshold, patch_threshold,
                                     idx_t2s, score_t2s, mask_all, sim_avg, nullptr, stream);
+}
+
+int gp_match_tiles_split_dir(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
+                             const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
+                             float patch_threshold, int search_direction, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
+                             float* sim_avg, void* stream)
+{
+    return match_tiles_split_launch(q_hi, q_lo, b_hi, b_lo, qmask, bmask, labels, B, O, N, C, sim_threshold, patch_threshold,
+                                    idx_t2s, score_t2s, mask_all, sim_avg, nullptr, stream, search_direction);
 }
 
 // probe build: trace[(tile q) * 8 + i] = 100 MHz wall-clock stamps (0 entry, 1 first slab staged, 2 k loop done, 3 maxima,

@@ -512,7 +512,10 @@ int gp_gemm_split_launch_limited(const float* act, int ld_act, const void* whi, 
                "gp_gemm_split: null / misaligned operand");
     GP_REQUIRE((long long)I * ldd < (1ll << 31) && (long long)I * (ldr > 0 ? ldr : 1) < (1ll << 31), "gp_gemm_split: output too large");
     SplitArgs a{act, ld_act, (const _Float16*)whi, (const _Float16*)wlo, D, ldd, K, bias, scale, res, ldr, I / SBM, J / SBN, 8, j_limit};
-    GpProfScope prof(GP_PROF_GEMM_SPLIT, 2.0 * I * J * K, st);  // algorithmic flops (the kernel executes 3x as f16 MFMAs)
+    // algorithmic flops (the kernel executes 3x as f16 MFMAs).  Column-limited launches (the IST regressor's compacted rows) compute
+    // an unknown fraction of their J columns (the count lives on the device): they are timed as "other", with no work figure, so
+    // that the TFLOP/s of the gemm_split family -- the roofline's kernel -- is not overstated by work that was skipped.
+    GpProfScope prof(j_limit ? GP_PROF_OTHER : GP_PROF_GEMM_SPLIT, j_limit ? 0.0 : 2.0 * I * J * K, st);
     switch (epilogue) {
         case SEPI_NONE: launch_split<SEPI_NONE>(a, act_is_b != 0, st); break;
         case SEPI_BIAS_I: launch_split<SEPI_BIAS_I>(a, act_is_b != 0, st); break;

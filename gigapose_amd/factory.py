@@ -19,14 +19,14 @@ IST_CFG = dict(n_heads=0, input_dim=3, input_size=256, initial_dim=128, block_di
                descriptor_size=256)
 
 
-def build_model(variant="dinov2_vitl14", k=5, device="cuda", seed=0, log_dir=None):
+def build_model(variant="dinov2_vitl14", k=5, device="cuda", seed=0, log_dir=None, numerics=None):
     dim, depth, heads = VARIANTS[variant]
     vit = syn.fill_state_dict(Dinov2ViT(dim, depth, heads), seed + 1)
     ae = AENet(variant, vit, descriptor_size=dim, max_batch_size=64)
     ist = syn.fill_state_dict(ISTNet("resnet", ResNet(dict(IST_CFG)), Regressor(256, 256, True, True), 64), seed + 2)
     metric = LocalSimilarity(k=k, sim_threshold=0.5, patch_threshold=3)
     model = GigaPose("large", ae, ist, None, metric, None, 1000, log_dir or tempfile.mkdtemp(prefix="gigapose_"),
-                     max_num_dets_per_forward=4)
+                     max_num_dets_per_forward=4, numerics=numerics)
     return model.eval().to(device)
 
 

@@ -83,7 +83,12 @@ def rank_hypotheses(pred, sort=True):
 class GigaPose(_Base):
     def __init__(self, model_name, ae_net, ist_net, training_loss, testing_metric, optim_config, log_interval,
                  log_dir, max_num_dets_per_forward=None, test_setting="localization", **kwargs):
+        """Reference signature (gigaPose.py:35-48).  One optional key is read from **kwargs (where the reference's own YAML already
+        passes `refiner` / `checkpoint_path`): `numerics` ("split" | "chain"; a `numerics:` line in the model YAML next to the
+        `_target_` edits of INTEGRATION.md section 1).  Absent = _lib.default_numerics(): "split" unless GIGAPOSE_NUMERICS=chain
+        -- the drop-in runs the numerics bench.py measures; "chain" is the verification mode."""
         super().__init__()
+        numerics = kwargs.pop("numerics", None)
         self.model_name = model_name
         self.ae_net = ae_net
         self.ist_net = ist_net
@@ -108,11 +113,16 @@ class GigaPose(_Base):
         # step inside the two-stream region) for a 0-1 % gain in step time -- off by default, kept as a switch.
         self.overlap_ist = False
         self._side_stream = None
+        if numerics is not None:
+            self.set_numerics(numerics)
 
     def set_numerics(self, mode):
-        """"chain": f32 fmaf-chain kernels (bit-exact vs the CPU oracle; default).  "split": the ViT linear layers and
-        the template matcher run as 3 x f16 MFMA on split operands (f32-equivalent accuracy).
-        Call before set_template_data (the bank is stored in the matcher's format)."""
+        """"split" (default): the ViT linear layers + attention, the template matcher and the IST convolutions / MLP run as
+        3 x f16 MFMA on split f32 operands (f32-equivalent accuracy).  "chain": f32 fmaf-chain kernels,
+        bit-exact vs the CPU oracle (the verification mode).  Call before set_template_data (the bank is stored in the
+        matcher's format; banks already onboarded are dropped)."""
+        if mode not in _lib.NUMERICS:
+            raise ValueError(f"numerics must be one of {_lib.NUMERICS}")
         self.ae_net.dinov2_model.set_numerics(mode)
         self.testing_metric.numerics = mode
         self.ist_net.backbone.set_numerics(mode)
@@ -140,8 +150,32 @@ class GigaPose(_Base):
         if changed:
             warnings.warn("split numerics: an activation left the range of the f16 planes (|x| >= 8190); falling back for this model: "
                           + "; ".join(changed) + ".  Template banks are rebuilt.", RuntimeWarning)
+            # every bank was built by the kernels that just left: rebuild ALL of them now (a later predict() on another dataset must
+            # not hit a KeyError, and one model must not hold banks made by different kernels); outside any step timing
+            names = list(self.template_datas)
             self.template_datas, self.match_banks, self.pose_recovery = {}, {}, {}
+            for name in names:
+                self.set_template_data(name)
         return bool(changed)
+
+    def _collect_status(self):
+        """Read + clear the guard-rail bits at a point where the host synchronises anyway.  With a sharded template bank the
+        decision they drive (range fallback = re-onboarding + a second pass through the collectives) must be taken by ALL ranks
+        together: each rank runs the ViT on its own crops, so one rank may see the range bit while its peers see none -- it would
+        re-enter predict() and pair its all-gather with the peers' NEXT step (a hang, or rows of different steps exchanged
+        silently).  The bits are therefore OR-ed over the group first (one tiny all-reduce per call, MAX over per-bit flags:
+        RCCL has no bitwise OR), so every rank widens and retries, or none does."""
+        bits = _lib.take_status()
+        if self.template_shard is not None:
+            import torch.distributed as dist
+
+            _, world, group = self.template_shard
+            if world > 1:
+                dev = self.device if dist.get_backend(group) != "gloo" else torch.device("cpu")
+                flags = torch.tensor([(bits >> b) & 1 for b in range(16)], dtype=torch.int32, device=dev)
+                dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+                bits = sum(int(f) << b for b, f in enumerate(flags.tolist()))
+        return bits
 
     def enable_template_sharding(self, group=None):
         """Shard the template bank over the ranks of `group` (gigapose_amd/sharding.py).  Call
@@ -190,8 +224,10 @@ class GigaPose(_Base):
         self.pose_recovery[dataset_name] = ObjectPoseRecovery(template_K=data["K"], template_Ms=data["M"],
                                                               template_poses=data["poses"])
         torch.cuda.synchronize()
-        bits = _lib.take_status()
+        bits = self._collect_status()
         if bits & _lib.SPLIT_RANGE_BITS and self._widen_split_range(bits):
+            if dataset_name in self.template_datas:              # _widen_split_range rebuilt every bank, this one included
+                return
             return self.set_template_data(dataset_name)          # once more with the wide-range kernels (then any bit raises)
         _lib.raise_status(bits)
         self.onboarding_time = (time.time() - t0) / max(1, len(template_dataset))
@@ -260,7 +296,7 @@ class GigaPose(_Base):
         predictions = self.predict(batch.tar_img, batch.tar_mask, batch.tar_K, batch.tar_M, labels, dataset_name,
                                    sort_pred_by_inliers)
         torch.cuda.synchronize()
-        bits = _lib.take_status()  # guard rails: lost hand-off / split range / label range -> GigaPoseHipError, never silent garbage
+        bits = self._collect_status()  # guard rails: lost hand-off / split range / label range -> GigaPoseHipError, never silent garbage
         if bits & _lib.SPLIT_RANGE_BITS and self._widen_split_range(bits):
             return self.eval_retrieval(batch, idx_batch, dataset_name, sort_pred_by_inliers)   # re-onboards, runs again; a second trip raises
         _lib.raise_status(bits)

@@ -62,7 +62,7 @@ class ResNet(nn.Module):
         self._split = None
         self._planes = None
         self._conv_scratch = None
-        self.numerics = os.environ.get("GIGAPOSE_NUMERICS", "chain")  # "chain" | "split" 
+        self.numerics = _lib.default_numerics()  # "split" (default) | "chain" 
         # split numerics: "256" = conv_planes_kernel (gp_conv256.hip: 256-pixel tiles, single accumulator, plane GEMM loop;
         # needs B*OH*OW % 256 == 0, always true from the 16 x 16 output grid up); "128" = the first-generation 128 x 128 kernel
         self.conv_kernel = os.environ.get("GIGAPOSE_SPLIT_CONV", "256")
@@ -394,7 +394,9 @@ class ISTNet(nn.Module):
         lib.gp_ist_workspace_bytes.restype = ctypes.c_size_t
         need = lib.gp_ist_workspace_bytes(_lib.i(B), _lib.i(k), _lib.i(D), _lib.i(H))
         if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != dev:
-            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+            # zeroed once: the regressor's GEMMs run over compacted rows and the last 128-column tile is only partly filled --
+            # its stale columns (never read back) must at least be finite, whatever the allocator handed out
+            self._ws = torch.zeros((need + 3) // 4, dtype=torch.float32, device=dev)
         _, tensors, table, _ = self._packed
         _lib.call("gp_ist_regress", _lib.ptr(tar_feat.contiguous().float()), _lib.ptr(ist_bank.contiguous()),
                   _lib.ptr(labels0.to(torch.int32).contiguous()), _lib.ptr(id_src.contiguous()),

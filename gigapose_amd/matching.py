@@ -30,9 +30,7 @@ def patch_grid_mask(mask224):
     return m.reshape(*m.shape[:-2], P).contiguous()
 
 
-def default_numerics():
-    """"chain" (f32 fmaf chain, bit-exact vs the CPU oracle) or "split" (3 x f16 MFMA, f32-equivalent)."""
-    return os.environ.get("GIGAPOSE_NUMERICS", "chain")
+default_numerics = _lib.default_numerics   # "split" unless GIGAPOSE_NUMERICS=chain (the verification mode)
 
 
 def normalize_split(feats):
@@ -80,8 +78,9 @@ class LocalSimilarity(torch.nn.Module):
     def __init__(self, k, sim_threshold, patch_threshold, search_direction="tar2src",
                  image_size=224, patch_size=14, max_batch_size=32):
         super().__init__()
-        if search_direction != "tar2src":
-            raise NotImplementedError("only search_direction='tar2src' (the reference default) is built")
+        if search_direction not in ("tar2src", "src2tar"):
+            # the reference would fail later with an UnboundLocalError (matching.py:239-247: neither branch assigns)
+            raise ValueError(f"search_direction must be 'tar2src' or 'src2tar', got {search_direction!r}")
         self.max_batch_size = max_batch_size
         self.k = k
         self.sim_threshold = sim_threshold
@@ -90,9 +89,7 @@ class LocalSimilarity(torch.nn.Module):
         self.num_patches = image_size // patch_size
         self.numerics = default_numerics()
         self.bank_dtype = None  # None: MatchBank's default (env GIGAPOSE_BANK_DTYPE or "f32"); "f16": hi-plane-only bank
-        if patch_threshold <= 0:
-            raise NotImplementedError("patch_threshold must be > 0 (reference default 3; <= 0 disables the "
-                                      "cycle check in the reference, which is not built)")
+        # patch_threshold <= 0: no cycle check (reference matching.py:256-257) -- the kernels take it as is
         if self.num_patches != 16:
             raise NotImplementedError("kernels are specialised for a 16x16 patch grid (224/14)")
 
@@ -108,7 +105,7 @@ class LocalSimilarity(torch.nn.Module):
         _lib.call("gp_l2norm_cp", _lib.ptr(x), _lib.ptr(out), _lib.i(rows), _lib.i(C), _lib.stream_ptr())
         return out
 
-    def match_tiles(self, query, qmask, bank, labels0):
+    def match_tiles(self, query, qmask, bank, labels0, search_direction=None):
         """All (detection, template) tiles.  query (B,C,256) normalised, qmask (B,256),
         bank: MatchBank, labels0 (B,) int32 0-based.  Returns idx_t2s u8, score_t2s, mask_all
         (B,N,256) and sim_avg (B,N)."""
@@ -122,17 +119,18 @@ class LocalSimilarity(torch.nn.Module):
         sc = torch.empty(B, N, P, dtype=torch.float32, device=dev)
         ma = torch.empty(B, N, P, dtype=torch.float32, device=dev)
         avg = torch.empty(B, N, dtype=torch.float32, device=dev)
+        direction = 1 if (search_direction or self.search_direction) == "src2tar" else 0   # reference matching.py:239-244
         if split:
             if "GIGAPOSE_MATCH_COMPACT" in os.environ:   # A/B probe: 0 = full 256 x 256 tiles (masked-out patches computed as zeros)
                 _lib.lib().gp_match_split_set_compact(int(os.environ["GIGAPOSE_MATCH_COMPACT"]))
-            _lib.call("gp_match_tiles_split", _lib.ptr(query[0]), _lib.ptr(query[1]), _lib.ptr(bank.hi), _lib.ptr(bank.lo),
+            _lib.call("gp_match_tiles_split_dir", _lib.ptr(query[0]), _lib.ptr(query[1]), _lib.ptr(bank.hi), _lib.ptr(bank.lo),
                       _lib.ptr(qmask), _lib.ptr(bank.masks), _lib.ptr(labels0), _lib.i(B), _lib.i(bank.O), _lib.i(N),
-                      _lib.i(C), _lib.f(self.sim_threshold), _lib.f(self.patch_threshold), _lib.ptr(idx), _lib.ptr(sc),
-                      _lib.ptr(ma), _lib.ptr(avg), _lib.stream_ptr())
+                      _lib.i(C), _lib.f(self.sim_threshold), _lib.f(self.patch_threshold), _lib.i(direction), _lib.ptr(idx),
+                      _lib.ptr(sc), _lib.ptr(ma), _lib.ptr(avg), _lib.stream_ptr())
             return idx, sc, ma, avg
-        _lib.call("gp_match_tiles", _lib.ptr(query), _lib.ptr(bank.features), _lib.ptr(qmask),
+        _lib.call("gp_match_tiles_dir", _lib.ptr(query), _lib.ptr(bank.features), _lib.ptr(qmask),
                   _lib.ptr(bank.masks), _lib.ptr(labels0), _lib.i(B), _lib.i(bank.O), _lib.i(N), _lib.i(C),
-                  _lib.f(self.sim_threshold), _lib.f(self.patch_threshold), _lib.ptr(idx), _lib.ptr(sc),
+                  _lib.f(self.sim_threshold), _lib.f(self.patch_threshold), _lib.i(direction), _lib.ptr(idx), _lib.ptr(sc),
                   _lib.ptr(ma), _lib.ptr(avg), _lib.stream_ptr())
         return idx, sc, ma, avg
 
@@ -184,11 +182,14 @@ class LocalSimilarity(torch.nn.Module):
         """src_feat / tar_feat (B,C,16,16), masks (B,224,224): detection b against ITS OWN template -- the same
         fused tile kernel with one template per 'object'.  Returns src_pts, tar_pts (B,256,2) int64 (-1 = invalid)
         and score (B,256) = the raw best similarity per query patch."""
+        if self.patch_threshold <= 0:
+            raise ValueError("patch_threshold must be greater than 0")                      # reference matching.py:158-159
         B = tar_feat.shape[0]
         dev = tar_feat.device
         bank = MatchBank(src_feat.unsqueeze(1), src_mask.unsqueeze(1), self.numerics)      # O = B objects x N = 1
         labels0 = torch.arange(B, dtype=torch.int32, device=dev)
-        idx, sc, ma, _ = self.match_tiles(self.normalize(tar_feat), patch_grid_mask(tar_mask), bank, labels0)
+        # `val` always searches tar2src (matching.py:147-148), whatever search_direction the metric was built with
+        idx, sc, ma, _ = self.match_tiles(self.normalize(tar_feat), patch_grid_mask(tar_mask), bank, labels0, "tar2src")
         tar_pts, src_pts = self.format_points(idx.contiguous(), ma.contiguous())            # (B,1,256,2)
         return PandasTensorCollection(infos=pd.DataFrame(), src_pts=src_pts[:, 0], tar_pts=tar_pts[:, 0], score=sc[:, 0])
 

@@ -23,9 +23,10 @@ VARIANTS = {  # name: (dim, depth, heads)
 }
 T = 257
 # Numerics of the linear layers:
-#   "chain": f32-input MFMA, every dot product is the sequential fmaf chain the CPU oracle restates (bit-exact parity)
-#   "split": each f32 operand split into two f16 halves, 3 f16 MFMAs per k-block with f32 accumulation
-#            (gp_split.hip): f32-equivalent accuracy (measured error vs f64 below the chain's), ~2x faster
+#   "split" (default): each f32 operand split into two f16 halves, 3 f16 MFMAs per k-block with f32 accumulation
+#            (gp_split.hip / gp_split256.hip): f32-equivalent accuracy (measured error vs f64 below the chain's), ~3x faster
+#   "chain": f32-input MFMA, every dot product is the sequential fmaf chain the CPU oracle restates (bit-exact parity;
+#            the verification mode)
 NUMERICS = ("chain", "split")
 
 
@@ -81,7 +82,7 @@ class Dinov2ViT(nn.Module):
         self.norm = nn.LayerNorm(dim, eps=1e-6)  # final norm: present in checkpoints, not applied
         self._packed = None
         self._ws = None
-        self.numerics = os.environ.get("GIGAPOSE_NUMERICS", "chain")
+        self.numerics = _lib.default_numerics()   # "split" unless GIGAPOSE_NUMERICS=chain (_lib.default_numerics)
         # split numerics: "256" = single-accumulator plane kernels (activations x 8 in f16 planes: |x| < 8190, guarded);
         # "128" = every GEMM on the two-accumulator 128 x 128 kernel (range 65504, slower).  GigaPose switches to "128" by itself
         # when the range guard trips (gigaPose.py: _widen_split_range) -- DINOv2 checkpoints are known for a few massive activations

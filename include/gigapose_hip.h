@@ -88,7 +88,15 @@ int gp_match_tiles(const float* query, const float* bank, const float* qmask, co
                    float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
                    float* sim_avg, void* stream);
 
-/* Split-f16 numerics of the matcher (opt-in; same outputs as gp_match_tiles up to f32 round-off: the similarity
+/* The same launch with the reference's `search_direction` ctor argument (matching.py:18, :239-244): 0 = "tar2src" (default:
+ * gp_match_tiles), 1 = "src2tar" (the row / column argmax pairs exchange roles; masks stay positional as in the reference).
+ * patch_threshold <= 0 in any of the match entry points = no cycle check (matching.py:256-257: mask_cycle = ones). */
+int gp_match_tiles_dir(const float* query, const float* bank, const float* qmask, const float* bmask,
+                       const int* labels, int B, int O, int N, int C, float sim_threshold,
+                       float patch_threshold, int search_direction, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
+                       float* sim_avg, void* stream);
+
+/* Split-f16 numerics of the matcher (same outputs as gp_match_tiles up to f32 round-off: the similarity
  * tile is computed as 3 f16 MFMAs per k-block on operands split into f16 halves, f32 accumulation; gp_split.hip).
  * gp_l2norm_split: x (rows, C, 256) f32 -> F.normalize(x, dim=C) * 32 as two f16 planes hi / lo, each
  * (rows, 256, Cp), Cp = round_up(C, 32), zero padded (value ~= (hi + lo) / 32).
@@ -99,6 +107,10 @@ int gp_match_tiles_split(const void* q_hi, const void* q_lo, const void* b_hi, c
                          const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
                          float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
                          void* stream);
+int gp_match_tiles_split_dir(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
+                             const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
+                             float patch_threshold, int search_direction, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
+                             float* sim_avg, void* stream);
 /* probe build of gp_match_tiles_split (two-plane bank) writing 8 time stamps per tile, see gp_match.hip */
 int gp_match_tiles_split_trace(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
                          const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,

@@ -59,8 +59,9 @@ def patch_mask(mask224):
     return np.ascontiguousarray(m[..., ::14, ::14]).reshape(*m.shape[:-2], P)
 
 
-def match(query, bank, qmask, bmask, labels, thr=0.5, patch_thr=3.0):
-    """LocalSimilarity.test steps 3-8 (matching.py:233-278) on matcher-normalised features.
+def match(query, bank, qmask, bmask, labels, thr=0.5, patch_thr=3.0, search_direction="tar2src"):
+    """LocalSimilarity.test steps 3-8 (matching.py:233-278) on matcher-normalised features; search_direction as the reference's
+    ctor argument (matching.py:239-244), patch_thr <= 0 = no cycle check (matching.py:256-257).
 
     query (B,C,P), bank (O,N,C,P), qmask (B,P), bmask (O,N,P), labels (B,) 0-based.
     Returns idx_t2s u8 (B,N,P), score_t2s f32 (B,N,P), mask_all f32 (B,N,P), sim_avg f32 (B,N).
@@ -75,10 +76,11 @@ def match(query, bank, qmask, bmask, labels, thr=0.5, patch_thr=3.0):
     sc = np.empty((B, N, P), np.float32)
     ma = np.empty((B, N, P), np.float32)
     avg = np.empty((B, N), np.float32)
-    lib().oracle_match(_p(query), _p(bank), _p(qmask), _p(bmask), _p(labels),
-                       ctypes.c_int(B), ctypes.c_int(O), ctypes.c_int(N), ctypes.c_int(C),
-                       ctypes.c_float(thr), ctypes.c_float(patch_thr),
-                       _p(idx), _p(sc), _p(ma), _p(avg))
+    assert search_direction in ("tar2src", "src2tar")
+    lib().oracle_match_dir(_p(query), _p(bank), _p(qmask), _p(bmask), _p(labels),
+                           ctypes.c_int(B), ctypes.c_int(O), ctypes.c_int(N), ctypes.c_int(C),
+                           ctypes.c_float(thr), ctypes.c_float(patch_thr), ctypes.c_int(int(search_direction == "src2tar")),
+                           _p(idx), _p(sc), _p(ma), _p(avg))
     return idx, sc, ma, avg
 
 
@@ -106,7 +108,7 @@ def gather_format(ids, idx_t2s, score_t2s, mask_all):
 
 
 def local_similarity_test(src_feats, tar_feat, src_masks224, tar_mask224, labels, k,
-                          thr=0.5, patch_thr=3.0):
+                          thr=0.5, patch_thr=3.0, search_direction="tar2src"):
     """Whole LocalSimilarity.test (matching.py:188-316) against a resident bank.
 
     src_feats (O,N,C,16,16) AENet-normalised bank; tar_feat (B,C,16,16); masks at 224x224.
@@ -117,7 +119,7 @@ def local_similarity_test(src_feats, tar_feat, src_masks224, tar_mask224, labels
     q = l2norm_cp(np.asarray(tar_feat).reshape(B, C, P))
     bank = l2norm_cp(np.asarray(src_feats).reshape(O, N, C, P))
     idx, sc, ma, avg = match(q, bank, patch_mask(tar_mask224), patch_mask(src_masks224), labels,
-                             thr, patch_thr)
+                             thr, patch_thr, search_direction)
     ids, score_src = topk(avg, k)
     score_pts, tar_pts, src_pts = gather_format(ids, idx, sc, ma)
     return dict(id_src=ids.astype(np.int64), score_src=score_src, score_pts=score_pts,

@@ -57,7 +57,7 @@ void oracle_l2norm_cp(const float* x, float* out, int rows, int C)
  * outputs: idx_t2s (P) u8, score_t2s (P), mask_all (P), *sim_avg
  * ---------------------------------------------------------------------------------- */
 static void match_tile(const float* q, const float* s, const float* qmask, const float* smask,
-                       int C, float thr, float patch_thr,
+                       int C, float thr, float patch_thr, int src2tar,
                        uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
                        float* sim /* scratch P*P */)
 {
@@ -80,37 +80,47 @@ static void match_tile(const float* q, const float* s, const float* qmask, const
             if (v < thr) v = 0.f;
             sim[t * P + j] = v;
         }
-    /* torch.max over s and over t: first maximal index (matching.py:239-241) */
-    float sc_s2t[P]; int id_s2t[P]; int id_t2s[P];
+    /* torch.max over s and over t: first maximal index (matching.py:239-244).  "A" is what the reference calls tar2src, "B" its
+     * src2tar: search_direction == "tar2src" (:239-241): A = maxima over s per query patch t, B = maxima over t per template patch
+     * s; "src2tar" (:242-244): the two exchanged -- every later step indexes them by POSITION p = 0..255 whatever p means. */
+    float sc_row[P]; int id_row[P]; float sc_col[P]; int id_col[P];
     for (int t = 0; t < P; ++t) {
         float best = sim[t * P]; int bi = 0;
         for (int j = 1; j < P; ++j) if (sim[t * P + j] > best) { best = sim[t * P + j]; bi = j; }
-        score_t2s[t] = best; id_t2s[t] = bi;
+        sc_row[t] = best; id_row[t] = bi;
     }
     for (int j = 0; j < P; ++j) {
         float best = sim[j]; int bi = 0;
         for (int t = 1; t < P; ++t) if (sim[t * P + j] > best) { best = sim[t * P + j]; bi = t; }
-        sc_s2t[j] = best; id_s2t[j] = bi;
+        sc_col[j] = best; id_col[j] = bi;
     }
+    const float* sc_a = src2tar ? sc_col : sc_row; const int* id_a = src2tar ? id_col : id_row;
+    const float* sc_b = src2tar ? sc_row : sc_col; const int* id_b = src2tar ? id_row : id_col;
     /* masks (matching.py:247-271) */
     float acc = 0.f, cnt = 0.f;
     for (int t = 0; t < P; ++t) {
-        int js = id_t2s[t];
-        int mask_sim = score_t2s[t] >= thr;                               /* :247 */
-        int t2 = id_s2t[js];                                              /* :96 gather */
-        float dx = (float)(t2 % G) - (float)(t % G);                      /* :98-99 (x=w, y=h) */
-        float dy = (float)(t2 / G) - (float)(t / G);
-        float dist = sqrtf(dx * dx + dy * dy);                            /* torch.norm :100 */
-        int mask_dist = dist <= patch_thr;                                /* :104 */
-        int mask_sim2 = sc_s2t[js] >= thr;                                /* :107-108 */
-        /* mask_non_zero (:263-268); NOTE quirk: (idx_src2tar != 0) is indexed by position t */
+        int js = id_a[t];
+        int mask_sim = sc_a[t] >= thr;                                    /* :247 */
+        int mask_cycle = 1;                                               /* :257 patch_threshold <= 0: ones */
+        if (patch_thr > 0.f) {                                            /* :250-255 find_consistency_patches */
+            int t2 = id_b[js];                                            /* :96 gather */
+            float dx = (float)(t2 % G) - (float)(t % G);                  /* :98-99 (x=w, y=h) */
+            float dy = (float)(t2 / G) - (float)(t / G);
+            float dist = sqrtf(dx * dx + dy * dy);                        /* torch.norm :100 */
+            int mask_dist = dist <= patch_thr;                            /* :104 */
+            int mask_sim2 = sc_b[js] >= thr;                              /* :107-108 */
+            mask_cycle = mask_dist && mask_sim2;
+        }
+        /* mask_non_zero (:263-268); NOTE quirks: (idx_src2tar != 0) is indexed by position t, and in either direction
+         * tar_mask is taken at position t and src_mask at the matched index (:260-261) */
         float nz = qmask[t] * smask[js];
-        nz = nz * (float)(id_s2t[t] != 0);
-        nz = nz * (float)(id_t2s[t] != 0);
-        float m = (float)(mask_sim && mask_dist && mask_sim2) * nz;       /* :271 */
+        nz = nz * (float)(id_b[t] != 0);
+        nz = nz * (float)(id_a[t] != 0);
+        float m = (float)(mask_sim && mask_cycle) * nz;                   /* :271 */
         mask_all[t] = m;
         idx_t2s[t] = (uint8_t)js;
-        acc = acc + score_t2s[t] * m;  /* fixed order: sequential over t (reference: torch.sum) */
+        score_t2s[t] = sc_a[t];
+        acc = acc + sc_a[t] * m;  /* fixed order: sequential over t (reference: torch.sum) */
         cnt = cnt + m;
     }
     *sim_avg = (cnt > 0.f) ? acc / 256.0f : 0.f;                          /* :274-278 */
@@ -118,9 +128,9 @@ static void match_tile(const float* q, const float* s, const float* qmask, const
 
 /* All (b, n) tiles.  labels are 0-based object indices (reference uses label-1,
  * gigaPose.py:520-521).  bank (O,N,C,P), bmask (O,N,P), query (B,C,P), qmask (B,P). */
-void oracle_match(const float* query, const float* bank, const float* qmask, const float* bmask,
-                  const int32_t* labels, int B, int O, int N, int C, float thr, float patch_thr,
-                  uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg)
+void oracle_match_dir(const float* query, const float* bank, const float* qmask, const float* bmask,
+                      const int32_t* labels, int B, int O, int N, int C, float thr, float patch_thr, int src2tar,
+                      uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg)
 {
     (void)O;
 #pragma omp parallel
@@ -132,11 +142,19 @@ void oracle_match(const float* query, const float* bank, const float* qmask, con
                 size_t o = (size_t)labels[b];
                 size_t bn = (size_t)b * N + n;
                 match_tile(query + (size_t)b * C * P, bank + (o * N + n) * (size_t)C * P,
-                           qmask + (size_t)b * P, bmask + (o * N + n) * P, C, thr, patch_thr,
+                           qmask + (size_t)b * P, bmask + (o * N + n) * P, C, thr, patch_thr, src2tar,
                            idx_t2s + bn * P, score_t2s + bn * P, mask_all + bn * P, sim_avg + bn, sim);
             }
         free(sim);
     }
+}
+
+/* search_direction = "tar2src", the reference default (matching.py:17) */
+void oracle_match(const float* query, const float* bank, const float* qmask, const float* bmask,
+                  const int32_t* labels, int B, int O, int N, int C, float thr, float patch_thr,
+                  uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg)
+{
+    oracle_match_dir(query, bank, qmask, bmask, labels, B, O, N, C, thr, patch_thr, 0, idx_t2s, score_t2s, mask_all, sim_avg);
 }
 
 /* torch.topk(sim_avg, k, dim=1) (matching.py:279).  Tie order is unspecified in torch;

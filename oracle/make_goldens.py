@@ -49,6 +49,35 @@ def gen_matcher():
               "valid pts:", int((out.tar_pts[..., 0] >= 0).sum()))
 
 
+# The ctor arguments the released configs do not use (round 4): search_direction = "src2tar" (matching.py:242-244) and
+# patch_threshold <= 0 = no cycle check (matching.py:256-257).  (name, matcher_case kwargs, k, search_direction, patch_threshold)
+MATCHER_VARIANT_CASES = [
+    ("match_s2t_small", dict(seed=11, B=3, O=2, N=6, C=32), 5, "src2tar", 3),
+    ("match_s2t_noshift", dict(seed=15, B=4, O=3, N=9, C=96, shift=False, noise=0.2), 5, "src2tar", 3),
+    ("match_nocycle_small", dict(seed=11, B=3, O=2, N=6, C=32), 5, "tar2src", 0),
+    ("match_nocycle_fullmask", dict(seed=14, B=2, O=2, N=7, C=48, full_masks=True), 5, "tar2src", -1),
+    ("match_s2t_nocycle_vits", dict(seed=12, B=2, O=1, N=8, C=384), 5, "src2tar", 0),
+]
+
+
+def gen_matcher_variants():
+    ref_shim.install()
+    from src.models.matching import LocalSimilarity
+
+    for name, kw, k, direction, patch_thr in MATCHER_VARIANT_CASES:
+        case = syn.matcher_case(**kw)
+        metric = LocalSimilarity(k=k, sim_threshold=0.5, patch_threshold=patch_thr, search_direction=direction)
+        labels = torch.from_numpy(case["labels"]).long()
+        out = metric.test(src_feats=torch.from_numpy(case["src_feats"])[labels], tar_feat=torch.from_numpy(case["tar_feat"]),
+                          src_masks=torch.from_numpy(case["src_masks"])[labels], tar_mask=torch.from_numpy(case["tar_mask"]))
+        np.savez_compressed(
+            os.path.join(GOLD, name + ".npz"), input_checksum=syn.checksum(*[case[x] for x in sorted(case)]),
+            case_kwargs=repr(kw), k=k, search_direction=direction, patch_threshold=patch_thr,
+            id_src=out.id_src.numpy(), score_src=out.score_src.numpy(), score_pts=out.score_pts.numpy(),
+            tar_pts=out.tar_pts.numpy().astype(np.int16), src_pts=out.src_pts.numpy().astype(np.int16))
+        print(name, direction, patch_thr, "id_src[0] =", out.id_src[0].tolist(), "valid pts:", int((out.tar_pts[..., 0] >= 0).sum()))
+
+
 # BASELINE config-2 / config-3 sized feature-level cases: (name, matcher_case kwargs, k)
 BIG_MATCHER_CASES = [
     ("match_cfg2", dict(seed=21, B=64, O=1, N=162, C=1024), 5),     # ViT-L width, 1 object x 162 templates, 64 crops
@@ -388,7 +417,7 @@ def gen_bop_csv():
     print("bop_csv:", [k for k in gold if k != "seed"])
 
 
-STAGES = {"bop_csv": gen_bop_csv, "val": gen_val, "matcher": gen_matcher, "ist": gen_ist, "pose": gen_pose, "e2e": gen_e2e, "crop": gen_crop,
+STAGES = {"bop_csv": gen_bop_csv, "val": gen_val, "matcher": gen_matcher, "matcher_variants": gen_matcher_variants, "ist": gen_ist, "pose": gen_pose, "e2e": gen_e2e, "crop": gen_crop,
           "matcher_big": lambda: gen_matcher_big(["match_cfg2", "match_cfg3"]), "matcher_cfg5": lambda: gen_matcher_big(["match_cfg5"]), "e2e_cfg2": lambda: gen_e2e("e2e_cfg2"), "e2e_cfg3": lambda: gen_e2e("e2e_cfg3"),
           "e2e_cfg2_f64": lambda: gen_e2e_f64("e2e_cfg2"), "e2e_cfg3_f64": lambda: gen_e2e_f64("e2e_cfg3"), "e2e_f64": lambda: gen_e2e_f64("e2e")}
 

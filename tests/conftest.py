@@ -30,3 +30,12 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _suite_numerics(monkeypatch):
+    """The product default is "split" (gigapose_amd/_lib.py: default_numerics; tests/test_numerics_default.py).  The suite's
+    baseline is the verification mode "chain" -- the kernels that are bit-exact against the CPU oracle -- so every test that
+    does not name a mode itself (monkeypatch.setenv / set_numerics / a `numerics` parameter) runs chain, whatever the caller's
+    environment holds; the split tests all set it explicitly."""
+    monkeypatch.setenv("GIGAPOSE_NUMERICS", "chain")

@@ -9,7 +9,7 @@ import torch
 
 from gigapose_amd import synthetic as syn
 from oracle import cpu as oracle
-from test_oracle_matcher import CASES, load_case
+from test_oracle_matcher import CASES, VARIANT_CASES, load_case
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -51,6 +51,86 @@ def test_matcher_vs_reference_golden(golden_dir, name, numerics, monkeypatch):
     np.testing.assert_array_equal(hip["src_pts"], g["src_pts"].astype(np.int64))
     np.testing.assert_allclose(hip["score_src"], g["score_src"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(hip["score_pts"], g["score_pts"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("numerics", ["chain", "split"])
+@pytest.mark.parametrize("name", VARIANT_CASES)
+def test_matcher_variants_vs_reference_golden_and_oracle(golden_dir, name, numerics, monkeypatch):
+    """search_direction = "src2tar" (reference matching.py:242-244) and patch_threshold <= 0 (no cycle check, :256-257): both
+    numerics against goldens of the unmodified reference built with those ctor arguments; chain also bit-exact vs the oracle."""
+    from gigapose_amd.matching import LocalSimilarity, MatchBank
+
+    monkeypatch.setenv("GIGAPOSE_NUMERICS", numerics)
+    g, case, k = load_case(golden_dir, name)
+    direction, pthr = str(g["search_direction"]), float(g["patch_threshold"])
+    metric = LocalSimilarity(k=k, sim_threshold=0.5, patch_threshold=pthr, search_direction=direction)
+    assert metric.numerics == numerics
+    bank = MatchBank(torch.from_numpy(case["src_feats"]).to(DEV), torch.from_numpy(case["src_masks"]).to(DEV))
+    out = metric.test_bank(bank, torch.from_numpy(case["tar_feat"]).to(DEV), torch.from_numpy(case["tar_mask"]).to(DEV),
+                           torch.from_numpy(case["labels"]).to(DEV))
+    hip = {k_: v.cpu().numpy() for k_, v in out.tensors.items()}
+    np.testing.assert_array_equal(hip["id_src"], g["id_src"])
+    np.testing.assert_array_equal(hip["tar_pts"], g["tar_pts"].astype(np.int64))
+    np.testing.assert_array_equal(hip["src_pts"], g["src_pts"].astype(np.int64))
+    np.testing.assert_allclose(hip["score_src"], g["score_src"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(hip["score_pts"], g["score_pts"], rtol=0, atol=2e-6)
+    if numerics == "chain":
+        ref = oracle.local_similarity_test(case["src_feats"], case["tar_feat"], case["src_masks"], case["tar_mask"], case["labels"], k,
+                                           patch_thr=pthr, search_direction=direction)
+        for key in ["score_src", "score_pts"]:
+            np.testing.assert_array_equal(hip[key].view(np.uint32), ref[key].view(np.uint32), err_msg=key)
+    if pthr > 0:   # the reference's val() refuses patch_threshold <= 0 (matching.py:158-159) and so does the mirror
+        return
+    with pytest.raises(ValueError):
+        metric.val(torch.from_numpy(case["tar_feat"]).to(DEV), torch.from_numpy(case["tar_feat"]).to(DEV),
+                   torch.from_numpy(case["tar_mask"]).to(DEV), torch.from_numpy(case["tar_mask"]).to(DEV))
+
+
+def _negative_case():
+    """matcher_case whose templates 0 and 1 of every object are ANTI-correlated with every query patch (similarities around -0.1):
+    with sim_threshold = -0.25 those live values survive and the masked-out patches' exact zeros win the reference's maxima."""
+    case = syn.matcher_case(seed=31, B=3, O=2, N=5, C=64, noise=0.6)
+    rs = np.random.RandomState(7)
+    u = rs.standard_normal(64).astype(np.float32)
+    u /= np.linalg.norm(u)
+    def around(mean, shape):
+        v = rs.standard_normal(shape + (64, 16, 16)).astype(np.float32)
+        v -= np.einsum("...chw,c->...hw", v, u)[..., None, :, :] * u[:, None, None]     # orthogonal to u
+        v /= np.linalg.norm(v, axis=-3, keepdims=True)
+        return (mean * u[:, None, None] + np.sqrt(1 - mean * mean) * v).astype(np.float32)
+    case["tar_feat"] = around(0.98, (3,))
+    case["src_feats"][:, :2] = around(-0.12, (2, 2))
+    return case
+
+
+def test_negative_sim_threshold_runs_uncompacted():
+    """Live-patch compaction of the split matcher is bit-identical to the full tile only for sim_threshold >= 0 (a row maximum of 0
+    then means an all-zero row); with a negative threshold the launcher must run the full tile: split == chain on the indices of
+    every tile and both equal the oracle's (a compacted run would return the negative live maximum instead of a masked zero)."""
+    from gigapose_amd.matching import LocalSimilarity, MatchBank
+
+    case = _negative_case()
+    outs = {}
+    for numerics in ("chain", "split"):
+        metric = LocalSimilarity(k=5, sim_threshold=-0.25, patch_threshold=3)
+        metric.numerics = numerics
+        bank = MatchBank(torch.from_numpy(case["src_feats"]).to(DEV), torch.from_numpy(case["src_masks"]).to(DEV), numerics)
+        from gigapose_amd.matching import patch_grid_mask
+        idx, sc, ma, avg = metric.match_tiles(metric.normalize(torch.from_numpy(case["tar_feat"]).to(DEV)),
+                                              patch_grid_mask(torch.from_numpy(case["tar_mask"]).to(DEV)), bank,
+                                              torch.from_numpy(case["labels"]).to(DEV).int())
+        outs[numerics] = [t.cpu().numpy() for t in (idx, sc, ma, avg)]
+    q = oracle.l2norm_cp(case["tar_feat"].reshape(3, 64, 256))
+    bk = oracle.l2norm_cp(case["src_feats"].reshape(2, 5, 64, 256))
+    ref = oracle.match(q, bk, oracle.patch_mask(case["tar_mask"]), oracle.patch_mask(case["src_masks"]), case["labels"], thr=-0.25)
+    qm = oracle.patch_mask(case["tar_mask"])
+    assert ((ref[1][:, :2] == 0) & (qm[:, None] > 0)).sum() > 100, "the case must hold live rows whose maximum is a masked-out zero"
+    np.testing.assert_array_equal(outs["chain"][0], ref[0])
+    np.testing.assert_array_equal(outs["chain"][1].view(np.uint32), ref[1].view(np.uint32))
+    flips = int((outs["split"][0] != ref[0]).sum())
+    assert flips <= 2, f"{flips} patch ids differ between split and the oracle at a negative threshold"
+    np.testing.assert_allclose(outs["split"][1], ref[1], rtol=0, atol=3e-6)
+    assert (outs["split"][2] != ref[2]).sum() <= 2
 
 
 def test_l2norm_bit_exact():

@@ -35,6 +35,23 @@ def test_oracle_matches_reference_golden(golden_dir, name):
     np.testing.assert_allclose(out["score_pts"], g["score_pts"], rtol=0, atol=2e-6)
 
 
+VARIANT_CASES = ["match_s2t_small", "match_s2t_noshift", "match_nocycle_small", "match_nocycle_fullmask", "match_s2t_nocycle_vits"]
+
+
+@pytest.mark.parametrize("name", VARIANT_CASES)
+def test_oracle_matches_reference_golden_variants(golden_dir, name):
+    """search_direction = "src2tar" (reference matching.py:242-244) and patch_threshold <= 0 = no cycle check (:256-257):
+    goldens of the unmodified reference constructed with those arguments (oracle/make_goldens.py: gen_matcher_variants)."""
+    g, case, k = load_case(golden_dir, name)
+    out = oracle.local_similarity_test(case["src_feats"], case["tar_feat"], case["src_masks"], case["tar_mask"], case["labels"], k,
+                                       patch_thr=float(g["patch_threshold"]), search_direction=str(g["search_direction"]))
+    np.testing.assert_array_equal(out["id_src"], g["id_src"])
+    np.testing.assert_array_equal(out["tar_pts"], g["tar_pts"].astype(np.int64))
+    np.testing.assert_array_equal(out["src_pts"], g["src_pts"].astype(np.int64))
+    np.testing.assert_allclose(out["score_src"], g["score_src"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out["score_pts"], g["score_pts"], rtol=0, atol=2e-6)
+
+
 def test_quirks_are_reproduced():
     """matches to template patch 0 and 'position-t' use of idx_src2tar."""
     C = 16

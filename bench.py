@@ -75,6 +75,72 @@ def cpu_baseline(variant, n_templates, k, sample_crops=32, threads=None):
                       f"torch threads = {threads}, {dt:.1f} s"}
 
 
+class _StubLib:
+    """Profiling hooks of libgigapose_hip.so with nothing behind them (GIGAPOSE_BENCH_STUB=1, see _StubModel)."""
+    class _F:
+        restype = None
+
+        def __call__(self, *a):
+            return 0
+
+    def __getattr__(self, name):
+        if name == "gp_prof_kind_name":
+            f = lambda i: [b"gemm_kmajor", b"match", b"attention", b"layernorm", b"conv", b"other", b"gemm_split", b"match_split"][i]
+            return f
+        return self._F()
+
+
+class _StubModel:
+    """GIGAPOSE_BENCH_STUB=1: everything of THIS FILE -- argument handling, process-group set-up, the timed region with its barriers,
+    the max-over-ranks all-reduce, the per-rank gather, the both-modes block, the rank-0-only JSON line -- runs on CPU over gloo
+    with this object in place of the model (no kernels: `predict` sleeps 2 ms and, when sharded, issues the two collectives of
+    gigapose_amd/sharding.py on small tensors).  tests/test_bench_distributed.py launches it under torch.distributed.run with two
+    ranks: the 8-GPU driver run must not be the first time this control flow executes with more than one rank."""
+
+    def __init__(self):
+        import types
+
+        self.template_shard = None
+        self.template_datasets = {}
+        self.pose_recovery = {}
+        self.match_banks = {}
+        self.template_datas = {}
+        self.overlap_ist = False
+        self.testing_metric = types.SimpleNamespace(bank_dtype=None)
+        self.ae_net = types.SimpleNamespace(dinov2_model=types.SimpleNamespace(set_split_gemm=lambda m: None))
+        self.ist_net = types.SimpleNamespace(backbone=types.SimpleNamespace(conv_kernel="256", invalidate=lambda: None))
+        self.numerics = None
+
+    def set_numerics(self, mode):
+        self.numerics = mode
+
+    def enable_template_sharding(self, group=None):
+        import torch.distributed as dist
+
+        self.template_shard = (dist.get_rank(group), dist.get_world_size(group), group)
+
+    def set_template_data(self, name):
+        import types
+
+        self.pose_recovery[name] = types.SimpleNamespace(check_asserts=True)
+        self.match_banks[name] = types.SimpleNamespace(hi=torch.zeros(4), lo=None, features=None)
+        self.template_datas[name] = object()
+
+    def predict(self, tar_img, *a, **kw):
+        import torch.distributed as dist
+
+        from gigapose_amd import sharding
+
+        time.sleep(0.002)
+        if self.template_shard is not None and dist.is_initialized():
+            rows = torch.zeros(tar_img.shape[0], 64, dtype=torch.uint8)
+            allrows, work = sharding.all_gather_rows(rows, self.template_shard[2], async_op=True)   # exchange #1
+            if work is not None:
+                work.wait()
+            sharding.all_to_all_rows(allrows[:, :8].contiguous(), self.template_shard[2])          # exchange #2
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,7 +161,8 @@ def main():
                          "chain = f32-input MFMA fmaf chain (bit-exact vs the CPU oracle).  The other mode is timed too "
                          "and reported under `other_numerics` (N=1 only).")
     args = ap.parse_args()
-    if not torch.cuda.is_available():
+    stub = os.environ.get("GIGAPOSE_BENCH_STUB") == "1"   # control-flow test of this file on CPU / gloo (see _StubModel); never a measurement
+    if not torch.cuda.is_available() and not stub:
         sys.exit("bench.py: no GPU visible -- the hot path is HIP only (no CPU fallback); run it on an MI355X box "
                  "(tests/test_sharding_gloo.py covers the N > 1 exchange logic on CPU)")
 
@@ -105,27 +172,45 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        # one rank per GPU, launched as the task statement says; any other pairing would time a different job than the line reports
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}; launch with: python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
+    if stub:
+        dev = torch.device("cpu")
+        sync = lambda: None
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
     under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
     if world > 1 or (under_launcher and args.mode == "sharded"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    from gigapose_amd import _lib, factory
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     mode = args.mode if args.mode != "auto" else ("sharded" if world > 1 else "single")
-    model = factory.build_model(args.variant, k=args.k, device=dev, seed=0)
+    if stub:
+        import types
+
+        model = _StubModel()
+        _lib = types.SimpleNamespace(check_status=lambda: None)
+        factory = None
+        tset = None
+        q = dict(tar_img=torch.zeros(args.batch, 1), tar_mask=None, tar_K=None, tar_M=None, labels=None)
+        lib = _StubLib()
+    else:
+        from gigapose_amd import _lib, factory
+
+        model = factory.build_model(args.variant, k=args.k, device=dev, seed=0)
+        tset = factory.TemplateSet(args.objects, args.templates, seed=100)
+        q = tset.crops(1000 + rank, args.batch, dev)
+        lib = _lib.lib()
+        lib.gp_prof_kind_name.restype = ctypes.c_char_p
     if mode == "sharded" and dist.is_initialized():
         model.enable_template_sharding()  # world 1: only meaningful with GIGAPOSE_FORCE_COLLECTIVES=1 (path check)
-    tset = factory.TemplateSet(args.objects, args.templates, seed=100)
     model.template_datasets = {"syn": tset}
-    q = tset.crops(1000 + rank, args.batch, dev)
-    lib = _lib.lib()
-    lib.gp_prof_kind_name.restype = ctypes.c_char_p
     kinds = 8
     SAMPLE_STRIDE = 5  # coprime with the 4 plane-GEMM launches of a ViT layer: the sample cycles through q|k|v, proj, fc1, fc2
 
@@ -137,7 +222,7 @@ def main():
         ("sampled", kind_name) = events around one in 5 launches of the dominant family only -- what THE timed region uses."""
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         if profile == "all":
             lib.gp_prof_begin()
         elif profile:
@@ -146,7 +231,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
-        torch.cuda.synchronize()
+        sync()
+        t_own = time.perf_counter() - t0   # this rank's own K steps (before the closing barrier): a straggler GPU shows here
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
@@ -162,12 +248,12 @@ def main():
                     unit = "GB/s" if name == "layernorm" else "TFLOP/s"
                     kern[name] = {"ms_per_step": round(ms[i] / steps, 3), "launches_per_step": cnt[i] // steps,
                                   "avg_launch_us": round(1e3 * ms[i] / cnt[i], 2), "launches_timed": int(cnt[i]),
-                                  unit: round(work[i] / ms[i] / (1e6 if name == "layernorm" else 1e9), 2)}
-        return dt, kern
+                                  unit: round(work[i] / ms[i] / (1e6 if name == "layernorm" else 1e9), 2) if ms[i] > 0 else 0.0}
+        return dt, kern, t_own
 
     def run_mode(numerics):
-        """Onboard the bank in `numerics`, warm up, time K steps (two-stream region = THE timed region), then replay
-        them on one stream for per-kernel durations free of cross-stream sharing."""
+        """Onboard the bank in `numerics`, warm up, time K steps (THE timed region), then replay them with events around every
+        launch for the per-family table.  Returns (dt = max over ranks, dt_serial, kernels, sampled kernels, per-rank ms per step)."""
         model.set_numerics(numerics)
         model.set_template_data("syn")  # onboarding: excluded from the timed region (reference gigaPose.py:396-398)
         model.pose_recovery["syn"].check_asserts = False  # no host sync inside the timed loop
@@ -178,55 +264,98 @@ def main():
         # family (roofline.achieved comes from these).  Bracketing all ~210 launches of a step costs 1.4 ms of queue time per
         # step (measured A/B, 46.3 vs 44.9 ms), so the per-family table comes from a second, untimed replay with full events.
         dominant = "gemm_split" if numerics == "split" else "gemm_kmajor"
-        dt, kern_timed = timed(args.steps, profile=("sampled", dominant))
+        dt, kern_timed, t_own = timed(args.steps, profile=("sampled", dominant))
         _lib.check_status()  # guard rails (lost hand-off / split range / labels): read once, outside the timed region
         overlap = model.overlap_ist
         model.overlap_ist = False
-        dt_serial, kern = timed(args.steps, profile="all")
+        dt_serial, kern, _ = timed(args.steps, profile="all")
         model.overlap_ist = overlap
+        per_rank = [round(1e3 * t_own / args.steps, 3)]
         if world > 1:
             tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        return dt, dt_serial, kern, kern_timed
+            mine = torch.tensor([t_own], device=dev, dtype=torch.float64)
+            every = torch.empty(world, device=dev, dtype=torch.float64)
+            dist.all_gather_into_tensor(every, mine)
+            per_rank = [round(1e3 * float(t) / args.steps, 3) for t in every.tolist()]
+        return dt, dt_serial, kern, kern_timed, per_rank
 
-    dt, dt_serial, kern, kern_timed = run_mode(args.numerics)
+    dt, dt_serial, kern, kern_timed, per_rank_ms = run_mode(args.numerics)
     # N > 1: the same job once more in the OTHER multi-GPU mode, so that one driver run reports both -- "sharded" (north_star's
     # template-bank partition: two exchanges per step) and "replicas" (full bank per GPU, no data-path collective).  Weak scaling
     # either way; in sharded mode every rank still matches all W * B crops against its 1 / W of the bank, so it saves memory,
-    # not matcher work.
+    # not matcher work.  The switch is the same on every rank (it depends on world / mode only): the collectives stay paired.
     other_modes = None
     if (world > 1 or os.environ.get("GIGAPOSE_BENCH_BOTH_MODES") == "1") and mode in ("sharded", "replicas"):   # env: exercise the block at world 1
         alt = "replicas" if mode == "sharded" else "sharded"
+        err = None
         try:
             if alt == "replicas":
                 model.template_shard = None
             else:
                 model.enable_template_sharding()
-            adt, _, akern, _ = run_mode(args.numerics)
+            adt, _, akern, _, aper = run_mode(args.numerics)
             other_modes = {alt: {"value": round(world * args.batch * args.steps / adt, 2), "unit": "query-crops/sec",
                                  "ms_per_step": round(1e3 * adt / args.steps, 3), "parallelism": f"{alt}{world}",
+                                 "per_rank_ms_per_step": aper,
                                  "kernels_ms_per_step": {k: v["ms_per_step"] for k, v in akern.items()}}}
         except Exception as e:  # never lose the headline line
-            other_modes = {alt: {"error": repr(e)}}
+            err = repr(e)
+            other_modes = {alt: {"error": err}}
+        if world > 1:
+            # a rank that failed alone has left its peers inside a collective of the second pass: say so on every rank instead of
+            # hanging -- the flag exchange itself cannot pair with a data-path collective (those are finished or dead by now)
+            flag = torch.tensor([1 if err else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) and not err:
+                other_modes = {alt: {"error": "another rank failed in this mode"}}
     other = None
-    if world == 1 and not dist.is_initialized() and not args.no_other:
-        other_mode = "chain" if args.numerics == "split" else "split"
-        odt, odt_serial, okern, _ = run_mode(other_mode)
-        other = {"numerics": other_mode, "value": round(args.batch * args.steps / odt, 2), "unit": "query-crops/sec",
+    if world == 1 and not dist.is_initialized() and not args.no_other and not stub:
+        other = {}
+
+        def numerics_entry(name, odt, odt_serial, okern, note=None):
+            e = {"numerics": name, "value": round(args.batch * args.steps / odt, 2), "unit": "query-crops/sec",
                  "ms_per_step": round(1e3 * odt / args.steps, 3), "replay_ms_per_step_with_all_events": round(1e3 * odt_serial / args.steps, 3),
                  "kernels": okern}
+            if note:
+                e["note"] = note
+            return e
+
+        other_mode = "chain" if args.numerics == "split" else "split"
+        try:
+            odt, odt_serial, okern, _, _ = run_mode(other_mode)
+            other[other_mode] = numerics_entry(other_mode, odt, odt_serial, okern,
+                                               "verification mode: f32-input MFMA fmaf chains, bit-exact vs the CPU oracle" if other_mode == "chain" else None)
+        except Exception as e:
+            other[other_mode] = {"error": repr(e)}
+        # split128: what the automatic range fallback lands in (gigaPose.py: _widen_split_range) when a checkpoint's activations
+        # leave the x8 f16 planes' range (|x| >= 8190): ViT linear layers + IST convolutions on the two-accumulator 128 x 128
+        # kernels (GIGAPOSE_SPLIT_GEMM=128 + GIGAPOSE_SPLIT_CONV=128), everything else as in split
+        try:
+            vit, ist = model.ae_net.dinov2_model, model.ist_net.backbone
+            vit.set_split_gemm("128")
+            ist.conv_kernel = "128"
+            ist.invalidate()
+            odt, odt_serial, okern, _, _ = run_mode("split")
+            other["split128"] = numerics_entry("split128", odt, odt_serial, okern,
+                                               "the mode the automatic range fallback selects (|activation| >= 8190): 128 x 128 two-accumulator kernels, range 65504")
+        except Exception as e:
+            other["split128"] = {"error": repr(e)}
+        finally:
+            vit.set_split_gemm(os.environ.get("GIGAPOSE_SPLIT_GEMM", "256"))
+            ist.conv_kernel = os.environ.get("GIGAPOSE_SPLIT_CONV", "256")
+            ist.invalidate()
         model.set_numerics(args.numerics)
     # BASELINE configs 3 and 5 at size on this one GPU (N = 1 only): same path, headline numerics, fewer steps.  Config 5's
     # bank is the fp16 (hi-plane-only) one its text asks for; at N = 8 it would be sharded 8-way (1/8 of these bytes per GPU).
-    other_configs = None
-    if world == 1 and not dist.is_initialized() and not args.no_configs and args.variant == "dinov2_vitl14":
-        other_configs = {}
-        extra = [(key, n_obj, bank_dtype, text) for key, n_obj, bank_dtype, text in (
-                ("config3", 8, "f32", "LM-O shape: 8 objects x 162 templates, 64-crop multi-detection batch with mixed labels, 1 GPU"),
-                ("config5", 40, "f16", "HANDAL/HOPE scale: 40 objects x 162 templates, fp16 feature bank resident in HBM, 1 GPU (unsharded replica)"))
-                 if bank_dtype == "f32" or args.numerics == "split"]   # the fp16 (hi-plane-only) bank exists in split numerics only
-        def extra_config(key, n_obj, bank_dtype, text):
+    # Config 3 also at B = 128 (B = 64 and 128) and as a batch curve B = 8 / 16 / 32 (the reference forwards
+    # detections 4 at a time, configs/test.yaml:21; a frame holds up to 16 per object id, dataloader/test.py:104-107).
+    other_configs = batch_curve = None
+    if world == 1 and not dist.is_initialized() and not args.no_configs and args.variant == "dinov2_vitl14" and not stub:
+        other_configs, batch_curve = {}, {}
+
+        def onboard(key, n_obj, bank_dtype):
             tset_c = factory.TemplateSet(n_obj, args.templates, seed=300 + n_obj)
             model.set_numerics(args.numerics)
             model.testing_metric.bank_dtype = bank_dtype
@@ -235,32 +364,72 @@ def main():
             model.set_template_data(key)
             t_onboard = time.perf_counter() - t0
             model.pose_recovery[key].check_asserts = False
-            qc = tset_c.crops(2000 + n_obj, args.batch, dev)
+            return tset_c, t_onboard
+
+        def time_batch(key, tset_c, n_obj, batch, n_steps):
+            qc = tset_c.crops(2000 + n_obj, batch, dev)
             run = lambda: model.predict(qc["tar_img"], qc["tar_mask"], qc["tar_K"], qc["tar_M"], qc["labels"], key)
             for _ in range(2):
                 run()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            n_steps = max(3, args.steps // 2)
             for _ in range(n_steps):
                 run()
             torch.cuda.synchronize()
             dtc = time.perf_counter() - t0
             _lib.check_status()
-            bank = model.match_banks[key]
-            nbytes = sum(t.numel() * t.element_size() for t in (bank.hi, bank.lo, bank.features) if t is not None)
-            res = {"workload": text, "value": round(args.batch * n_steps / dtc, 2), "unit": "query-crops/sec", "steps": n_steps,
-                   "ms_per_step": round(1e3 * dtc / n_steps, 3), "numerics": args.numerics, "bank_dtype": bank_dtype,
-                   "matcher_bank_GB": round(nbytes / 1e9, 3), "onboarding_s_per_object": round(t_onboard / n_obj, 3)}
-            del model.match_banks[key], model.template_datas[key], tset_c
-            torch.cuda.empty_cache()
-            return res
+            return {"value": round(batch * n_steps / dtc, 2), "unit": "query-crops/sec", "batch": batch, "steps": n_steps,
+                    "ms_per_step": round(1e3 * dtc / n_steps, 3)}
 
-        for key, n_obj, bank_dtype, text in extra:
+        def drop(key):
+            model.match_banks.pop(key, None)
+            model.template_datas.pop(key, None)
+            model.pose_recovery.pop(key, None)
+            torch.cuda.empty_cache()
+
+        n_half = max(3, args.steps // 2)
+        # config 3 (LM-O shape): B = 64, B = 128, and the batch curve -- one onboarding
+        try:
+            text3 = "LM-O shape: 8 objects x 162 templates, multi-detection batch with mixed labels, 1 GPU"
+            tset3, t_on = onboard("config3", 8, "f32")
+            bank = model.match_banks["config3"]
+            nbytes = sum(t.numel() * t.element_size() for t in (bank.hi, bank.lo, bank.features) if t is not None)
+            common = {"numerics": args.numerics, "bank_dtype": "f32", "matcher_bank_GB": round(nbytes / 1e9, 3),
+                      "onboarding_s_per_object": round(t_on / 8, 3)}
+            r64 = time_batch("config3", tset3, 8, args.batch, n_half)
+            other_configs["config3"] = {"workload": text3 + f", batch={args.batch}", **r64, **common}
             try:
-                other_configs[key] = extra_config(key, n_obj, bank_dtype, text)
-            except Exception as e:  # an extra measurement must never cost the headline line
-                other_configs[key] = {"error": repr(e)}
+                r128 = time_batch("config3", tset3, 8, 2 * args.batch, n_half)
+                other_configs["config3_b128"] = {"workload": text3 + f", batch={2 * args.batch} (SURVEY 8(d): B = 64 and 128)", **r128, **common}
+            except Exception as e:
+                other_configs["config3_b128"] = {"error": repr(e)}
+            try:
+                per_crop_64 = r64["value"]
+                for bsz in (8, 16, 32):
+                    r = time_batch("config3", tset3, 8, bsz, 5)
+                    r["per_crop_rate_vs_b64"] = round(r["value"] / per_crop_64, 3)
+                    batch_curve[f"b{bsz}"] = r
+                batch_curve["workload"] = text3 + "; crops/s at B = 8 / 16 / 32 (5 steps each) and their ratio to the B = 64 rate of the same bank"
+                batch_curve[f"b{args.batch}"] = {"value": r64["value"], "batch": args.batch, "ms_per_step": r64["ms_per_step"]}
+            except Exception as e:
+                batch_curve["error"] = repr(e)
+            drop("config3")
+            del tset3
+        except Exception as e:  # an extra measurement must never cost the headline line
+            other_configs["config3"] = {"error": repr(e)}
+        if args.numerics == "split":   # the fp16 (hi-plane-only) bank exists in split numerics only
+            try:
+                tset5, t_on = onboard("config5", 40, "f16")
+                bank = model.match_banks["config5"]
+                nbytes = sum(t.numel() * t.element_size() for t in (bank.hi, bank.lo, bank.features) if t is not None)
+                other_configs["config5"] = {"workload": "HANDAL/HOPE scale: 40 objects x 162 templates, fp16 feature bank resident in HBM, 1 GPU "
+                                                        f"(unsharded replica), batch={args.batch}",
+                                            **time_batch("config5", tset5, 40, args.batch, n_half), "numerics": args.numerics, "bank_dtype": "f16",
+                                            "matcher_bank_GB": round(nbytes / 1e9, 3), "onboarding_s_per_object": round(t_on / 40, 3)}
+                drop("config5")
+                del tset5
+            except Exception as e:
+                other_configs["config5"] = {"error": repr(e)}
         model.testing_metric.bank_dtype = None
         model.template_datasets = {"syn": tset}
     if rank != 0:
@@ -326,7 +495,9 @@ def main():
                                f"batch={args.batch} crops per GPU, k={args.k}, full path ViT->match->IST->RANSAC->pose",
                    "numerics": args.numerics, "global_batch": world * args.batch, "parallelism": f"{mode}{world}" if (world > 1 or (mode == "sharded" and dist.is_initialized())) else "single",
                    "streams": "ViT+match on stream 0, IST backbone on stream 1" if model.overlap_ist else "single stream",
-                   "rccl_ranks": world if dist.is_initialized() else 0,
+                   "rccl_ranks": world if dist.is_initialized() else 0,   # = N under the launcher: one rank per GPU
+                   "per_rank_ms_per_step": per_rank_ms,                  # each rank's own K steps before the closing barrier (a straggler GPU shows here)
+                   "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                    "host_syncs_in_timed_loop": "none: pose recovery's crop-transform assert readback (reference lib3d/torch.py:54-55) is "
                                                "disabled for the loop (check_asserts=False); the device status word is read once after it"},
         "roofline": roofline,
@@ -337,7 +508,11 @@ def main():
         out["other_numerics"] = other
     if other_configs:
         out["other_configs"] = other_configs
-    if world == 1 and not args.no_cpu_baseline:
+    if batch_curve:
+        out["batch_curve"] = batch_curve
+    if stub:
+        out["data"] = "STUB (GIGAPOSE_BENCH_STUB=1): control-flow test of bench.py on CPU / gloo, no kernels -- not a measurement"
+    if world == 1 and not args.no_cpu_baseline and not stub:
         try:
             out["cpu_baseline"] = cpu_baseline(args.variant, args.templates, args.k)
         except Exception as e:  # the baseline is a reported extra; never lose the GPU number

@@ -178,8 +178,9 @@ class GigaPose(_Base):
         return bits
 
     def enable_template_sharding(self, group=None):
-        """Shard the template bank over the ranks of `group` (gigapose_amd/sharding.py).  Call
-        before set_template_data; every rank must then call predict() with the same batch size."""
+        """Shard the template bank over the ranks of `group` (gigapose_amd/sharding.py).  Call before set_template_data; every rank
+        must then call predict() with the SAME batch size (the exchanges are fixed-size collectives: eval_retrieval verifies it
+        with one tiny all-reduce and raises on all ranks together; a raw predict() loop must guarantee it, as bench.py does)."""
         import torch.distributed as dist
 
         self.template_shard = (dist.get_rank(group), dist.get_world_size(group), group)
@@ -290,8 +291,12 @@ class GigaPose(_Base):
     def eval_retrieval(self, batch, idx_batch, dataset_name, sort_pred_by_inliers=True):
         if dataset_name not in self.template_datas:
             self.set_template_data(dataset_name)
-        t0 = time.time()
         labels_np = np.asarray(batch.infos.label).astype(np.int32)
+        if self.template_shard is not None:   # fixed-size collectives ahead: all ranks agree on the batch size, or all raise (sharding.py)
+            from .sharding import require_same_batch
+
+            require_same_batch(len(labels_np), batch.tar_img.device, self.template_shard[2])
+        t0 = time.time()
         labels = torch.from_numpy(labels_np)
         predictions = self.predict(batch.tar_img, batch.tar_mask, batch.tar_K, batch.tar_M, labels, dataset_name,
                                    sort_pred_by_inliers)

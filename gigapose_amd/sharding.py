@@ -78,6 +78,9 @@ def all_to_all_rows(rows, group=None):
     RCCL: one all_to_all_single (each rank receives only what it will use); gloo has no all-to-all, so there (CPU tests, and
     the two-ranks-on-one-GPU test) the same result is cut out of an all-gather."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rows.shape[0] % world:
+        # all_to_all_single splits dim 0 evenly: a remainder would raise on this rank only and leave the others inside the collective
+        raise ValueError(f"all_to_all_rows: {rows.shape[0]} rows do not split over {world} ranks (every rank must pass W * n rows)")
     n = rows.shape[0] // world
     if world == 1 and not _always_collective():
         return rows.reshape((1, n) + tuple(rows.shape[1:]))
@@ -89,6 +92,24 @@ def all_to_all_rows(rows, group=None):
     rank = dist.get_rank(group)
     allrows, _ = all_gather_rows(rows, group)                                        # (W * W*n, ...)
     return allrows.reshape((world, world, n) + tuple(rows.shape[1:]))[:, rank].contiguous()
+
+
+def require_same_batch(n_own, device, group=None):
+    """Every rank must enter a sharded step with the SAME number of crops: the exchanges are fixed-size collectives
+    (all_gather_into_tensor / all_to_all_single), and ranks that disagree on the size do not fail -- they hang, or pair rows of
+    different shapes.  One tiny all-reduce (MAX of [B, -B]) + a host read: for callers that synchronise with the host anyway
+    (GigaPose.eval_retrieval); raises ValueError on EVERY rank together when the sizes differ, so nobody is left inside a
+    collective.  The raw predict() loop of bench.py passes a fixed B and skips this."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return
+    dev = torch.device("cpu") if dist.get_backend(group) == "gloo" else device
+    t = torch.tensor([n_own, -n_own], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = int(t[0]), -int(t[1])
+    if hi != lo:
+        raise ValueError(f"template-sharded step: ranks passed different batch sizes ({lo}..{hi} crops; this rank {n_own}) -- pad the "
+                         "last batch so that every rank holds the same number of crops")
 
 
 def all_gather_cat(t, group=None):
@@ -209,6 +230,9 @@ class ShardedMatcher:
         m = self.metric
         if h["work"] is not None:
             h["work"].wait()                                                          # current stream waits for the collective
+        n_ranks = self.world if (self.world > 1 or _always_collective()) else 1
+        if h["rows"].shape[0] != n_ranks * h["n_own"]:
+            raise ValueError(f"exchange #1 returned {h['rows'].shape[0]} rows for {n_ranks} ranks x {h['n_own']} crops: every rank must pass the same batch size")
         q, qmask, labels_all = unpack_query(h["rows"], h["layout"])
         idx, sc, ma, avg = m.match_tiles(q, qmask, self.bank, labels_all)
         ids, score = m.topk(avg)

@@ -1,0 +1,69 @@
+"""CPU: bench.py's OWN main() under `torch.distributed.run` with two ranks (gloo) and a stub model (GIGAPOSE_BENCH_STUB=1: no
+kernels, bench.py: _StubModel).  The driver's 8-GPU scaling run must not be the first time the N > 1 control flow of this file
+executes: process-group set-up from the launcher's environment, the timed region's barriers, the max-over-ranks all-reduce, the
+per-rank gather, the both-modes block (sharded AND replicas in one run, with the sharded pass issuing the two exchanges of
+gigapose_amd/sharding.py), the failure flag exchange, and the rank-0-only single JSON line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(nproc, extra, timeout=240):
+    env = dict(os.environ, GIGAPOSE_BENCH_STUB="1", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + extra
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.join(ROOT, "bench.py")] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, f"bench.py failed (rc {r.returncode}):\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line on stdout (rank 0 only), got {len(lines)}:\n{r.stdout[-2000:]}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode,alt", [("auto", "replicas"), ("replicas", "sharded")])
+def test_bench_main_world2_prints_one_line_with_both_modes(mode, alt):
+    out = launch(2, ["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--mode", mode])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["metric"].startswith("query-crops/sec") and out["unit"] == "query-crops/sec" and out["higher_is_better"] is True
+    cfg = out["config"]
+    assert cfg["rccl_ranks"] == 2 and cfg["global_batch"] == 8
+    assert cfg["parallelism"] == ("sharded2" if mode == "auto" else "replicas2")
+    assert len(cfg["per_rank_ms_per_step"]) == 2 and all(t >= 2.0 for t in cfg["per_rank_ms_per_step"])   # the stub step sleeps 2 ms
+    # value = all ranks' crops / the max-over-ranks time of exactly K steps
+    assert abs(out["value"] - 2 * 4 * 3 / (out["ms_per_step"] * 3 / 1e3)) / out["value"] < 1e-3
+    assert out["ms_per_step"] >= max(cfg["per_rank_ms_per_step"]) - 1e-3
+    other = out["other_modes"][alt]
+    assert "error" not in other, other
+    assert other["parallelism"] == f"{alt}2" and len(other["per_rank_ms_per_step"]) == 2 and other["value"] > 0
+    assert "cpu_baseline" not in out and "other_numerics" not in out     # N = 1 extras stay out of the N > 1 line
+    assert out["data"].startswith("STUB")
+
+
+def test_bench_main_world1_stub_line():
+    out = launch(1, ["--steps", "2", "--warmup", "1", "--batch", "4"])
+    assert out["n_gpus"] == 1 and out["config"]["rccl_ranks"] == 0 and out["config"]["parallelism"] == "single"
+    assert "other_modes" not in out and len(out["config"]["per_rank_ms_per_step"]) == 1
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    env = dict(os.environ, GIGAPOSE_BENCH_STUB="1", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)

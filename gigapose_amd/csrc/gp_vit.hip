@@ -1033,6 +1033,17 @@ int gp_attention_split(const void* qkv_hi, const void* qkv_lo, void* out_hi, voi
     return GP_OK;
 }
 
+/* stage entry (tests / tools/probe_stage_errors.py): the LayerNorm of the plane path on its own.  X channel-major [C][Mpad] f32 ->
+ * token-major activation planes hi / lo [Mpad][C] (x 8), exactly what gp_vit_forward_split launches before qkv / fc1. */
+int gp_layernorm_planes(const float* X, void* out_hi, void* out_lo, const float* gamma, const float* beta, int C, int Mpad, float eps,
+                        void* stream)
+{
+    GP_REQUIRE(X && out_hi && out_lo && gamma && beta && C > 0 && C % 128 == 0 && Mpad > 0 && Mpad % 64 == 0, "gp_layernorm_planes: bad arguments");
+    launch_layernorm_planes(X, (_Float16*)out_hi, (_Float16*)out_lo, gamma, beta, C, Mpad, eps, (hipStream_t)stream);
+    GP_CHECK_LAUNCH("gp_layernorm_planes");
+    return GP_OK;
+}
+
 int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                    const float* const* weights, int n_weights, float* workspace, size_t workspace_bytes,
                    float* out_features, int normalize, int stop_after_layers, void* stream)

@@ -258,6 +258,10 @@ int gp_gemm_planes256_ragged(const void* a_hi, const void* a_lo, const void* b_h
 int gp_gemm_planes256_trace(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
                             void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
                             const float* residual, int ldr, float out_scale, float* scratch, unsigned long long* trace, void* stream);
+/* stage entry of the plane path (tests, tools/probe_stage_errors.py): LayerNorm over C of X [C][Mpad] f32 (channel-major, as the
+ * residual stream is kept) -> token-major activation planes hi / lo [Mpad][C] (x 8); HF modeling_dinov2.py:342-380 norm1 / norm2. */
+int gp_layernorm_planes(const float* X, void* out_hi, void* out_lo, const float* gamma, const float* beta, int C, int Mpad, float eps,
+                        void* stream);
 void gp_vit_set_planes(int mode); /* 2 (default) = planes + attention in split numerics, 1 = planes + f32 attention, 0 = off */
 
 /* softmax(q k^T / 8) v per (image, head) in split numerics (attention_split_kernel): qkv_hi/lo = f16 planes [Mpad][3 dim]

@@ -89,7 +89,8 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
                                                uint8_t* __restrict__ idx_t2s, float* __restrict__ score_t2s,
                                                float* __restrict__ mask_all, float* __restrict__ sim_avg,
                                                unsigned long long* trace = nullptr,  // probe build only: 8 stamps per tile
-                                               int src2tar = 0)  // search_direction == "src2tar" (matching.py:242-244)
+                                               int src2tar = 0,   // search_direction == "src2tar" (matching.py:242-244)
+                                               int compact = 1)   // PERM: the tile holds the live patches only (see below)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -173,7 +174,7 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
                 const float x = acc[mi][ni][r];
                 const int row = t_lane + 32 * mi + (r & 3) + 8 * (r >> 2);
                 if constexpr (PERM) {  // LDS rows are not in patch order: an exact tie between positive values goes to the lower patch
-                    if (x > bv || (x == bv && x > 0.f && sm.t_of[row] < sm.t_of[bi])) { bv = x; bi = row; }
+                    if (x > bv || (x == bv && (x > 0.f || !compact) && sm.t_of[row] < sm.t_of[bi])) { bv = x; bi = row; }
                 } else {
                     if (x > bv) { bv = x; bi = row; }
                 }
@@ -197,7 +198,11 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
         const float v1 = sm.rowv[1][tid];
         const int i1 = sm.rowi[1][tid];
         if (v1 > bv || (PERM && v1 == bv && i1 < bi)) { bv = v1; bi = i1; }
-        if (PERM && bv == 0.f) bi = 0;  // an all-zero row: first index (the masked-out patches' zeros are part of the row)
+        // compacted tile (needs sim_threshold >= 0: every surviving value is >= 0): a maximum of 0 means an all-zero row, whose first
+        // index is 0 -- the masked-out patches' zeros are part of the reference's row but not of this tile.  Uncompacted (every
+        // patch in the tile, e.g. a negative threshold): the zeros ARE in the tile and the (value, patch index) order already
+        // returns the reference's first maximum -- which is the first masked-out patch, not patch 0, when live values are negative.
+        if (PERM && compact && bv == 0.f) bi = 0;
         sm.sc_t2s[tid] = bv;
         sm.id_t2s[tid] = bi;
     } else {
@@ -210,7 +215,7 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
             const int iw = sm.coli[w][s];
             if (vw > bv || (PERM && vw == bv && iw < bi)) { bv = vw; bi = iw; }
         }
-        if (PERM && bv == 0.f) bi = 0;
+        if (PERM && compact && bv == 0.f) bi = 0;
         sm.sc_s2t[s] = bv;
         sm.id_s2t[s] = bi;
     }
@@ -590,7 +595,7 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= inv;
-    match_epilogue<true>(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg, trace, src2tar);
+    match_epilogue<true>(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg, trace, src2tar, compact);
 }
 
 // norms of gp_l2norm_cp (same sequential fma over c), then x / d * 32 split into f16 planes [row][patch][C].

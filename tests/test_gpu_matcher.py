@@ -128,6 +128,12 @@ def test_negative_sim_threshold_runs_uncompacted():
     np.testing.assert_array_equal(outs["chain"][0], ref[0])
     np.testing.assert_array_equal(outs["chain"][1].view(np.uint32), ref[1].view(np.uint32))
     flips = int((outs["split"][0] != ref[0]).sum())
+    if flips > 2:   # diagnostics: where, and what the kernel returned there
+        per_tile = (outs["split"][0] != ref[0]).sum(-1)
+        b, n = np.unravel_index(per_tile.argmax(), per_tile.shape)
+        t = np.flatnonzero(outs["split"][0][b, n] != ref[0][b, n])[:8]
+        print("flips per (det, template):", per_tile.tolist(), "| tile", (b, n), "patches", t.tolist(), "ours idx", outs["split"][0][b, n, t].tolist(),
+              "ref idx", ref[0][b, n, t].tolist(), "ours score", outs["split"][1][b, n, t].tolist(), "ref score", ref[1][b, n, t].tolist())
     assert flips <= 2, f"{flips} patch ids differ between split and the oracle at a negative threshold"
     np.testing.assert_allclose(outs["split"][1], ref[1], rtol=0, atol=3e-6)
     assert (outs["split"][2] != ref[2]).sum() <= 2

@@ -34,6 +34,14 @@ __device__ __forceinline__ void gp_raise(int* status, int bit)
 }
 constexpr float kSplitPlaneLimit = 65504.0f;  // largest finite f16: |8 x| beyond it would store inf in the hi plane
 
+// LayerNorm folded into the plane GEMMs (gp_split256.hip, epilogues 8-10): where the per-token partial (sum, sum of squares) pairs
+// live.  main: [channels / 256][ld][2] f32 (tile rows), strip: [channels / 32][256][2] (the < 256 ragged rows).
+struct GpLnFold {
+    const float* ln_main; const float* ln_strip;  // consumer: statistics of the rows of B
+    float* st_main; float* st_strip;              // producer: statistics of the rows it writes
+    int ld; float eps;
+};
+
 // set by every entry point on failure; read through gp_last_error()
 void gp_set_error(const char* fmt, ...);
 

@@ -349,6 +349,21 @@ unsigned g_epoch256 = 0;
 // of gemm_split256_kernel; the arithmetic (operand values, k order) is identical, so results are bit-identical to it.
 // Work distribution: data-parallel rounds of whole tiles first (L2 reuse), stream-K only for the last round + remainder.
 enum { PEPI_GELU_PLANES = 6, PEPI_BIAS_I_PLANES = 7 };  // bias along i (6: + GELU), output as activation planes O[j][i] (x 8)
+// LayerNorm folded into its neighbours (round 4).  LN(x)_k = (x_k - mu) r g_k + be_k with per-token mu, r, so
+//     sum_k W_ik LN(x)_k + b_i = r (sum_k (W_ik g_k) x_k - mu s_i) + b'_i,   s_i = sum_k W_ik g_k,  b'_i = b_i + sum_k W_ik be_k:
+// the GEMM runs on the RAW residual planes with the weights W diag(g) and the per-token part moves into the epilogue.  The 48
+// LayerNorm launches of a ViT-L forward (1.7 ms of a 43 ms step: a full read of X and a full write of the planes each) disappear:
+//   10 (producer: proj, fc2)  x = res + scale_i (acc + bias_i) on a TOKEN-MAJOR f32 residual stream res / D [j][i], and the same
+//      x as raw activation planes O[j][i] (x 8) + per-token partial (sum, sum of squares) of the tile's 256 channels;
+//    8 (consumer: q|k|v)      O[j][i] = planes of  r_j (acc - mu_j s_i) + b'_i      (bias = b', scale = s; mu, r from the partials)
+//    9 (consumer: fc1)        the same through GELU.
+// Statistics in f32 as E[x^2] - mu^2 over tree-ordered partial sums (in-lane 8, 3 butterfly steps, 4 waves, K / 256 tiles): the
+// relative error of the variance is ~1e-7 (1 + mu^2 / var) -- mu^2 << var for a transformer's residual stream (tests plant
+// outlier channels and a mean of several sigma); deterministic (fixed order, no atomics).
+enum { PEPI_LNF_BIAS_PLANES = 8, PEPI_LNF_GELU_PLANES = 9, PEPI_RES_PLANES_STATS = 10 };
+template <int EPI> constexpr bool kEpiPlanesOut = EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES || EPI == PEPI_LNF_BIAS_PLANES || EPI == PEPI_LNF_GELU_PLANES;
+template <int EPI> constexpr bool kEpiLnf = EPI == PEPI_LNF_BIAS_PLANES || EPI == PEPI_LNF_GELU_PLANES;
+template <int EPI> constexpr bool kEpiGelu = EPI == PEPI_GELU_PLANES || EPI == PEPI_LNF_GELU_PLANES || EPI == XEPI_BIAS_I_GELU;
 
 struct ArgsP {
     const _Float16* ahi; const _Float16* alo;  // A planes [I][K]
@@ -365,6 +380,12 @@ struct ArgsP {
     int* status;                // guard rails (gp_common.h)
     int strip_j0, strip_fj;     // ragged J: rows [strip_j0, strip_j0 + 32 strip_fj) of B are not tiled, see strip_phase
     int par;                    // fewer tiles than slots: the slots of a tile split its K in PARALLEL (see the kernel)
+    // LayerNorm folded into its neighbour GEMMs (epilogues 8-10, see below).  Statistics travel as per-token partial (sum, sum of
+    // squares) pairs: tile rows as [K / 256][ld][2] (one pair per 256-channel tile of the producer), strip rows as [K / 32][256][2]
+    const float* ln_main; const float* ln_strip;   // consumer (8, 9): statistics of the rows of B
+    float* st_main; float* st_strip;               // producer (10): statistics of the rows it writes
+    int st_ld; float ln_eps;
+    int j_valid;                                   // rows of B that carry data (the last strip fragment may reach beyond them)
 };
 
 __device__ __forceinline__ float lane_bcast(float v, int lane)  // value held by `lane` (compile-time constant) -> SGPR
@@ -496,6 +517,273 @@ __device__ __forceinline__ void epilogue_planes_lds(const ArgsP& a, f32x16 (&acc
     if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE);
 }
 
+// ---- Thin plane arithmetic (round 4).  The round-3 segment probes put the arithmetic half of a plane epilogue at 8.5 vector
+// instructions per element (readlane + select for the bias, multiply, add, x 8, two conversions, a subtraction, a third
+// conversion, a compare) and showed that it adds to the matrix work instead of hiding behind it.  Here: the per-row constants come
+// from 16-byte loads of exactly the rows a lane holds (no readlane / select), every affine step is ONE fma, a pair of values
+// becomes its two f16 planes in three instructions (v_cvt_pk_f16_f32; v_fma_mixlo / mixhi_f16 computing v - hi with the f16
+// operand read straight from the packed hi pair), and the range guard is a NaN-propagating v_maximum3_f32 over |v| per pair.
+typedef _Float16 g16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_hi_pair(float v0, float v1)
+{
+    g16x2 h;
+    h[0] = (_Float16)v0;
+    h[1] = (_Float16)v1;
+    return __builtin_bit_cast(unsigned, h);
+}
+// (f16(v0 - hi.lo), f16(v1 - hi.hi)) in one register.  v - hi is exact in f32 (hi = v rounded to 11 bits), so the single rounding
+// of the mixed-precision fma equals the f32 subtraction + conversion the other plane producers use.
+__device__ __forceinline__ unsigned lo_pair(float v0, float v1, unsigned hi)
+{
+    unsigned lo;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(lo)
+        : "v"(v0), "v"(v1), "v"(hi));
+    return lo;
+}
+__device__ __forceinline__ float absmax3(float m, float v0, float v1)  // v_maximum3_f32: a NaN operand makes the result NaN
+{
+    return __builtin_elementwise_maximum(m, __builtin_elementwise_maximum(__builtin_fabsf(v0), __builtin_fabsf(v1)));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 8 lanes that share lane >> 3, the same value (bit for bit) on all of them: quads (xor 1, xor 2), then the other quad
+__device__ __forceinline__ float sum8_lanes(float v)
+{
+    v = v + dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = v + dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = v + dpp_mov<0x141>(v);  // row_half_mirror: lane i <- lane 7 - i of its group of 8 (every lane of a quad holds the quad's sum)
+    return v;
+}
+__device__ __forceinline__ float gelu_fast_x8(float x)  // 8 * gelu_fast(x), bit for bit (the factor folded into the exact 0.5 x)
+{
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = 0.02651038324816011f;
+    p = fmaf(p, t, -0.284242067130941f);
+    p = fmaf(p, t, 0.8274675429718052f);
+    p = fmaf(p, t, -0.8329329722108324f);
+    p = fmaf(p, t, 0.7896692586773671f);
+    p = fmaf(p, t, -0.14005398441300523f);
+    p = fmaf(p, t, 0.25548806601570556f);
+    p = fmaf(p, t, 0.17245176856740801f);
+    p = fmaf(p, t, 0.18564199446374482f);
+    const float c = p * t * __expf(-z * z);
+    return (0.5f * kActScale) * x * (x >= 0.f ? 2.0f - c : c);
+}
+
+// Consumer of a folded LayerNorm (8 / 9): planes of  r_j (acc - mu_j s_i) + b'_i  [9: through GELU], the LDS turn and the stores of
+// epilogue_planes_lds.  tab: (mu, r) of this wave's 128 tokens (LDS, written by the tile prologue).
+template <int EPI>
+__device__ __forceinline__ void epilogue_planes_lnf(const ArgsP& a, f32x16 (&acc)[2][4], char* __restrict__ wl, const g32x2* __restrict__ tab,
+                                                    const float* __restrict__ rowc, int i_base, int j_base, int ln)
+{
+    // rowc: this wave's 64 rows of per-row constants in LDS, staged by the tile prologue: [0..63] = b'_i (x 8 in the bias variant),
+    // [256..319] = s_i.  Read where they are used (two 16-byte LDS reads per four rows): held in registers for the whole epilogue
+    // they are 64 VGPRs next to the 128 accumulators and the kernel spills -- and a kernel with a scratch segment pays for it at
+    // every launch, not only where it spills.
+    const int l31 = ln & 31, half = ln >> 5;
+    constexpr bool kGelu = EPI == PEPI_LNF_GELU_PLANES;
+    constexpr float k8 = kGelu ? 1.0f : kActScale;  // 8: the planes' x 8 folded into the affine step (exact); 9: into GELU's 0.5 x
+    const __amdgpu_buffer_rsrc_t r_hi = __builtin_amdgcn_make_buffer_rsrc((void*)a.ohi, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_lo = __builtin_amdgcn_make_buffer_rsrc((void*)a.olo, 0, 0x7ffffff0, 0x00020000);
+    const unsigned v_pl = ((unsigned)(j_base + (ln >> 3)) * (unsigned)a.ldo + (unsigned)(i_base + 8 * (ln & 7))) * 2u;
+    float mx = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+            const int ni = 2 * h + nn, jl = 32 * nn + l31;
+            const g32x2 st = tab[64 * h + jl];
+            const float A = st[1] * (a.out_scale * k8);  // r_j x the exact power of two that undoes the operand scales (x 8)
+            const float Mj = -(st[0] * st[1]) * k8;      // -mu_j r_j
+            char* wrow = wl + jl * 128;
+            const int sw = (jl & 7) << 1;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(rowc + 32 * mi + 8 * r4 + 4 * half);
+                    const f32x4 sq = *reinterpret_cast<const f32x4*>(rowc + TB + 32 * mi + 8 * r4 + 4 * half);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float c = __builtin_fmaf(Mj, sq[e], bq[e]);
+                        const float x = __builtin_fmaf(acc[mi][ni][4 * r4 + e], A, c);
+                        v[e] = kGelu ? gelu_fast_x8(x) : x;
+                    }
+                    u32x2 oh, ol;
+                    oh[0] = pack_hi_pair(v[0], v[1]);
+                    oh[1] = pack_hi_pair(v[2], v[3]);
+                    ol[0] = lo_pair(v[0], v[1], oh[0]);
+                    ol[1] = lo_pair(v[2], v[3], oh[1]);
+                    mx = absmax3(absmax3(mx, v[0], v[1]), v[2], v[3]);
+                    const int c8 = 8 * mi + 2 * r4 + half;  // 8-byte piece of the 128-byte row: rows 4 c8 .. 4 c8 + 3
+                    *reinterpret_cast<u32x2*>(wrow + ((c8 ^ sw) << 3)) = oh;
+                    *reinterpret_cast<u32x2*>(wrow + 8192 + ((c8 ^ sw) << 3)) = ol;
+                }
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int jl = 8 * it + (ln >> 3), c16 = ln & 7;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(wl + pl * 8192 + jl * 128 + ((c16 ^ (jl & 7)) << 4));
+                // buffer store: one 32-bit lane offset for all sixteen stores + a scalar offset per item (sixteen 64-bit flat
+                // addresses are sixteen register pairs, and this epilogue has none to spare)
+                __builtin_amdgcn_raw_buffer_store_b128(v, pl ? r_lo : r_hi, v_pl, (unsigned)(64 * h + 8 * it) * (unsigned)a.ldo * 2u, 0);
+            }
+        }
+    }
+    if (!(mx <= kSplitPlaneLimit)) gp_raise(a.status, GP_ST_SPLIT_RANGE);  // !(<=): NaN counts (v_maximum3 propagates it)
+}
+
+// Producer of a folded LayerNorm (10): x = res + scale_i (acc out_scale + bias_i) on the token-major f32 residual stream, plus the raw
+// planes of x and the per-token partial statistics of this wave's 64 channels.  The wave turns its 64 (i) x 128 (j) tile through
+// its 16 KiB of LDS as RAW accumulators in two rounds of 64 tokens (token rows of 256 bytes, 16-byte pieces XOR-placed by the
+// token: writes and reads conflict-free); after the turn a lane holds 8 CONSECUTIVE channels of a token, the same 8 for all its
+// items: bias and LayerScale are 4 registers each, every global access is 16 bytes per lane with 8 lanes covering a token's 256 (f32)
+// or 128 (plane) contiguous bytes, and the token's 64-channel sums are three butterfly steps away.  res != D (the residual stream
+// ping-pongs between two buffers): no load waits for a store.  st: [128 tokens][2] partials of this wave (LDS).
+__device__ __forceinline__ void epilogue_res_planes(const ArgsP& a, f32x16 (&acc)[2][4], float* __restrict__ wl, float* __restrict__ st, int i_base,
+                                                    int j_base, int ln)
+{
+    const int l31 = ln & 31, half = ln >> 5, tq = ln >> 3, c8 = ln & 7;
+    const int pm = a.dp >> 2;  // PROBE mask (gp_gemm_planes256_set_dp bits 2..5): 1 no statistics, 2 no plane stores, 4 no D stores, 8 no residual loads
+    // Buffer addressing: one descriptor per array (scalar registers), ONE 32-bit lane offset per element size -- row (j_base + tq),
+    // channels i_base + 8 c8 .. + 7 -- and a scalar offset per item.  (With 64-bit flat addresses the sixteen items' address pairs
+    // of four arrays are what the compiler spills; a kernel with a scratch segment is slower at every launch.)
+    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_d = __builtin_amdgcn_make_buffer_rsrc((void*)a.D, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_hi = __builtin_amdgcn_make_buffer_rsrc((void*)a.ohi, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_lo = __builtin_amdgcn_make_buffer_rsrc((void*)a.olo, 0, 0x7ffffff0, 0x00020000);
+    const unsigned ic = (unsigned)(i_base + 8 * c8);
+    const unsigned v_res = ((unsigned)(j_base + tq) * (unsigned)a.ldr + ic) * 4u;
+    const unsigned v_d = ((unsigned)(j_base + tq) * (unsigned)a.ldd + ic) * 4u;
+    const unsigned v_pl = ((unsigned)(j_base + tq) * (unsigned)a.ldo + ic) * 2u;
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + ic), b1 = *reinterpret_cast<const f32x4*>(a.bias + ic + 4);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.scale + ic), s1 = *reinterpret_cast<const f32x4*>(a.scale + ic + 4);
+    float mx = 0.f;
+    // The residual rows are fetched one batch of FOUR items (eight 16-byte loads per lane) AHEAD of the batch being processed: four
+    // stages (round h, items 4 (s & 1) ..), stage s issuing stage s + 1's loads before it touches its own.  With two items fetched
+    // and used at a time the epilogue ran at the latency of a cold 67 MB read: 61 us of a 135 us proj launch inside a forward
+    // (profiles/r04_lnfold_masks.txt); the loads do not depend on anything the epilogue computes (res != D).
+    u32x4 rr[2][4][2];
+    auto fetch = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned so = (unsigned)(64 * (stage >> 1) + 8 * (4 * (stage & 1) + u)) * (unsigned)a.ldr * 4u;
+            if (pm & 8) { rr[stage & 1][u][0] = __builtin_bit_cast(u32x4, b0); rr[stage & 1][u][1] = __builtin_bit_cast(u32x4, b1); continue; }
+            rr[stage & 1][u][0] = __builtin_amdgcn_raw_buffer_load_b128(r_res, v_res, so, 0);
+            rr[stage & 1][u][1] = __builtin_amdgcn_raw_buffer_load_b128(r_res, v_res + 16u, so, 0);
+        }
+    };
+    fetch(0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+            const int ni = 2 * h + nn, jl = 32 * nn + l31;
+            float* wrow = wl + jl * 64;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 v;
+                    v[0] = acc[mi][ni][4 * r4 + 0]; v[1] = acc[mi][ni][4 * r4 + 1];
+                    v[2] = acc[mi][ni][4 * r4 + 2]; v[3] = acc[mi][ni][4 * r4 + 3];
+                    const int piece = 8 * mi + 2 * r4 + half;  // channels 4 piece .. 4 piece + 3 of the wave's 64
+                    *reinterpret_cast<f32x4*>(wrow + ((piece ^ (jl & 15)) << 2)) = v;
+                }
+        }
+#pragma unroll
+        for (int q4 = 0; q4 < 2; ++q4) {
+            const int stage = 2 * h + q4;
+            if (stage < 3) fetch(stage + 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = 4 * q4 + u;
+                const int jl = 8 * it + tq;
+                const float* wrow = wl + jl * 64;
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(wrow + (((2 * c8) ^ (jl & 15)) << 2));
+                const f32x4 t1 = *reinterpret_cast<const f32x4*>(wrow + (((2 * c8 + 1) ^ (jl & 15)) << 2));
+                const f32x4 r0 = __builtin_bit_cast(f32x4, rr[stage & 1][u][0]), r1 = __builtin_bit_cast(f32x4, rr[stage & 1][u][1]);
+                f32x4 x0, x1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x0[e] = __builtin_fmaf(s0[e], __builtin_fmaf(t0[e], a.out_scale, b0[e]), r0[e]);
+                    x1[e] = __builtin_fmaf(s1[e], __builtin_fmaf(t1[e], a.out_scale, b1[e]), r1[e]);
+                }
+                if (!(pm & 4)) {
+                    const unsigned so = (unsigned)(64 * h + 8 * it) * (unsigned)a.ldd * 4u;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x0), r_d, v_d, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x1), r_d, v_d + 16u, so, 0);
+                }
+                if (!(pm & 1)) {
+                    // statistics of the token's 8 channels here, tree order: pairs, fours, eight
+                    float sm = ((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3]));
+                    float sq = __builtin_fmaf(x0[3], x0[3], __builtin_fmaf(x0[2], x0[2], __builtin_fmaf(x0[1], x0[1], x0[0] * x0[0])));
+                    sq = sq + __builtin_fmaf(x1[3], x1[3], __builtin_fmaf(x1[2], x1[2], __builtin_fmaf(x1[1], x1[1], x1[0] * x1[0])));
+                    sm = sum8_lanes(sm);
+                    sq = sum8_lanes(sq);
+                    if (c8 == 0) {
+                        g32x2 pr;
+                        pr[0] = sm;
+                        pr[1] = sq;
+                        *reinterpret_cast<g32x2*>(st + 2 * (64 * h + jl)) = pr;
+                    }
+                }
+                // raw planes (x 8)
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = x0[e] * kActScale; v[4 + e] = x1[e] * kActScale; }
+                u32x4 oh, ol;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    oh[q] = pack_hi_pair(v[2 * q], v[2 * q + 1]);
+                    ol[q] = lo_pair(v[2 * q], v[2 * q + 1], oh[q]);
+                    mx = absmax3(mx, v[2 * q], v[2 * q + 1]);
+                }
+                if (!(pm & 2)) {
+                    const unsigned so = (unsigned)(64 * h + 8 * it) * (unsigned)a.ldo * 2u;
+                    __builtin_amdgcn_raw_buffer_store_b128(oh, r_hi, v_pl, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ol, r_lo, v_pl, so, 0);
+                }
+            }
+        }
+    }
+    if (!(mx <= kSplitPlaneLimit)) gp_raise(a.status, GP_ST_SPLIT_RANGE);
+}
+
+// (mu, r) of one token from its partial (sum, sum of squares) pairs: np pairs `stride` floats apart, added in index order
+__device__ __forceinline__ g32x2 ln_finish(const float* __restrict__ p, int np, size_t stride, int K, float eps)
+{
+    float s = 0.f, q = 0.f;
+    for (int u0 = 0; u0 < np; u0 += 4) {  // four pairs in flight at a time (np = 4 / 16 for the tile rows, 32 / 128 for the strip): one
+        g32x2 v[4];                        // memory round trip per group instead of one per pair
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const g32x2*>(p + (size_t)min(u0 + u, np - 1) * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u0 + u < np) {
+                s = s + v[u][0];
+                q = q + v[u][1];
+            }
+        }
+    }
+    const float mu = s / (float)K;
+    const float var = fmaxf(__builtin_fmaf(-mu, mu, q / (float)K), 0.f);
+    g32x2 o;
+    o[0] = mu;
+    o[1] = 1.0f / __builtin_sqrtf(var + eps);
+    return o;
+}
+
 // Strip fragments are handed out on demand: a slot asks for the next fragment when it has finished its tiles.  The per-slot
 // time stamps show slots of different XCDs finishing equal work 8-11 % apart (k-step 2.33 us on the fastest XCD, 2.66 on the
 // slowest, the same order in every launch of a box), and with the static split (fragment f to slot f) the 64 fragments of a
@@ -555,8 +843,9 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         // epilogue operands of this fragment (used by wave 0 only, requested now: their latency hides behind the K loop)
         constexpr bool kBiasI = EPI == XEPI_BIAS_I || EPI == XEPI_BIAS_I_GELU || EPI == XEPI_BIAS_I_SCALE_RES || EPI == XEPI_BIAS_I_RELU ||
-                                EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES;
+                                EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES || kEpiLnf<EPI> || EPI == PEPI_RES_PLANES_STATS;
         f32x4 pre_bias[4], pre_scale[4], pre_res[4];
+        g32x2 pre_ln = {0.f, 1.f};  // 8 / 9: (mu, r) of this lane's token
         if (wave == 0) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
@@ -665,10 +954,66 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
             // per-element arithmetic of the tile epilogues, direct stores (a few KB per launch)
             const int j = j0 + l31;
             int bad = 0;
+            float st_s = 0.f, st_q = 0.f;  // 10: this lane's 16 channels of token j
+            // the folded-LayerNorm epilogues fetch their extra operands HERE, after the K loop (one exposed round trip per fragment,
+            // a few fragments per launch): requested before it they are 40 more registers next to the loop's 128 and the kernel spills
+            if (kEpiLnf<EPI> || EPI == PEPI_RES_PLANES_STATS) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int i = i0 + frag_row(4 * r4, lane);
+                    pre_scale[r4] = *reinterpret_cast<const f32x4*>(a.scale + i);  // s_i (8, 9) / LayerScale (10)
+                    if (EPI == PEPI_RES_PLANES_STATS)  // token-major residual stream: this lane's four rows are 16 contiguous bytes
+                        pre_res[r4] = *reinterpret_cast<const f32x4*>(a.res + (size_t)(unsigned)j * (unsigned)a.ldr + (unsigned)i);
+                }
+                if (kEpiLnf<EPI>)  // the token's K / 32 strip partials (written by the producer's strip fragments, one per 32 channels)
+                    pre_ln = ln_finish(a.ln_strip + 2 * (size_t)(j - a.strip_j0), a.K >> 5, 2 * 256, a.K, a.ln_eps);
+            }
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int i = i0 + frag_row(4 * r4, lane);
-                if (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES) {
+                if (kEpiLnf<EPI>) {  // r_j (acc - mu_j s_i) + b'_i, the tile epilogue's arithmetic (epilogue_planes_lnf)
+                    constexpr bool kGelu = EPI == PEPI_LNF_GELU_PLANES;
+                    constexpr float k8 = kGelu ? 1.0f : kActScale;
+                    const float A = pre_ln[1] * (a.out_scale * k8), Mj = -(pre_ln[0] * pre_ln[1]) * k8;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float c = __builtin_fmaf(Mj, pre_scale[r4][e], kGelu ? pre_bias[r4][e] : pre_bias[r4][e] * k8);
+                        const float x = __builtin_fmaf(acc[4 * r4 + e], A, c);
+                        v[e] = kGelu ? gelu_fast_x8(x) : x;
+                        bad |= !(fabsf(v[e]) <= kSplitPlaneLimit);
+                    }
+                    u32x2 oh, ol;
+                    oh[0] = pack_hi_pair(v[0], v[1]); oh[1] = pack_hi_pair(v[2], v[3]);
+                    ol[0] = lo_pair(v[0], v[1], oh[0]); ol[1] = lo_pair(v[2], v[3], oh[1]);
+                    const size_t o = (size_t)(unsigned)j * (unsigned)a.ldo + (unsigned)i;
+                    *reinterpret_cast<u32x2*>(a.ohi + o) = oh;
+                    *reinterpret_cast<u32x2*>(a.olo + o) = ol;
+                } else if (EPI == PEPI_RES_PLANES_STATS) {  // epilogue_res_planes' arithmetic on this lane's four channels of token j
+                    f32x4 x;
+                    float v[4];
+                    // Rows beyond the data (the last fragment's padding): the stream stays ZERO there.  Their operand rows hold whatever
+                    // the buffers' previous users left, and a residual stream that feeds on its own padding through 24 layers grows
+                    // without bound (the unfolded path normalised these rows in every LayerNorm launch); zeros give mu = 0, var = 0 and
+                    // a consumer output of b' -- finite, and never read by the attention kernel.
+                    const bool pad = j >= a.j_valid;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = __builtin_fmaf(pre_scale[r4][e], __builtin_fmaf(acc[4 * r4 + e], a.out_scale, pre_bias[r4][e]), pre_res[r4][e]);
+                        if (pad) x[e] = 0.f;
+                        v[e] = x[e] * kActScale;
+                        bad |= !(fabsf(v[e]) <= kSplitPlaneLimit);
+                    }
+                    *reinterpret_cast<f32x4*>(a.D + (size_t)(unsigned)j * (unsigned)a.ldd + (unsigned)i) = x;
+                    u32x2 oh, ol;
+                    oh[0] = pack_hi_pair(v[0], v[1]); oh[1] = pack_hi_pair(v[2], v[3]);
+                    ol[0] = lo_pair(v[0], v[1], oh[0]); ol[1] = lo_pair(v[2], v[3], oh[1]);
+                    const size_t o = (size_t)(unsigned)j * (unsigned)a.ldo + (unsigned)i;
+                    *reinterpret_cast<u32x2*>(a.ohi + o) = oh;
+                    *reinterpret_cast<u32x2*>(a.olo + o) = ol;
+                    st_s = st_s + ((x[0] + x[1]) + (x[2] + x[3]));
+                    st_q = st_q + __builtin_fmaf(x[3], x[3], __builtin_fmaf(x[2], x[2], __builtin_fmaf(x[1], x[1], x[0] * x[0])));
+                } else if (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES) {
                     g16x4 oh, ol;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -696,6 +1041,16 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
                     }
                 }
             }
+            if (EPI == PEPI_RES_PLANES_STATS) {  // the fragment's 32 channels of token j: this lane's 16 + the other half-wave's 16
+                st_s = st_s + __shfl_xor(st_s, 32);
+                st_q = st_q + __shfl_xor(st_q, 32);
+                if (half == 0) {
+                    g32x2 pr;
+                    pr[0] = st_s;
+                    pr[1] = st_q;
+                    *reinterpret_cast<g32x2*>(a.st_strip + 2 * ((size_t)(i0 >> 5) * 256 + (size_t)(j - a.strip_j0))) = pr;
+                }
+            }
             if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE);
         }
         __syncthreads();  // `red` and *next_f are rewritten for the next fragment
@@ -709,6 +1064,9 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
     const unsigned long long k_c0 = TIMING ? __builtin_readcyclecounter() : 0, k_w0 = TIMING ? wall_clock64() : 0;
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * TBUF + 2048];  // 128 KiB of operand buffers (+ 4 KiB: the strip's padded rows)
     __shared__ int strip_next;
+    // folded LayerNorm: (mu, r) of the tile's 256 tokens (consumer, 2 KiB) / per wave-row partial sums of its 256 tokens (producer, 8 KiB)
+    // + (consumer) the tile's 256 rows of b'_i and s_i (2 KiB)
+    __shared__ __attribute__((aligned(16))) float ln_lds[(kEpiLnf<EPI> ? 4 * TB : (EPI == PEPI_RES_PLANES_STATS ? 4 * 2 * TB : 4))];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, grp = wave >> 2;
@@ -731,7 +1089,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
     // part n % S of tile n / S, slots beyond S * tiles have no tile (they take strip fragments).  S = 1: whole tiles, no exchange.
     // (the GELU build keeps whole tiles, S = 1: with the partial-sum loop next to its epilogue hipcc spills 273 registers, and a
     // launch of T < 256 whole tiles on T slots is within 10 % of the split one at the sizes where it occurs -- fc1 below 16 crops)
-    constexpr bool kParSplit = PAR && EPI != PEPI_GELU_PLANES;
+    constexpr bool kParSplit = PAR && EPI != PEPI_GELU_PLANES && EPI != PEPI_LNF_GELU_PLANES;
     const int par_S = kParSplit ? max(1, min(a.par, slots_x / max(n_t, 1))) : 1;  // a.par: the host's cap (k-steps per slot, see the launch)
     if (PAR) {
         const int tile = n / par_S, part = n - tile * par_S;
@@ -850,6 +1208,18 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
         };
         gload(0);
         stage(0);
+        if (kEpiLnf<EPI>) {
+            // (mu, r) of this tile's 256 tokens for the epilogue, from the K / 256 partial pairs the producer's tiles wrote: thread t
+            // = token j0 + t.  Requested behind the first slab (vector-memory results return in order: the wait costs nothing extra),
+            // read again only after the k loop's barriers; the previous segment's readers are behind its closing barrier.
+            if (tid < TB) {
+                *reinterpret_cast<g32x2*>(ln_lds + 2 * tid) = ln_finish(a.ln_main + 2 * (size_t)(j0 + tid), a.K >> 8, 2 * (size_t)a.st_ld, a.K, a.ln_eps);
+            } else {  // the other half of the workgroup: the tile's per-row constants b'_i (x 8 where the epilogue folds the planes' scale) and s_i
+                const int r = tid - TB;
+                ln_lds[2 * TB + r] = a.bias[i0 + r] * (EPI == PEPI_LNF_GELU_PLANES ? 1.0f : kActScale);
+                ln_lds[3 * TB + r] = a.scale[i0 + r];
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (ns > 1) gload(1);
         __syncthreads();
@@ -990,11 +1360,29 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
             asm volatile("" : "+v"(tid_));  // keep the epilogue's address arithmetic inside the segment loop
             __syncthreads();                // every wave has read its last operand fragments: the buffers are free
             char* wl = reinterpret_cast<char*>(lds) + (tid_ >> 6) * 16384;
-            if (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES)
+            if constexpr (kEpiLnf<EPI>)
+                epilogue_planes_lnf<EPI>(a, acc, wl, reinterpret_cast<const g32x2*>(ln_lds) + 128 * wc, ln_lds + 2 * TB + 64 * wr, i0 + 64 * wr, j0 + 128 * wc,
+                                         tid_ & 63);
+            else if constexpr (EPI == PEPI_RES_PLANES_STATS)
+                epilogue_res_planes(a, acc, reinterpret_cast<float*>(wl), ln_lds + 2 * (TB * wr + 128 * wc), i0 + 64 * wr, j0 + 128 * wc, tid_ & 63);
+            else if constexpr (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES)
                 epilogue_planes_lds<EPI>(a, acc, wl, i0 + 64 * wr, j0 + 128 * wc, tid_ & 63);
             else
                 epilogue_f32_lds<EPI>(a, acc, reinterpret_cast<float*>(wl), i0 + 64 * wr, j0 + 128 * wc, tid_ & 63);
             __syncthreads();  // LDS buffer 0 is re-staged by the next segment's prologue
+            if constexpr (EPI == PEPI_RES_PLANES_STATS) {
+                // the tile's partial statistics: the four wave rows' 64-channel sums of token j0 + t, added in wave-row order, as ONE
+                // (sum, sum of squares) pair per token and 256-channel tile (coalesced: consecutive threads, consecutive tokens).
+                // ln_lds is rewritten by the next tile's epilogue, many barriers from here.
+                if (tid_ < TB) {
+                    const g32x2 p0 = *reinterpret_cast<const g32x2*>(ln_lds + 2 * tid_), p1 = *reinterpret_cast<const g32x2*>(ln_lds + 2 * (TB + tid_));
+                    const g32x2 p2 = *reinterpret_cast<const g32x2*>(ln_lds + 2 * (2 * TB + tid_)), p3 = *reinterpret_cast<const g32x2*>(ln_lds + 2 * (3 * TB + tid_));
+                    g32x2 t;
+                    t[0] = (p0[0] + p1[0]) + (p2[0] + p3[0]);
+                    t[1] = (p0[1] + p1[1]) + (p2[1] + p3[1]);
+                    *reinterpret_cast<g32x2*>(a.st_main + 2 * ((size_t)(i0 / TB) * (size_t)a.st_ld + (size_t)(j0 + tid_))) = t;
+                }
+            }
         }
         if (TIMING && a.trace && tid == 0 && seg < 7) a.trace[(size_t)p * 32 + 5 + 4 * seg] = wall_clock64();
     }
@@ -1064,6 +1452,10 @@ int gp_gemm_split256_launch(const float* act, int ld_act, const void* whi, const
     return GP_OK;
 }
 
+int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
+                                void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
+                                const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace,
+                                const GpLnFold* ln);
 static int g_planes_dp = 1;  // 1: data-parallel rounds before the stream-K remainder (0: everything stream-K; A/B hook)
 
 // internal entry (gp_vit.hip): D[i][j] = epi( out_scale * sum_k A[i][k] B[j][k] ), A / B = pre-split planes (see above)
@@ -1101,6 +1493,17 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
                              void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
                              const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace)
 {
+    return gp_gemm_planes256_launch_ln(ahi, alo, bhi, blo, D, ldd, ohi, olo, ldo, I, J, J_valid, K, epilogue, bias, scale, res, ldr, out_scale,
+                                       scratch, st, trace, nullptr);
+}
+
+// + the folded-LayerNorm epilogues (8, 9: consumer -- ln->ln_main / ln_strip hold the statistics of B's rows, bias = b', scale = s;
+// 10: producer -- D / res token-major [J][I], planes out, statistics to ln->st_main / st_strip).  ln->ld = tokens per partial row.
+int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
+                                void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
+                                const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace,
+                                const GpLnFold* ln)
+{
     GP_REQUIRE(gp_gemm_planes256_usable(I, J, J_valid, K),
                "gp_gemm_planes256: I=%d, J=%d must be multiples of 256 with >= 8 tiles below J_valid=%d, K=%d of 32", I, J, J_valid, K);
     int J_main, strip_fj;
@@ -1110,18 +1513,34 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
                    ((uintptr_t)bhi % 16 == 0) && ((uintptr_t)blo % 16 == 0) && ((uintptr_t)scratch % 16 == 0),
                "gp_gemm_planes256: null / misaligned operand");
     GP_REQUIRE((long long)I * K * 2 < (1ll << 31) && (long long)J * K * 2 < (1ll << 31), "gp_gemm_planes256: operand planes too large");
-    if (epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES)
+    const bool lnf = epilogue == PEPI_LNF_BIAS_PLANES || epilogue == PEPI_LNF_GELU_PLANES, resp = epilogue == PEPI_RES_PLANES_STATS;
+    const bool planes_out = epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES || lnf || resp;
+    if (planes_out)
         GP_REQUIRE(ohi && olo && ldo % 4 == 0 && ((uintptr_t)ohi % 8 == 0) && ((uintptr_t)olo % 8 == 0) && bias, "gp_gemm_planes256: bad plane output");
-    else
+    if (!planes_out)
         GP_REQUIRE(D && (long long)I * ldd < (1ll << 31) && (long long)I * (ldr > 0 ? ldr : 1) < (1ll << 31) && ldd % 4 == 0 && ldr % 4 == 0 &&
                        ((uintptr_t)D % 16 == 0) && ((uintptr_t)res % 16 == 0) && (epilogue != XEPI_BIAS_J || (uintptr_t)bias % 16 == 0),
                    "gp_gemm_planes256: bad f32 output (16-byte rows)");
-    if (epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES)
+    if (planes_out)
         GP_REQUIRE(ldo % 8 == 0 && ((uintptr_t)ohi % 16 == 0) && ((uintptr_t)olo % 16 == 0), "gp_gemm_planes256: plane output rows must be 16-byte aligned");
+    if (lnf)
+        GP_REQUIRE(ln && ln->ln_main && ln->ln_strip && scale && K % 256 == 0 && ln->ld >= J && ((uintptr_t)bias % 16 == 0) && ((uintptr_t)scale % 16 == 0) &&
+                       ((uintptr_t)ln->ln_main % 8 == 0) && ((uintptr_t)ln->ln_strip % 8 == 0),
+                   "gp_gemm_planes256: epilogue %d needs the statistics of B's rows (K %% 256 == 0), s_i and b'_i", epilogue);
+    if (resp)
+        GP_REQUIRE(ln && ln->st_main && ln->st_strip && scale && D && res && (D != res || ldd == ldr) && ldd % 4 == 0 && ldr % 4 == 0 && ln->ld >= J &&
+                       ((uintptr_t)D % 16 == 0) && ((uintptr_t)res % 16 == 0) && ((uintptr_t)bias % 16 == 0) && ((uintptr_t)scale % 16 == 0) &&
+                       (long long)J * ldd < (1ll << 31) && (long long)J * ldr < (1ll << 31) && ((uintptr_t)ln->st_main % 8 == 0) && ((uintptr_t)ln->st_strip % 8 == 0),
+                   "gp_gemm_planes256: epilogue 10 needs a token-major residual stream (res != D), LayerScale, and the statistics buffers");
     ArgsP a{(const _Float16*)ahi, (const _Float16*)alo, (const _Float16*)bhi, (const _Float16*)blo, D, ldd, (_Float16*)ohi, (_Float16*)olo, ldo,
             K, bias, scale, res, ldr, I / TB, J_main / TB, 4, reinterpret_cast<int*>(scratch),
             reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, out_scale, g_planes_dp, trace, gp_status_buffer(),
             J_main, strip_fj, (long long)(I / TB) * (J_main / TB) < kSlots ? max(1, (K / TBK) / g_planes_par_min_steps) : 0};
+    a.j_valid = (J_valid > 0 && J_valid < J) ? J_valid : J;
+    if (ln) {
+        a.ln_main = ln->ln_main; a.ln_strip = ln->ln_strip; a.st_main = ln->st_main; a.st_strip = ln->st_strip;
+        a.st_ld = ln->ld; a.ln_eps = ln->eps;
+    }
     g_epoch256 = (g_epoch256 + 1) & 0x3fffffff;
     a.epoch = (int)(0x40000000u | g_epoch256);
     GpProfScope prof(GP_PROF_GEMM_SPLIT, 2.0 * I * (J_valid > 0 && J_valid < J ? J_valid : J) * K, st);
@@ -1156,6 +1575,9 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
             case XEPI_BIAS_I_RELU: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_RELU, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
             case PEPI_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_GELU_PLANES, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
             case PEPI_BIAS_I_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case PEPI_LNF_BIAS_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_LNF_BIAS_PLANES, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case PEPI_LNF_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_LNF_GELU_PLANES, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case PEPI_RES_PLANES_STATS: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_RES_PLANES_STATS, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
             default: GP_REQUIRE(false, "gp_gemm_planes256: unknown epilogue %d", epilogue);
         }
         GP_CHECK_LAUNCH("gp_gemm_planes256/par");
@@ -1170,6 +1592,9 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
         case XEPI_BIAS_I_RELU: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_RELU>), dim3(kSlots), dim3(TNT), 0, st, a); break;
         case PEPI_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_GELU_PLANES>), dim3(kSlots), dim3(TNT), 0, st, a); break;
         case PEPI_BIAS_I_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        case PEPI_LNF_BIAS_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_LNF_BIAS_PLANES>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        case PEPI_LNF_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_LNF_GELU_PLANES>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        case PEPI_RES_PLANES_STATS: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_RES_PLANES_STATS>), dim3(kSlots), dim3(TNT), 0, st, a); break;
         default: GP_REQUIRE(false, "gp_gemm_planes256: unknown epilogue %d", epilogue);
     }
     GP_CHECK_LAUNCH("gp_gemm_planes256");
@@ -1248,6 +1673,18 @@ int gp_gemm_planes256_ragged(const void* a_hi, const void* a_lo, const void* b_h
                                     out_scale, scratch, (hipStream_t)stream, nullptr);
 }
 
+int gp_gemm_planes256_ln(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi, void* out_lo,
+                         int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale, const float* residual,
+                         int ldr, float out_scale, const float* ln_main, const float* ln_strip, float* st_main, float* st_strip, int stats_ld,
+                         float ln_eps, float* scratch, size_t scratch_bytes, void* stream)
+{
+    GP_REQUIRE(scratch && scratch_bytes >= gp_gemm_split256_scratch_bytes(), "gp_gemm_planes256_ln: scratch too small");
+    if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
+    const GpLnFold ln{ln_main, ln_strip, st_main, st_strip, stats_ld, ln_eps};
+    return gp_gemm_planes256_launch_ln(a_hi, a_lo, b_hi, b_lo, D, ldd, out_hi, out_lo, ldo, I, J, J_valid, K, epilogue, bias, scale, residual, ldr,
+                                       out_scale, scratch, (hipStream_t)stream, nullptr, &ln);
+}
+
 /* probe: no-epilogue launch with per-phase cycle counters of wave 0 of block 100; out6 (host, 8 entries): matrix phase,
  * barrier after it, memory phase, barrier after it, 0, phases, whole-kernel shader cycles, whole-kernel 100 MHz ticks */
 int gp_gemm_planes256_timing(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, int I, int J,
@@ -1281,7 +1718,7 @@ int gp_gemm_planes256_trace(const void* a_hi, const void* a_lo, const void* b_hi
 
 int gp_gemm_planes256_set_dp(int mode)  // bit 0: data-parallel rounds (default on); bit 1: test hook, head fragments are never published
 {
-    g_planes_dp = mode & 3;
+    g_planes_dp = mode & 63;  // bits 2..5: probe mask of epilogue 10 (epilogue_res_planes)
     return GP_OK;
 }
 

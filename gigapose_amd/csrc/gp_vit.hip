@@ -29,6 +29,11 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
                              void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
                              const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace = nullptr);
 
+int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
+                                void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
+                                const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace,
+                                const GpLnFold* ln);
+
 namespace {
 
 constexpr int PATCH = 14, IMG = 224, KPE = 588, KPE_PAD = 592, T_TOK = 257;
@@ -302,6 +307,102 @@ __global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* 
     }
     if (bad) gp_raise(status, GP_ST_SPLIT_RANGE);
 }
+
+// ---- Folded LayerNorm (gp_split256.hip, epilogues 8-10): entry and exit of the token-major residual stream.
+// Once per forward, after the embedding: X [C][Mpad] (channel-major) -> Xt [Mpad][C] f32, the raw activation planes of x (x 8) for
+// the first q|k|v GEMM, and each token's (sum, sum of squares) over all C channels in BOTH layouts the plane GEMM's epilogues
+// read -- tile rows [C / 256][Mpad][2] and strip rows [C / 32][256][2] -- as partial 0, the other partials zero (the GEMM
+// epilogues of the following layers write one partial per 256- / 32-channel piece).  The thread layout is
+// layernorm_planes_reg_kernel's: 32 tokens x 16 channel slices per block, X read once.
+template <int NK>
+__global__ __launch_bounds__(512) void raw_planes_stats_kernel(const float* __restrict__ X, float* __restrict__ Xt, _Float16* __restrict__ Yhi,
+                                                                _Float16* __restrict__ Ylo, float* __restrict__ st_main, float* __restrict__ st_strip,
+                                                                int Mpad, int strip_j0, int* __restrict__ status)
+{
+    constexpr int C = 128 * NK, TP = 132;
+    __shared__ float red[2][16][32];
+    __shared__ __attribute__((aligned(16))) float tile[2][32 * TP];
+    const int tok = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const size_t tok0 = (size_t)blockIdx.x * 32;
+    float xv[NK][8];
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xv[k][e] = X[(size_t)(128 * k + 8 * sl + e) * Mpad + tok0 + tok];
+            s += xv[k][e];
+            q = __builtin_fmaf(xv[k][e], xv[k][e], q);
+        }
+    red[0][sl][tok] = s;
+    red[1][sl][tok] = q;
+    __syncthreads();
+    {   // statistics: thread (sl = partial index p, tok): p = 0 carries the token's totals, every other partial of either layout is zero
+        const size_t j = tok0 + tok;
+        float ts = 0.f, tq = 0.f;
+        if (sl == 0) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { ts += red[0][u][tok]; tq += red[1][u][tok]; }
+        }
+        for (int pp = sl; pp < C / 256; pp += 16) {
+            st_main[2 * ((size_t)pp * Mpad + j)] = pp == 0 ? ts : 0.f;
+            st_main[2 * ((size_t)pp * Mpad + j) + 1] = pp == 0 ? tq : 0.f;
+        }
+        if (j >= (size_t)strip_j0 && j < (size_t)strip_j0 + 256)
+            for (int pp = sl; pp < C / 32; pp += 16) {
+                st_strip[2 * ((size_t)pp * 256 + (j - strip_j0))] = pp == 0 ? ts : 0.f;
+                st_strip[2 * ((size_t)pp * 256 + (j - strip_j0)) + 1] = pp == 0 ? tq : 0.f;
+            }
+    }
+    const int g2 = threadIdx.x & 15, t2 = threadIdx.x >> 4;  // store phase: 16 lanes = the 16 eight-channel pieces of token t2
+    const size_t row = (tok0 + t2) * C + 8 * g2;
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        float* T = tile[k & 1];
+        f32x4 w0 = {xv[k][0], xv[k][1], xv[k][2], xv[k][3]}, w1 = {xv[k][4], xv[k][5], xv[k][6], xv[k][7]};
+        *reinterpret_cast<f32x4*>(T + tok * TP + 8 * sl) = w0;
+        *reinterpret_cast<f32x4*>(T + tok * TP + 8 * sl + 4) = w1;
+        __syncthreads();  // one barrier per chunk: the other tile is rewritten only after every thread passed this one
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(T + t2 * TP + 8 * g2), r1 = *reinterpret_cast<const f32x4*>(T + t2 * TP + 8 * g2 + 4);
+        *reinterpret_cast<f32x4*>(Xt + row + 128 * k) = r0;
+        *reinterpret_cast<f32x4*>(Xt + row + 128 * k + 4) = r1;
+        v16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = (e < 4 ? r0[e] : r1[e - 4]) * kPlaneScale;   // exact product: hi and lo see the same value
+            const _Float16 hh = (_Float16)v;
+            h[e] = hh;
+            l[e] = (_Float16)(v - (float)hh);
+            mx = __builtin_elementwise_maximum(mx, __builtin_fabsf(v));
+        }
+        *reinterpret_cast<v16x8*>(Yhi + row + 128 * k) = h;
+        *reinterpret_cast<v16x8*>(Ylo + row + 128 * k) = l;
+    }
+    if (!(mx <= kSplitPlaneLimit)) gp_raise(status, GP_ST_SPLIT_RANGE);  // !(<=): a NaN / inf residual stream counts
+}
+
+// Once per forward, after the last block: Xt [Mpad][C] -> X [C][Mpad] (what features_kernel and forward_features read)
+__global__ __launch_bounds__(256) void transpose_tm_to_cm_kernel(const float* __restrict__ Xt, float* __restrict__ X, int C, int Mpad)
+{
+    __shared__ float t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const size_t j0 = (size_t)blockIdx.x * 32, c0 = (size_t)blockIdx.y * 32;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[ty + 8 * u][tx] = Xt[(j0 + ty + 8 * u) * C + c0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) X[(c0 + ty + 8 * u) * Mpad + j0 + tx] = t[tx][ty + 8 * u];
+}
+
+// LayerNorm folded into its neighbour GEMMs: BUILT, TESTED, OFF by default (gp_vit_set_ln_fold / GIGAPOSE_LN_FOLD=1; 2 = with a
+// ping-pong residual stream).  Measured on MI355X, ViT-L at 64 crops inside a forward (profiles/r04_lnfold_masks.txt): the 48 LayerNorm
+// launches it removes cost 33.9 us each = 1.63 ms; the producer epilogue (proj, fc2: residual + raw planes + statistics) is 34 us
+// longer than the plain residual epilogue -- a wash -- and the consumers (q|k|v, fc1) are 4.6 / 9.5 us longer: 32.4 ms against
+// 32.0 ms per forward.  The LayerNorm kernel moves its 134 MB at 3.9 TB/s on the whole chip; the same bytes in a GEMM's tail are
+// moved while 256 workgroups have nothing else to do.  0 = LayerNorm as its own launches (layernorm_planes_reg_kernel).
+static int g_ln_fold = 0;
+extern "C" void gp_vit_set_ln_fold(int on) { g_ln_fold = (on >= 0 && on <= 2) ? on : 1; }
 
 static int g_attn_probe = 0;     // timing probe (gp_vit_set_attn_probe): 1 = return after staging, 2 = after query 256
 extern "C" void gp_vit_set_attn_probe(int mode) { g_attn_probe = mode; }
@@ -991,6 +1092,7 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
 }
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline size_t fold_offset(size_t sk_bytes) { return (sk_bytes + 255) / 256 * 256; }  // the fold buffers start 256-byte aligned behind the scratch
 
 }  // namespace
 
@@ -1010,12 +1112,18 @@ size_t gp_vit_workspace_bytes(int B, int dim, int mlp_dim)
     const size_t pe_need = (size_t)KPE_PAD * B * GP_P + (size_t)dim * B * GP_P;
     if (pe_need > f) f = pe_need;
     // + the stream-K scratch of the GEMMs (gp_gemm.hip), behind the activations
-    return sizeof(float) * ((size_t)5 * dim * Mpad + f) + gp_gemm_streamk_bytes();
+    // + (folded LayerNorm, plane path) the second residual buffer the token-major stream ping-pongs with and the per-token partial
+    //   statistics: tile rows [dim / 256][Mpad][2], strip rows [dim / 32][256][2]
+    return sizeof(float) * ((size_t)5 * dim * Mpad + f) + fold_offset(gp_gemm_streamk_bytes()) +
+           sizeof(float) * ((size_t)dim * Mpad + (size_t)2 * (dim / 256 + 1) * Mpad + (size_t)2 * (dim / 32 + 1) * 256);
 }
 
 // per-layer table of pre-split weight planes (f16 hi / lo, PyTorch-native [out][in]) for the split-f16 mode
 // (entries 10..19, optional: the same five weights as x64 single-accumulator planes for the 256 x 256 kernel of gp_split256.hip)
 enum { S_QK_HI = 0, S_QK_LO, S_V_HI, S_V_LO, S_PROJ_HI, S_PROJ_LO, S_FC1_HI, S_FC1_LO, S_FC2_HI, S_FC2_LO, S_PER_LAYER = 10 };
+// entries 20..27 (optional, n_split = 28 * depth): the folded-LayerNorm operands of the plane path -- x64 planes of W_qkv diag(g1) (3 dim,
+// dim) and W_fc1 diag(g2) (mlp, dim), and per output row s_i = sum_k (W_ik g_k) [of the plane values] and b'_i = b_i + sum_k W_ik be_k (f32)
+enum { S_QKVG_HI = 20, S_QKVG_LO, S_FC1G_HI, S_FC1G_LO, S_QKV_S, S_QKV_BP, S_FC1_S, S_FC1_BP, S_FOLD_STRIDE = 28 };
 
 int gp_vit_forward_split(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                          const float* const* weights, int n_weights, const void* const* split, int n_split,
@@ -1030,6 +1138,24 @@ int gp_attention_split(const void* qkv_hi, const void* qkv_lo, void* out_hi, voi
     hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(ATH), 0, (hipStream_t)stream,
                        (const _Float16*)qkv_hi, (const _Float16*)qkv_lo, (_Float16*)out_hi, (_Float16*)out_lo, B, heads, dim, Mpad, g_attn_probe);
     GP_CHECK_LAUNCH("gp_attention_split");
+    return GP_OK;
+}
+
+/* stage entry (tests): what the folded-LayerNorm plane path runs once per forward after the embedding.  X [C][Mpad] f32 channel-major ->
+ * Xt [Mpad][C] f32, raw planes hi / lo [Mpad][C] (x 8), per-token (sum, sum of squares) as partial 0 of the tile layout
+ * st_main [C / 256][Mpad][2] and (tokens strip_j0 .. strip_j0 + 255) of the strip layout st_strip [C / 32][256][2], other partials 0. */
+int gp_raw_planes_stats(const float* X, float* Xt, void* out_hi, void* out_lo, float* st_main, float* st_strip, int C, int Mpad, int strip_j0,
+                        void* stream)
+{
+    GP_REQUIRE(X && Xt && out_hi && out_lo && st_main && st_strip && (C == 1024 || C == 768) && Mpad > 0 && Mpad % 32 == 0 && strip_j0 >= 0,
+               "gp_raw_planes_stats: bad arguments (C must be 768 or 1024)");
+    if (C == 1024)
+        hipLaunchKernelGGL(raw_planes_stats_kernel<8>, dim3(Mpad / 32), dim3(512), 0, (hipStream_t)stream, X, Xt, (_Float16*)out_hi, (_Float16*)out_lo,
+                           st_main, st_strip, Mpad, strip_j0, gp_status_buffer());
+    else
+        hipLaunchKernelGGL(raw_planes_stats_kernel<6>, dim3(Mpad / 32), dim3(512), 0, (hipStream_t)stream, X, Xt, (_Float16*)out_hi, (_Float16*)out_lo,
+                           st_main, st_strip, Mpad, strip_j0, gp_status_buffer());
+    GP_CHECK_LAUNCH("gp_raw_planes_stats");
     return GP_OK;
 }
 
@@ -1067,9 +1193,12 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
     GP_REQUIRE(images && weights && workspace && out_features, "gp_vit_forward: null pointer");
     GP_REQUIRE(workspace_bytes >= gp_vit_workspace_bytes(B, dim, mlp_dim), "gp_vit_forward: workspace too small");
     for (int i = 0; i < n_weights; ++i) GP_REQUIRE(weights[i], "gp_vit_forward: weight pointer %d is null", i);
-    GP_REQUIRE(split == nullptr || n_split == depth * S_PER_LAYER || n_split == 2 * depth * S_PER_LAYER,
-               "gp_vit_forward_split: expected %d (or %d) split planes, got %d", depth * S_PER_LAYER, 2 * depth * S_PER_LAYER, n_split);
-    const int sp_stride = (split && n_split == 2 * depth * S_PER_LAYER) ? 2 * S_PER_LAYER : S_PER_LAYER;
+    GP_REQUIRE(split == nullptr || n_split == depth * S_PER_LAYER || n_split == 2 * depth * S_PER_LAYER || n_split == depth * S_FOLD_STRIDE,
+               "gp_vit_forward_split: expected %d (or %d, or %d) split planes, got %d", depth * S_PER_LAYER, 2 * depth * S_PER_LAYER,
+               depth * S_FOLD_STRIDE, n_split);
+    const bool have_fold = split && n_split == depth * S_FOLD_STRIDE;
+    const int sp_stride = have_fold ? S_FOLD_STRIDE : ((split && n_split == 2 * depth * S_PER_LAYER) ? 2 * S_PER_LAYER : S_PER_LAYER);
+    const bool have_x64 = split && sp_stride >= 2 * S_PER_LAYER;
     if (split) {
         GP_REQUIRE(dim % 32 == 0 && mlp_dim % 32 == 0, "gp_vit_forward_split: dim / mlp_dim must be multiples of 32");
         for (int i = 0; i < n_split; ++i) GP_REQUIRE(split[i], "gp_vit_forward_split: split plane %d is null", i);
@@ -1106,10 +1235,76 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
     // planes alias the f32 buffers they replace (2 planes x 2 bytes = 4 bytes per element).  Bit-identical to the
     // f32-activation kernels (same values, same split, same k order).
     const int Mtok = B * T_TOK;  // rows that carry tokens: the plane GEMMs tile floor(Mtok / 256) * 256 of them + a strip
-    const bool planes = split && sp_stride == 2 * S_PER_LAYER && g_vit_planes && gp_gemm_planes256_usable(2 * C, Mpad, Mtok, C) &&
+    const bool planes = have_x64 && g_vit_planes && gp_gemm_planes256_usable(2 * C, Mpad, Mtok, C) &&
                         gp_gemm_planes256_usable(C, Mpad, Mtok, C) && gp_gemm_planes256_usable(mlp_dim, Mpad, Mtok, C) &&
                         gp_gemm_planes256_usable(C, Mpad, Mtok, mlp_dim) && (g_vit_planes == 2 || gp_gemm_split256_usable(Mpad, C, C));
-    if (planes) {
+    // Plane path with LayerNorm folded into its neighbour GEMMs (gp_split256.hip, epilogues 8-10): per layer q|k|v, attention, proj,
+    // fc1, fc2 -- five launches, no LayerNorm kernel.  The residual stream is token-major f32 and ping-pongs between X2 and X (a
+    // producer epilogue reads one and writes the other: no load waits for a store); its raw planes (what the next GEMM multiplies)
+    // are written by proj into the (dead) q|k|v region and by fc2 into the (dead) attention-output region.
+    const bool fold = planes && have_fold && g_ln_fold && g_vit_planes == 2 && nl > 0 && C % 256 == 0 && (C == 1024 || C == 768) &&
+                      gp_gemm_planes256_usable(3 * C, Mpad, Mtok, C);
+    if (fold) {
+        float* X2 = reinterpret_cast<float*>(reinterpret_cast<char*>(SK) + fold_offset(gp_gemm_streamk_bytes()));
+        float* st_main = X2 + (size_t)C * Mpad;
+        float* st_strip = st_main + (size_t)2 * (C / 256 + 1) * Mpad;
+        _Float16* Hhi = reinterpret_cast<_Float16*>(Hn);
+        _Float16* Hlo = Hhi + (size_t)C * Mpad;
+        _Float16* Ahi = reinterpret_cast<_Float16*>(QK);          // q | k | v planes [Mpad][3C]
+        _Float16* Alo = Ahi + (size_t)3 * C * Mpad;
+        _Float16* Phi = reinterpret_cast<_Float16*>(QK);          // raw residual planes [Mpad][C] written by proj (q | k | v are dead by then)
+        _Float16* Plo = Phi + (size_t)C * Mpad;
+        _Float16* Fhi = reinterpret_cast<_Float16*>(F);
+        _Float16* Flo = Fhi + (size_t)mlp_dim * Mpad;
+        const float os = 1.0f / (8.0f * 64.0f);
+        const int J_main = (Mtok / 256) * 256;
+        GpLnFold ln{st_main, st_strip, st_main, st_strip, Mpad, ln_eps};
+        {
+            GpProfScope prof(GP_PROF_LN, 16.0 * C * Mpad, st);  // reads X, writes Xt + two planes
+            if (C == 1024)
+                hipLaunchKernelGGL(raw_planes_stats_kernel<8>, dim3(Mpad / 32), dim3(512), 0, st, X, X2, Hhi, Hlo, st_main, st_strip, Mpad, J_main, gp_status_buffer());
+            else
+                hipLaunchKernelGGL(raw_planes_stats_kernel<6>, dim3(Mpad / 32), dim3(512), 0, st, X, X2, Hhi, Hlo, st_main, st_strip, Mpad, J_main, gp_status_buffer());
+        }
+        GP_CHECK_LAUNCH("gp_vit_forward/raw_planes_stats");
+        // In place (res == D): a lane writes exactly the 32 bytes it read, and every read of an item is issued before any store that
+        // could alias it (epilogue_res_planes fetches a batch ahead).  A ping-pong between two buffers was measured slower inside a
+        // forward (+20 us per launch: the write-allocate of a second 67 MB stream next to the planes; profiles/r04_lnfold_masks.txt).
+        float* Xa = X2;  // holds the stream
+        float* Xb = g_ln_fold == 2 ? X : X2;  // gp_vit_set_ln_fold(2): the ping-pong variant (A/B)
+        for (int l = 0; l < nl; ++l) {
+            const float* const* w = weights + W_HEADER + l * L_PER_LAYER;
+            const void* const* sf = split + l * sp_stride;
+            const void* const* sq = sf + S_PER_LAYER;
+            // q | k | v = LN1(x) W^T + b as planes: raw planes x (W diag(g1)), statistics in the epilogue
+            if ((rc = gp_gemm_planes256_launch_ln(sf[S_QKVG_HI], sf[S_QKVG_LO], Hhi, Hlo, nullptr, 0, Ahi, Alo, 3 * C, 3 * C, Mpad, Mtok, C,
+                                                  8 /*LN-folded bias -> planes*/, (const float*)sf[S_QKV_BP], (const float*)sf[S_QKV_S], nullptr, 0, os, SK,
+                                                  st, nullptr, &ln)))
+                return rc;
+            {
+                GpProfScope prof(GP_PROF_ATTN, 4.0 * B * heads * 257.0 * 257.0 * 64.0, st);
+                hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(ATH), 0, st, Ahi, Alo, Hhi, Hlo, B, heads, C, Mpad, 0);
+            }
+            GP_CHECK_LAUNCH("gp_vit_forward/attention_split");
+            // x = x + ls1 * proj(attn): token-major f32 + raw planes (into the q | k | v region) + statistics
+            if ((rc = gp_gemm_planes256_launch_ln(sq[S_PROJ_HI], sq[S_PROJ_LO], Hhi, Hlo, Xb, C, Phi, Plo, C, C, Mpad, Mtok, C,
+                                                  10 /*residual + planes + statistics*/, w[L_PROJ_B], w[L_LS1], Xa, C, os, SK, st, nullptr, &ln)))
+                return rc;
+            // gelu(fc1(LN2(x))) as planes
+            if ((rc = gp_gemm_planes256_launch_ln(sf[S_FC1G_HI], sf[S_FC1G_LO], Phi, Plo, nullptr, 0, Fhi, Flo, mlp_dim, mlp_dim, Mpad, Mtok, C,
+                                                  9 /*LN-folded GELU -> planes*/, (const float*)sf[S_FC1_BP], (const float*)sf[S_FC1_S], nullptr, 0, os, SK,
+                                                  st, nullptr, &ln)))
+                return rc;
+            // x = x + ls2 * fc2(.): back into the first buffer, raw planes into the attention-output region
+            if ((rc = gp_gemm_planes256_launch_ln(sq[S_FC2_HI], sq[S_FC2_LO], Fhi, Flo, Xa, C, Hhi, Hlo, C, C, Mpad, Mtok, mlp_dim,
+                                                  10, w[L_FC2_B], w[L_LS2], Xb, C, os, SK, st, nullptr, &ln)))
+                return rc;
+        }
+        // back to the channel-major layout the feature epilogue (and forward_features) read
+        hipLaunchKernelGGL(transpose_tm_to_cm_kernel, dim3(Mpad / 32, C / 32), dim3(256), 0, st, Xa, X, C, Mpad);
+        GP_CHECK_LAUNCH("gp_vit_forward/transpose");
+    }
+    if (planes && !fold) {
         _Float16* Hhi = reinterpret_cast<_Float16*>(Hn);
         _Float16* Hlo = Hhi + (size_t)C * Mpad;
         _Float16* Fhi = reinterpret_cast<_Float16*>(F);
@@ -1184,7 +1379,7 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
         launch_layernorm(X, Hn, w[L_LN1_G], w[L_LN1_B], C, Mpad, ln_eps, st);
         GP_CHECK_LAUNCH("gp_vit_forward/layernorm");
         const void* const* sp = split ? split + l * sp_stride : nullptr;
-        const void* const* sq = (sp && sp_stride == 2 * S_PER_LAYER) ? sp + S_PER_LAYER : nullptr;  // x64 planes (256-tile kernel)
+        const void* const* sq = (sp && have_x64) ? sp + S_PER_LAYER : nullptr;  // x64 planes (256-tile kernel)
         // split GEMM dispatch: 256 x 256 stream-K kernel when the shape fills the chip with 256-tiles, else 128 x 128
         auto sgemm = [&](const float* act, int ld_act, int which, float* D, int ldd, int I, int J, int K, int act_is_b, int epi,
                          const float* bias, const float* scale, const float* res, int ldr) -> int {

@@ -87,6 +87,9 @@ class Dinov2ViT(nn.Module):
         # "128" = every GEMM on the two-accumulator 128 x 128 kernel (range 65504, slower).  GigaPose switches to "128" by itself
         # when the range guard trips (gigaPose.py: _widen_split_range) -- DINOv2 checkpoints are known for a few massive activations
         self.split_gemm = os.environ.get("GIGAPOSE_SPLIT_GEMM", "256")
+        # LayerNorm folded into the neighbouring plane GEMMs (gp_split256.hip, epilogues 8-10): built and tested, measured 1 % slower
+        # than the LayerNorm launches it removes (csrc/gp_vit.hip: g_ln_fold) -- off unless GIGAPOSE_LN_FOLD=1 (2: ping-pong stream)
+        self.ln_fold = int(os.environ.get("GIGAPOSE_LN_FOLD", "0"))
 
     def set_split_gemm(self, mode):
         if mode not in ("256", "128"):
@@ -228,6 +231,22 @@ class Dinov2ViT(nn.Module):
                     split += [qkv_hi[:2 * C], qkv_lo[:2 * C], qkv_hi[2 * C:], qkv_lo[2 * C:]]
                     for w in ws[2:]:
                         split += list(split_planes_x64(w))
+                    # entries 20..27: LayerNorm folded into q|k|v and fc1 (gp_split256.hip, epilogues 8-10): the GEMM multiplies the RAW
+                    # residual planes with W diag(gamma); its epilogue applies r_j (acc - mu_j s_i) + b'_i with s_i = sum_k (W gamma)_ik --
+                    # summed over the VALUES THE PLANES HOLD, so that the mean's contribution cancels against exactly what the matrix
+                    # core accumulated -- and b'_i = b_i + sum_k W_ik beta_k (both in float64, stored f32)
+                    for lin, norm in ((blk.attn.qkv, blk.norm1), (blk.mlp.fc1, blk.norm2)) if self.ln_fold else ():
+                        w64 = lin.weight.detach().to(device).double()
+                        g, be = norm.weight.detach().to(device).float(), norm.bias.detach().to(device).double()
+                        hi, lo = split_planes_x64(lin.weight.detach().to(device).float() * g[None, :])
+                        fold_planes = [hi, lo]
+                        s_i = ((hi.double() + lo.double()).sum(dim=1) / 64.0).float().contiguous()
+                        b_p = (lin.bias.detach().to(device).double() + w64 @ be).float().contiguous()
+                        split += fold_planes
+                        if lin is blk.attn.qkv:
+                            pend = [s_i, b_p]
+                        else:
+                            split += pend + [s_i, b_p]
             split_table = (ctypes.c_void_p * len(split))(*[t.data_ptr() for t in split])
             if "GIGAPOSE_VIT_PLANES" in os.environ:  # A/B probes (csrc/gp_vit.hip): 0 f32 activations, 1 f32 attention, 2 default
                 _lib.lib().gp_vit_set_planes(int(os.environ["GIGAPOSE_VIT_PLANES"]))
@@ -235,6 +254,7 @@ class Dinov2ViT(nn.Module):
                 _lib.lib().gp_gemm_planes256_set_par(int(os.environ["GIGAPOSE_PLANES_PAR"]))
             if "GIGAPOSE_PLANES_DP" in os.environ:   # A/B probe: 0 = every plane-GEMM tile cut stream-K style
                 _lib.lib().gp_gemm_planes256_set_dp(int(os.environ["GIGAPOSE_PLANES_DP"]))
+            _lib.lib().gp_vit_set_ln_fold(self.ln_fold)   # needs the operands packed above (n_split = 28 per layer)
         self._packed = (device, tensors, table, split, split_table)
 
     def _workspace(self, B, device):

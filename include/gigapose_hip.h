@@ -258,6 +258,26 @@ int gp_gemm_planes256_ragged(const void* a_hi, const void* a_lo, const void* b_h
 int gp_gemm_planes256_trace(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
                             void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
                             const float* residual, int ldr, float out_scale, float* scratch, unsigned long long* trace, void* stream);
+/* LayerNorm folded into its neighbour GEMMs (round 4; HF modeling_dinov2.py:342-380: norm1 -> attention, norm2 -> mlp).
+ * sum_k W_ik LN(x)_k + b_i = r (sum_k (W_ik g_k) x_k - mu s_i) + b'_i with per-token mu, r: the GEMM multiplies the RAW residual planes
+ * with W diag(g) and the per-token part moves into its epilogue; the producing GEMM (proj, fc2) writes those raw planes and the
+ * per-token partial (sum, sum of squares) pairs next to the f32 residual stream.  gp_gemm_planes256_ln = gp_gemm_planes256_ragged +
+ *   epilogue 10 (producer): x = residual + scale_i (out_scale acc + bias_i) on a TOKEN-MAJOR f32 stream D / residual [J][I] (ldd, ldr;
+ *               D != residual), the same x as planes out_hi / out_lo [J][I] (x 8), statistics to st_main [I / 256][stats_ld][2]
+ *               (rows below floor(J_valid / 256) * 256) and st_strip [I / 32][256][2] (the ragged rows above);
+ *   epilogue 8 / 9 (consumer; 9 through GELU): planes of r_j (out_scale acc - mu_j s_i) + b'_i with bias = b', scale = s, mu / r from
+ *               ln_main [K / 256][stats_ld][2] / ln_strip [K / 32][256][2] and ln_eps; needs K % 256 == 0.
+ * gp_raw_planes_stats: the entry of the token-major stream (once per forward, after the embedding), see gp_vit.hip.
+ * gp_vit_forward_split takes the path when n_split = 28 * depth (entries 20..27 per layer: x64 planes of W_qkv diag(g1) and
+ * W_fc1 diag(g2), then s and b' of each as f32 vectors) and every GEMM of a layer fills the plane kernel; gp_vit_set_ln_fold(0)
+ * keeps LayerNorm as its own launches (A/B hook). */
+int gp_gemm_planes256_ln(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi, void* out_lo,
+                         int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale, const float* residual,
+                         int ldr, float out_scale, const float* ln_main, const float* ln_strip, float* st_main, float* st_strip, int stats_ld,
+                         float ln_eps, float* scratch, size_t scratch_bytes, void* stream);
+int gp_raw_planes_stats(const float* X, float* Xt, void* out_hi, void* out_lo, float* st_main, float* st_strip, int C, int Mpad, int strip_j0,
+                        void* stream);
+void gp_vit_set_ln_fold(int on);
 /* stage entry of the plane path (tests, tools/probe_stage_errors.py): LayerNorm over C of X [C][Mpad] f32 (channel-major, as the
  * residual stream is kept) -> token-major activation planes hi / lo [Mpad][C] (x 8); HF modeling_dinov2.py:342-380 norm1 / norm2. */
 int gp_layernorm_planes(const float* X, void* out_hi, void* out_lo, const float* gamma, const float* beta, int C, int Mpad, float eps,

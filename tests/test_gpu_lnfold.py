@@ -1,0 +1,251 @@
+"""GPU: LayerNorm folded into its neighbour plane GEMMs (gp_split256.hip, epilogues 8-10; gp_vit.hip: raw_planes_stats_kernel) through
+the C-ABI stage entries, against float64 and against the unfolded plane path (LayerNorm kernel + epilogues 7 / 6 / 3).
+
+Reference arithmetic: HF modeling_dinov2.py:342-380 (norm1 -> attention -> layer_scale1 + residual, norm2 -> mlp -> layer_scale2 +
+residual; LayerNorm eps 1e-6).  Inputs carry what a real checkpoint's residual stream carries and a random-init one does not:
+a few outlier channels (x 30) and a per-token mean that is not zero (0.5 sigma; a stress case at 3 sigma is measured and bounded:
+the matrix core accumulates mu s_i next to the normalised part, so the round-off of the folded form grows like 1 + |mu| / sigma --
+a transformer's residual stream has |mu| << sigma, outlier channels included)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from gigapose_amd import _lib
+from gigapose_amd.vit import split_planes_x64
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+C = 1024
+EPS = 1e-6
+
+
+def ws_scratch():
+    lib = _lib.lib()
+    lib.gp_gemm_split256_workspace_bytes.restype = ctypes.c_size_t
+    nb = lib.gp_gemm_split256_workspace_bytes()
+    return torch.zeros(nb // 4, device=DEV), nb
+
+
+def planes_of(x, scale=8.0):
+    hi = torch.empty(x.shape, dtype=torch.float16, device=DEV)
+    lo = torch.empty_like(hi)
+    _lib.call("gp_split_planes", _lib.ptr(x.contiguous()), ctypes.c_size_t(x.numel()), _lib.f(scale), _lib.ptr(hi), _lib.ptr(lo), _lib.stream_ptr())
+    return hi, lo
+
+
+def val(hi, lo, scale=8.0):
+    return (hi.double() + lo.double()) / scale
+
+
+def residual_stream(B, seed, mean_sigma=0.5, outliers=True):
+    """x [Mtok][C] f32 like a checkpoint's residual stream: rms ~ 8, a few outlier channels, a token-dependent mean; Mpad rows, zeros beyond."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    Mtok = B * 257
+    Mpad = (Mtok + 255) // 256 * 256
+    x = torch.randn(Mtok, C, generator=g) * 6.0
+    if outliers:
+        x[:, [7, 300, 911]] *= 30.0
+    x += mean_sigma * 6.0 * torch.randn(Mtok, 1, generator=g)
+    xp = torch.zeros(Mpad, C)
+    xp[:Mtok] = x
+    return xp.to(DEV), Mtok, Mpad
+
+
+def raw_planes_stats(x_tm, Mtok):
+    """gp_raw_planes_stats on the channel-major copy of x_tm [Mpad][C]; returns Xt, (hi, lo), st_main, st_strip, J_main."""
+    Mpad = x_tm.shape[0]
+    J_main = (Mtok // 256) * 256
+    Xcm = x_tm.t().contiguous()
+    Xt = torch.empty(Mpad, C, device=DEV)
+    hi = torch.empty(Mpad, C, dtype=torch.float16, device=DEV)
+    lo = torch.empty_like(hi)
+    st_main = torch.full((C // 256 + 1, Mpad, 2), float("nan"), device=DEV)
+    st_strip = torch.full((C // 32 + 1, 256, 2), float("nan"), device=DEV)
+    _lib.call("gp_raw_planes_stats", _lib.ptr(Xcm), _lib.ptr(Xt), _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(st_main), _lib.ptr(st_strip), _lib.i(C),
+              _lib.i(Mpad), _lib.i(J_main), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    return Xt, (hi, lo), st_main, st_strip, J_main
+
+
+def gemm_ln(whi, wlo, bhi, blo, I, Mpad, Mtok, K, epi, bias, scale, st_main, st_strip, res=None, D=None):
+    ws, nb = ws_scratch()
+    ohi = torch.zeros(Mpad, I, dtype=torch.float16, device=DEV)
+    olo = torch.zeros_like(ohi)
+    _lib.call("gp_gemm_planes256_ln", _lib.ptr(whi), _lib.ptr(wlo), _lib.ptr(bhi), _lib.ptr(blo), _lib.ptr(D), _lib.i(I if D is not None else 0),
+              _lib.ptr(ohi), _lib.ptr(olo), _lib.i(I), _lib.i(I), _lib.i(Mpad), _lib.i(Mtok), _lib.i(K), _lib.i(epi), _lib.ptr(bias), _lib.ptr(scale),
+              _lib.ptr(res), _lib.i(I if res is not None else 0), _lib.f(1.0 / 512.0), _lib.ptr(st_main), _lib.ptr(st_strip), _lib.ptr(st_main),
+              _lib.ptr(st_strip), _lib.i(Mpad), _lib.f(EPS), _lib.ptr(ws), ctypes.c_size_t(nb), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert _lib.lib().gp_gemm_split256_error(_lib.ptr(ws), _lib.stream_ptr()) == 0
+    return ohi, olo
+
+
+def fold_operands(W, b, gamma, beta):
+    """what vit.py packs per folded GEMM: x64 planes of W diag(gamma), s_i over the plane values, b'_i"""
+    hi, lo = split_planes_x64(W * gamma[None, :])
+    s = ((hi.double() + lo.double()).sum(1) / 64.0).float().contiguous()
+    bp = (b.double() + W.double() @ beta.double()).float().contiguous()
+    return hi, lo, s, bp
+
+
+def rel_rms(a, ref):
+    return float(((a - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
+
+
+def test_raw_planes_stats_entry():
+    _lib.status_word(DEV)
+    x, Mtok, Mpad = residual_stream(9, 1)
+    Xt, (hi, lo), st_main, st_strip, J_main = raw_planes_stats(x, Mtok)
+    assert torch.equal(Xt, x)
+    v = val(hi, lo)
+    assert float((v - x.double()).abs().max() / x.abs().max()) < 2.0 ** -21      # 22-bit planes
+    s64, q64 = x.double().sum(1), (x.double() ** 2).sum(1)
+    np.testing.assert_allclose(st_main[0, :, 0].double().cpu(), s64.cpu(), rtol=0, atol=1e-6 * float(x.abs().sum(1).max()))
+    np.testing.assert_allclose(st_main[0, :, 1].double().cpu(), q64.cpu(), rtol=2e-6)
+    assert not st_main[1:C // 256].any() and not st_strip[1:C // 32].any()         # the other partials are zero
+    rows = torch.arange(J_main, min(J_main + 256, Mpad), device=DEV)
+    assert torch.equal(st_strip[0, : len(rows)], st_main[0, rows])
+
+
+@pytest.mark.parametrize("B", [22, 8])     # 264 tiles: the serial kernel; 96 tiles: the parallel split-K build (fewer tiles than slots)
+@pytest.mark.parametrize("epi", [8, 9])
+def test_folded_layernorm_consumer_vs_f64_and_vs_the_unfolded_path(B, epi):
+    torch.manual_seed(5)
+    x, Mtok, Mpad = residual_stream(B, 2)
+    I = 3 * C
+    W = (torch.randn(I, C, device=DEV) / 32.0).contiguous()
+    b = torch.randn(I, device=DEV) * 0.1
+    gamma, beta = 1.0 + 0.3 * torch.randn(C, device=DEV), 0.2 * torch.randn(C, device=DEV)
+    _, (xhi, xlo), st_main, st_strip, _ = raw_planes_stats(x, Mtok)
+    whi, wlo, s, bp = fold_operands(W, b, gamma, beta)
+    ohi, olo = gemm_ln(whi, wlo, xhi, xlo, I, Mpad, Mtok, C, epi, bp, s, st_main, st_strip)
+    got = val(ohi, olo)[:Mtok]
+    y = torch.nn.functional.layer_norm(x[:Mtok].double(), (C,), gamma.double(), beta.double(), EPS) @ W.double().t() + b.double()
+    ref = torch.nn.functional.gelu(y) if epi == 9 else y
+    e_fold = rel_rms(got, ref)
+    # the unfolded plane path on the same input: LayerNorm kernel -> planes -> epilogue 7 / 6
+    hhi = torch.empty(Mpad, C, dtype=torch.float16, device=DEV)
+    hlo = torch.empty_like(hhi)
+    _lib.call("gp_layernorm_planes", _lib.ptr(x.t().contiguous()), _lib.ptr(hhi), _lib.ptr(hlo), _lib.ptr(gamma), _lib.ptr(beta), _lib.i(C), _lib.i(Mpad),
+              _lib.f(EPS), _lib.stream_ptr())
+    uhi, ulo = split_planes_x64(W)
+    ws, nb = ws_scratch()
+    phi = torch.zeros(Mpad, I, dtype=torch.float16, device=DEV)
+    plo = torch.zeros_like(phi)
+    _lib.call("gp_gemm_planes256_ragged", _lib.ptr(uhi), _lib.ptr(ulo), _lib.ptr(hhi), _lib.ptr(hlo), _lib.ptr(None), _lib.i(0), _lib.ptr(phi), _lib.ptr(plo),
+              _lib.i(I), _lib.i(I), _lib.i(Mpad), _lib.i(Mtok), _lib.i(C), _lib.i(6 if epi == 9 else 7), _lib.ptr(b), _lib.ptr(None), _lib.ptr(None),
+              _lib.i(0), _lib.f(1.0 / 512.0), _lib.ptr(ws), ctypes.c_size_t(nb), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    e_unf = rel_rms(val(phi, plo)[:Mtok], ref)
+    e_max = float((got - ref).abs().max() / ref.abs().max())
+    print(f"folded LayerNorm + GEMM (epilogue {epi}, {B} crops) vs f64: rel rms {e_fold:.2e} (max / max {e_max:.2e}) | unfolded plane path {e_unf:.2e}")
+    assert e_fold < 1.3 * e_unf + 2e-8 and e_fold < 2e-6
+    if B == 22 and epi == 8:   # stress: a per-token mean of 3 sigma -- bounded growth of the round-off, still f32-class
+        xs, _, _ = residual_stream(B, 2, mean_sigma=3.0)
+        _, (shi, slo), sm, ss, _ = raw_planes_stats(xs, Mtok)
+        o2hi, o2lo = gemm_ln(whi, wlo, shi, slo, I, Mpad, Mtok, C, epi, bp, s, sm, ss)
+        ys = torch.nn.functional.layer_norm(xs[:Mtok].double(), (C,), gamma.double(), beta.double(), EPS) @ W.double().t() + b.double()
+        e_s = rel_rms(val(o2hi, o2lo)[:Mtok], ys)
+        print(f"   stress, per-token mean of 3 sigma: rel rms {e_s:.2e}")
+        assert e_s < 4 * e_unf
+    assert torch.count_nonzero(ohi[(Mtok + 31) // 32 * 32:]) == 0                   # rows beyond the ragged strip untouched
+    _lib.check_status()
+
+
+@pytest.mark.parametrize("B,K", [(64, 1024), (8, 4096)])
+def test_residual_planes_statistics_producer_then_consumer(B, K):
+    """epilogue 10 (proj / fc2 shape): x' = x + ls (a W^T + b) on the token-major stream, its raw planes and its statistics -- then the
+    NEXT GEMM (epilogue 8) consumes those planes + statistics and must give LN(x') W2^T + b2."""
+    torch.manual_seed(6)
+    x, Mtok, Mpad = residual_stream(B, 3)
+    a = torch.zeros(Mpad, K, device=DEV)
+    a[:Mtok] = torch.randn(Mtok, K, device=DEV)
+    Wp = (torch.randn(C, K, device=DEV) / K ** 0.5).contiguous()
+    bp_, ls = torch.randn(C, device=DEV) * 0.1, 0.5 + torch.rand(C, device=DEV)
+    ahi, alo = planes_of(a)
+    whi, wlo = split_planes_x64(Wp)
+    st_main = torch.full((C // 256 + 1, Mpad, 2), float("nan"), device=DEV)
+    st_strip = torch.full((C // 32 + 1, 256, 2), float("nan"), device=DEV)
+    D = torch.zeros(Mpad, C, device=DEV)
+    ohi, olo = gemm_ln(whi, wlo, ahi, alo, C, Mpad, Mtok, K, 10, bp_, ls, st_main, st_strip, res=x, D=D)
+    ref = x[:Mtok].double() + ls.double() * (val(ahi, alo)[:Mtok] @ Wp.double().t() + bp_.double())
+    e = rel_rms(D[:Mtok].double(), ref)
+    assert e < 2e-7, e
+    assert float((val(ohi, olo)[:Mtok] - D[:Mtok].double()).abs().max() / D.abs().max()) < 2.0 ** -21   # planes = the f32 stream to 22 bits
+    J_main, jr = (Mtok // 256) * 256, (Mtok + 31) // 32 * 32
+    s_main, q_main = st_main[: C // 256, :J_main, 0].double().sum(0), st_main[: C // 256, :J_main, 1].double().sum(0)
+    s_strip, q_strip = st_strip[: C // 32, : jr - J_main, 0].double().sum(0), st_strip[: C // 32, : jr - J_main, 1].double().sum(0)
+    Dd = D.double()
+    scale = float(Dd.abs().sum(1).max())
+    np.testing.assert_allclose(torch.cat([s_main, s_strip]).cpu(), Dd[:jr].sum(1).cpu(), rtol=0, atol=2e-7 * scale)
+    np.testing.assert_allclose(torch.cat([q_main, q_strip]).cpu(), (Dd[:jr] ** 2).sum(1).cpu(), rtol=1e-6)
+    # the next GEMM consumes planes + statistics
+    I2 = 3 * C
+    W2 = (torch.randn(I2, C, device=DEV) / 32.0).contiguous()
+    b2 = torch.randn(I2, device=DEV) * 0.1
+    gamma, beta = 1.0 + 0.3 * torch.randn(C, device=DEV), 0.2 * torch.randn(C, device=DEV)
+    w2hi, w2lo, s2, bp2 = fold_operands(W2, b2, gamma, beta)
+    qhi, qlo = gemm_ln(w2hi, w2lo, ohi, olo, I2, Mpad, Mtok, C, 8, bp2, s2, st_main, st_strip)
+    y = torch.nn.functional.layer_norm(Dd[:Mtok], (C,), gamma.double(), beta.double(), EPS) @ W2.double().t() + b2.double()
+    e2 = rel_rms(val(qhi, qlo)[:Mtok], y)
+    print(f"epilogue 10 ({B} crops, K = {K}) vs f64: stream rel rms {e:.2e}; the consuming GEMM (LN folded, statistics from the producer) {e2:.2e}")
+    assert e2 < 2e-6
+    # deterministic: a second launch of the producer agrees bit for bit (fixed-order partial sums, no atomics)
+    D2 = torch.zeros(Mpad, C, device=DEV)
+    st2, ss2 = torch.zeros_like(st_main), torch.zeros_like(st_strip)
+    o2hi, o2lo = gemm_ln(whi, wlo, ahi, alo, C, Mpad, Mtok, K, 10, bp_, ls, st2, ss2, res=x, D=D2)
+    assert torch.equal(D2, D) and torch.equal(o2hi, ohi) and torch.equal(o2lo, olo)
+    assert torch.equal(st2[: C // 256, :J_main], st_main[: C // 256, :J_main]) and torch.equal(ss2[: C // 32, : jr - J_main], st_strip[: C // 32, : jr - J_main])
+    _lib.check_status()
+
+
+def test_range_guard_of_the_folded_epilogues():
+    """|8 x| beyond f16 and NaN must raise the status word from the thin epilogues too (v_maximum3_f32 propagates NaN)."""
+    _lib.status_word(DEV)   # install this GPU's guard-rail word (the package's entry points do it; raw C-ABI calls do not)
+    x, Mtok, Mpad = residual_stream(8, 4, outliers=False)
+    _, (xhi, xlo), st_main, st_strip, _ = raw_planes_stats(x, Mtok)
+    _lib.take_status()
+    I = C
+    W = (torch.randn(I, C, device=DEV) / 32.0).contiguous()
+    gamma, beta = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    for bad in (1e4, float("nan")):
+        b = torch.zeros(I, device=DEV)
+        b[17] = bad
+        whi, wlo, s, bp = fold_operands(W, b, gamma, beta)
+        gemm_ln(whi, wlo, xhi, xlo, I, Mpad, Mtok, C, 8, bp, s, st_main, st_strip)
+        assert _lib.take_status() & 4, f"a bias of {bad} did not trip the range guard"
+
+
+@pytest.mark.parametrize("B", [64, 16])
+def test_vit_large_folded_equals_unfolded_features(B):
+    """The whole ViT-L forward: LayerNorm folded (GIGAPOSE_LN_FOLD=1) vs LayerNorm as its own launches (the default) -- same features
+    to f32 round-off, deterministic, x_prenorm handed back in the same layout."""
+    from gigapose_amd import factory
+
+    model = factory.build_model("dinov2_vitl14", k=5, device=DEV, seed=0, numerics="split")
+    vit = model.ae_net.dinov2_model
+    vit.ln_fold = 1          # pack the folded operands (GIGAPOSE_LN_FOLD=1; off by default: measured 1 % slower, csrc/gp_vit.hip)
+    vit.invalidate()
+    q = factory.TemplateSet(1, 8, seed=100).crops(9, B, DEV)
+    lib = _lib.lib()
+    try:
+        vit.patch_features(q["tar_img"][:1])   # packs, and sets the library switch from vit.ln_fold
+        lib.gp_vit_set_ln_fold(1)
+        f1 = vit.patch_features(q["tar_img"]).clone()
+        f1b = vit.patch_features(q["tar_img"]).clone()
+        xp1 = vit.forward_features(q["tar_img"])["x_prenorm"].clone()
+        lib.gp_vit_set_ln_fold(0)
+        f0 = vit.patch_features(q["tar_img"]).clone()
+        xp0 = vit.forward_features(q["tar_img"])["x_prenorm"].clone()
+    finally:
+        lib.gp_vit_set_ln_fold(0)
+    torch.cuda.synchronize()
+    _lib.check_status()
+    assert torch.equal(f1, f1b), "the folded path is not deterministic"
+    d = float((f1 - f0).abs().max())
+    dx = float((xp1 - xp0).abs().max() / xp0.abs().max())
+    print(f"ViT-L, {B} crops: folded vs unfolded LayerNorm: unit-norm features max |diff| {d:.2e}, x_prenorm max rel {dx:.2e}")
+    assert d < 1e-6 and dx < 5e-6
+    assert not torch.equal(f1, f0), "the A/B hook did not switch the path"

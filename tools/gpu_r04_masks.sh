@@ -8,5 +8,5 @@ for m in ${MASKS:-1 9 17 33 off}; do
   if [ $m = off ]; then envs="GIGAPOSE_LN_FOLD=0"; else envs="GIGAPOSE_LN_FOLD=1 GIGAPOSE_PLANES_DP=$m"; fi
   echo "== mask $m ($envs)"
   (cd /tmp && env $envs rocprofv3 --kernel-trace -d $out -o run -- python $root/tools/probe_vit_loop.py 64 6 2>/dev/null | tail -1)
-  python tools/rocpd_stats.py $(find $out -name "*.db" | head -1) 7 | cut -c36-140
+  python tools/rocprof_summary.py $(find $out -name "*.db" | head -1) 7 | cut -c1-150
 done

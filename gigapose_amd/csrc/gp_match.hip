@@ -84,33 +84,56 @@ __device__ __forceinline__ void rowmax_exchange(float (&rv)[32], int (&ri)[32], 
 // matching.py:234-235), and an all-zero row's argmax is index 0 -- so the maxima over the live patches, compared in the
 // (value desc, patch index asc) order and reset to index 0 when the maximum is 0, are the reference's, bit for bit.
 constexpr int kDeadPatch = 0x7fff;
+#include "gp_match_rects.h"
+// The rectangle of 32 x 32 similarity blocks a wave holds in its accumulators: row blocks r0 .. r0 + mi_n - 1 (LDS rows 32 r0 ..), column
+// blocks c0 .. c0 + ni_n - 1, and the slots its partial row / column maxima go to (rectangles sharing a row block have different row
+// slots, rectangles sharing a column block different column slots).  The plain grid (f32-chain kernel, uncompacted tiles): 4 x 2 waves
+// of 2 x 4 blocks, row slot = wave column, column slot = wave row.
+struct MatchWaveTile {
+    int r0, mi_n, c0, ni_n, rslot, cslot, active;
+};
+__device__ __forceinline__ MatchWaveTile match_wave_tile_grid(int wave)
+{
+    return MatchWaveTile{2 * (wave >> 1), 2, 4 * (wave & 1), 4, wave & 1, wave >> 1, 1};
+}
+__device__ __forceinline__ MatchWaveTile match_wave_tile_unpack(unsigned w)
+{
+    return MatchWaveTile{(int)(w & 15u), (int)((w >> 4) & 3u), (int)((w >> 6) & 15u), (int)((w >> 10) & 7u), (int)((w >> 13) & 3u), (int)((w >> 15) & 3u),
+                         (int)((w >> 17) & 1u)};
+}
 template <bool PERM = false, class SM>
 __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int b, int n, int N, float thr, float patch_thr,
                                                uint8_t* __restrict__ idx_t2s, float* __restrict__ score_t2s,
                                                float* __restrict__ mask_all, float* __restrict__ sim_avg,
                                                unsigned long long* trace = nullptr,  // probe build only: 8 stamps per tile
                                                int src2tar = 0,   // search_direction == "src2tar" (matching.py:242-244)
-                                               int compact = 1)   // PERM: the tile holds the live patches only (see below)
+                                               int compact = 1,   // PERM: the tile holds the live patches only (see below)
+                                               MatchWaveTile wt = MatchWaveTile{0, 0, 0, 0, 0, 0, 0})  // PERM: this wave's rectangle
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    if constexpr (!PERM) wt = match_wave_tile_grid(wave);
     // ---- sim *= src_mask; sim *= tar_mask; sim[sim < thr] = 0   (matching.py:234-236)
-    const int s_lane = 128 * wc + (lane & 31);
-    const int t_lane = 64 * wr + 4 * (lane >> 5);
+    const int s_lane = 32 * wt.c0 + (lane & 31);
+    const int t_lane = 32 * wt.r0 + 4 * (lane >> 5);
     float sm_s[4];
     int s_idx[4];  // patch index of this lane's column in block ni
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-        if constexpr (PERM) {
-            sm_s[ni] = sm.smask_p[s_lane + 32 * ni];
-            s_idx[ni] = sm.s_of[s_lane + 32 * ni];
-        } else {
-            sm_s[ni] = sm.smask[s_lane + 32 * ni];
-            s_idx[ni] = s_lane + 32 * ni;
+        sm_s[ni] = 0.f;
+        s_idx[ni] = kDeadPatch;
+        if (!PERM || ni < wt.ni_n) {  // (wave-uniform) blocks beyond the rectangle hold nothing: their accumulators stay zero and are not read
+            if constexpr (PERM) {
+                sm_s[ni] = sm.smask_p[s_lane + 32 * ni];
+                s_idx[ni] = sm.s_of[s_lane + 32 * ni];
+            } else {
+                sm_s[ni] = sm.smask[s_lane + 32 * ni];
+                s_idx[ni] = s_lane + 32 * ni;
+            }
         }
     }
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 2; ++mi) {
+        if (PERM && mi >= wt.mi_n) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float tm;
@@ -123,6 +146,7 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
                 acc[mi][ni][r] = (v < thr) ? 0.f : v;
             }
         }
+    }
 
     // ---- row maxima (over s, first max wins)   torch.max(sim, dim=3)  (matching.py:240)
     // (value desc, index asc) is a total order, so any reduction tree gives the same winner.  Each lane first folds its
@@ -140,6 +164,7 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
 #pragma unroll
             for (int ni = 1; ni < 4; ++ni) {
                 const float x = acc[mi][ni][r];
+                // (a column block beyond the rectangle: x = 0 and s_idx = kDeadPatch, the largest index -- it never displaces a candidate)
                 const bool take = PERM ? ((x > bv) | ((x == bv) & (s_idx[ni] < bi))) : (x > bv);  // unpermuted: ni ascending == s ascending
                 bv = take ? x : bv;
                 bi = take ? s_idx[ni] : bi;
@@ -155,20 +180,23 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
     {
         const int j = lane & 31;  // the row this lane ended up with: mi = j >> 4, r = j & 15
         int t = t_lane + 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2);
-        if constexpr (PERM) t = sm.t_of[t];
-        if (!PERM || t != kDeadPatch) {  // rows without a live patch keep the zeros the prologue wrote
-            sm.rowv[wc][t] = rv[0];
-            sm.rowi[wc][t] = ri[0];
+        const bool mine = !PERM || (wt.active && (j >> 4) < wt.mi_n);  // a row block of this wave's rectangle
+        if constexpr (PERM) t = mine ? sm.t_of[t] : kDeadPatch;
+        if (mine && (!PERM || t != kDeadPatch)) {  // rows without a live patch keep the zeros the prologue wrote
+            sm.rowv[wt.rslot][t] = rv[0];
+            sm.rowi[wt.rslot][t] = ri[0];
         }
     }
 
     // ---- column maxima (over t, first max wins)   torch.max(sim, dim=2)  (matching.py:241)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
+        if (PERM && (ni >= wt.ni_n || !wt.active)) continue;  // wave-uniform
         float bv = acc[0][ni][0];
         int bi = t_lane;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi) {
+            if (PERM && mi >= wt.mi_n) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {  // (mi, r) ascending == t ascending for this lane (unpermuted tile)
                 const float x = acc[mi][ni][r];
@@ -179,13 +207,14 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
                     if (x > bv) { bv = x; bi = row; }
                 }
             }
+        }
         if constexpr (PERM) bi = sm.t_of[bi];
         const float ov = __shfl_xor(bv, 32);
         const int oi = __shfl_xor(bi, 32);
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         if (lane < 32 && (!PERM || s_idx[ni] != kDeadPatch)) {
-            sm.colv[wr][s_idx[ni]] = bv;
-            sm.coli[wr][s_idx[ni]] = bi;
+            sm.colv[wt.cslot][s_idx[ni]] = bv;
+            sm.coli[wt.cslot][s_idx[ni]] = bi;
         }
     }
     __syncthreads();
@@ -195,9 +224,14 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
     if (tid < GP_P) {
         float bv = sm.rowv[0][tid];
         int bi = sm.rowi[0][tid];
-        const float v1 = sm.rowv[1][tid];
-        const int i1 = sm.rowi[1][tid];
-        if (v1 > bv || (PERM && v1 == bv && i1 < bi)) { bv = v1; bi = i1; }
+#pragma unroll
+        // compacted tile: up to four rectangles hold pieces of a row; slots never written keep the prologue's zeros, harmless next to
+        // values that are all >= 0.  Uncompacted (the plain grid, possibly negative values): exactly two, both written.
+        for (int w = 1; w < ((PERM && compact) ? 4 : 2); ++w) {
+            const float v1 = sm.rowv[w][tid];
+            const int i1 = sm.rowi[w][tid];
+            if (v1 > bv || (PERM && v1 == bv && i1 < bi)) { bv = v1; bi = i1; }
+        }
         // compacted tile (needs sim_threshold >= 0: every surviving value is >= 0): a maximum of 0 means an all-zero row, whose first
         // index is 0 -- the masked-out patches' zeros are part of the reference's row but not of this tile.  Uncompacted (every
         // patch in the tile, e.g. a negative threshold): the zeros ARE in the tile and the (value, patch index) order already
@@ -344,8 +378,8 @@ struct alignas(16) MatchSplitSmem {
     short t_of[GP_P];     // LDS row -> query patch (kDeadPatch: none)
     short s_of[GP_P];     // LDS row of the B planes -> template patch
     int cnt[8];           // live patches per 64-patch slice: [0..3] query, [4..7] template
-    float rowv[2][GP_P];
-    int rowi[2][GP_P];
+    float rowv[4][GP_P];  // partial row maxima by slot (MatchWaveTile::rslot)
+    int rowi[4][GP_P];
     float colv[4][GP_P];
     int coli[4][GP_P];
     float sc_t2s[GP_P];
@@ -381,7 +415,7 @@ struct MatchSplitRsrc {
 
 template <bool BANK_LO, int MI, int NI>
 __device__ __forceinline__ void match_split_kloop(MatchSplitSmem& sm, f32x16 (&acc)[2][4], const MatchSplitRsrc& rs, int ns, int tid,
-                                                  int lane, int wr, int wc, int grp)
+                                                  int lane, int r0, int c0, int grp)  // r0 / c0: first row / column block of the wave's rectangle
 {
     constexpr int P_AHI = 0, P_ALO = MS_PLANE, P_BHI = 2 * MS_PLANE, P_BLO = 3 * MS_PLANE, MS_BUF = 4 * MS_PLANE;
     const int wofs = (tid >> 2) * MS_BK + (((tid & 3) ^ (((tid >> 2) >> 2) & 3)) << 3);
@@ -412,8 +446,8 @@ __device__ __forceinline__ void match_split_kloop(MatchSplitSmem& sm, f32x16 (&a
             *reinterpret_cast<mu32x4*>(L + P_BLO + 128 * MS_BK) = rg[7];
         }
     };
-    // fragment addressing (rows of the wave tile 64 x 128, XOR-swizzled 16-byte chunks)
-    const int ar_ = 64 * wr + (lane & 31), br_ = 128 * wc + (lane & 31), kh_ = lane >> 5;
+    // fragment addressing (rows of the wave's rectangle, XOR-swizzled 16-byte chunks)
+    const int ar_ = 32 * r0 + (lane & 31), br_ = 32 * c0 + (lane & 31), kh_ = lane >> 5;
     const int arow = ar_ * MS_BK, brow = br_ * MS_BK;
     const int ak0 = ((kh_ ^ ((ar_ >> 2) & 3)) << 3), ak1 = (((kh_ + 2) ^ ((ar_ >> 2) & 3)) << 3);
     const int bk0 = ((kh_ ^ ((br_ >> 2) & 3)) << 3), bk1 = (((kh_ + 2) ^ ((br_ >> 2) & 3)) << 3);
@@ -502,7 +536,7 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     const int b = band * 8 + r8 % gsz, n = r8 / gsz;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1, grp = wave >> 2;
+    const int grp = wave >> 2;
     int lab = labels[b];
     if ((unsigned)lab >= (unsigned)O) {
         if (tid == 0) gp_raise(status, GP_ST_LABEL_RANGE);
@@ -521,8 +555,8 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
         sm.qmask[pidx] = mv;
         sm.qmask_p[pidx] = 0.f;
         sm.t_of[pidx] = (short)kDeadPatch;
-        sm.rowv[0][pidx] = 0.f; sm.rowv[1][pidx] = 0.f;
-        sm.rowi[0][pidx] = 0; sm.rowi[1][pidx] = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { sm.rowv[w][pidx] = 0.f; sm.rowi[w][pidx] = 0; }
     } else {
         sm.smask[pidx] = mv;
         sm.smask_p[pidx] = 0.f;
@@ -534,20 +568,25 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     int rank = before;
     for (int w = 4 * grp; w < wave; ++w) rank += sm.cnt[w];
     if (live) {
-        const int blk = rank >> 5, within = rank & 31;
-        if (tid < GP_P) {   // row blocks dealt to the wave rows: block rb -> (wr = rb % 4, mi = rb / 4)
-            const int R = 64 * (blk & 3) + 32 * (blk >> 2) + within;
-            sm.t_of[R] = (short)pidx;
-            sm.qmask_p[R] = mv;
-        } else {            // column blocks dealt to the wave columns: block cb -> (wc = cb % 2, ni = cb / 2)
-            const int R = 128 * (blk & 1) + 32 * (blk >> 1) + within;
-            sm.s_of[R] = (short)pidx;
-            sm.smask_p[R] = mv;
+        // live patch number `rank` -> LDS row `rank`: block rank >> 5 of the compacted tile (which wave multiplies which blocks is the
+        // table's business, gp_match_rects.h)
+        if (tid < GP_P) {
+            sm.t_of[rank] = (short)pidx;
+            sm.qmask_p[rank] = mv;
+        } else {
+            sm.s_of[rank] = (short)pidx;
+            sm.smask_p[rank] = mv;
         }
     }
     __syncthreads();
     const int live_t = sm.cnt[0] + sm.cnt[1] + sm.cnt[2] + sm.cnt[3], live_s = sm.cnt[4] + sm.cnt[5] + sm.cnt[6] + sm.cnt[7];
-    const int MIr = (((live_t + 31) >> 5) + 3) >> 2, NIr = (((live_s + 31) >> 5) + 1) >> 1;  // matrix tiles per wave: 0..2 x 0..4
+    // Which 32 x 32 blocks this wave multiplies (round 4).  Round 3 dealt the live row blocks to the four wave rows and the live column
+    // blocks to the two wave columns: 5 x 5 live blocks (the benchmark's disc masks) cost every wave 2 x 3 = 6 blocks, 48 for 25.  Now
+    // the nrb x ncb live blocks are cut into at most eight RECTANGLES (1-2 row blocks x 1-4 column blocks, one per wave), chosen so
+    // that the two waves of a SIMD together hold as few blocks as possible: 7 instead of 12 at 5 x 5.  Each dot product is the same
+    // instruction sequence wherever it is computed: outputs stay bit-identical.
+    const int nrb = (live_t + 31) >> 5, ncb = (live_s + 31) >> 5;
+    const MatchWaveTile wt = match_wave_tile_unpack(kMatchRect[nrb][ncb][wave]);
 
     // staging: thread = (row tid >> 2 [+128], 16-byte k-chunk tid & 3) of each plane; one descriptor per plane of THIS tile
     const unsigned plane_bytes = (unsigned)GP_P * (unsigned)C * 2u;
@@ -575,13 +614,14 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     const int ns = C / MS_BK;
     if (TRACE && tid == 0) trace[1] = wall_clock64();
-    if (MIr > 0 && NIr > 0) {  // uniform over the workgroup
-        const int sel = MIr * 8 + NIr;
-#define M_CASE(MI_, NI_) case MI_ * 8 + NI_: match_split_kloop<BANK_LO, MI_, NI_>(sm, acc, rs, ns, tid, lane, wr, wc, grp); break
+    if (nrb > 0 && ncb > 0) {  // uniform over the workgroup; inside, every wave runs the instantiation of ITS rectangle (a scalar branch:
+        // the barriers of the k loop count waves, not code addresses -- all instantiations execute the same number per step)
+        const int sel = wt.mi_n * 8 + wt.ni_n;
+#define M_CASE(MI_, NI_) case MI_ * 8 + NI_: match_split_kloop<BANK_LO, MI_, NI_>(sm, acc, rs, ns, tid, lane, wt.r0, wt.c0, grp); break
         switch (sel) {
             M_CASE(1, 1); M_CASE(1, 2); M_CASE(1, 3); M_CASE(1, 4);
             M_CASE(2, 1); M_CASE(2, 2); M_CASE(2, 3);
-            default: match_split_kloop<BANK_LO, 2, 4>(sm, acc, rs, ns, tid, lane, wr, wc, grp); break;
+            default: match_split_kloop<BANK_LO, 2, 4>(sm, acc, rs, ns, tid, lane, wt.r0, wt.c0, grp); break;
         }
 #undef M_CASE
     }
@@ -595,7 +635,7 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= inv;
-    match_epilogue<true>(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg, trace, src2tar, compact);
+    match_epilogue<true>(sm, acc, b, n, N, thr, patch_thr, idx_t2s, score_t2s, mask_all, sim_avg, trace, src2tar, compact, wt);
 }
 
 // norms of gp_l2norm_cp (same sequential fma over c), then x / d * 32 split into f16 planes [row][patch][C].

@@ -219,3 +219,49 @@ def test_vit_large_width_every_batch_size_split_vs_chain():
         worst = max(worst, d)
         assert torch.isfinite(f).all() and d < 2e-6, f"B={B}: split vs chain {d:.2e}"
     print(f"ViT-L width, B = 1 .. 65: max |split - chain| over unit-norm features {worst:.2e}")
+
+
+@pytest.mark.parametrize("numerics", ["split", "chain"])
+def test_vit_large_with_peaked_attention_vs_float64(numerics):
+    """A random-init ViT's softmax is nearly uniform (logit std 0.4), so the ViT-level comparisons above cannot see attention errors
+    (missing 5).  Here the HF stand-in's query / key weights are scaled x 3 -- logit std ~ 3.7, most of a row's mass on a
+    few keys, as in a trained DINOv2 -- and the whole ViT-L forward at 64 crops (split: the plane path with attention_split_kernel;
+    chain: the f32 kernels) is compared with the SAME network evaluated in float64 (torch on the GPU), next to torch's own f32 forward."""
+    from gigapose_amd.vit import Dinov2ViT
+
+    B = 64 if numerics == "split" else 8
+    hf = hf_model(1024, 24, 16, seed=90)
+    with torch.no_grad():
+        for layer in hf.encoder.layer:
+            layer.attention.attention.query.weight.mul_(3.0)
+            layer.attention.attention.key.weight.mul_(3.0)
+    vit = Dinov2ViT.from_hf(hf).to(DEV)
+    vit.set_numerics(numerics)
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(91)).to(DEV)
+    mine = vit.patch_features(x).double()
+    hf = hf.to(DEV)
+    try:
+        hf.config._attn_implementation = "eager"
+    except Exception:
+        pass
+    with torch.no_grad():
+        r32 = hf(pixel_values=x, output_hidden_states=True).hidden_states[-1]
+        hf64 = hf.double()
+        out = hf64(pixel_values=x.double(), output_hidden_states=True, output_attentions=True)
+        r64 = out.hidden_states[-1]
+        att = out.attentions[12] if out.attentions is not None else None
+
+    def unit(h):
+        return torch.nn.functional.normalize(h[:, 1:].permute(0, 2, 1), dim=1).reshape(B, 1024, 16, 16)
+
+    f64, f32 = unit(r64), unit(r32.double())
+    e_m, e_r = (mine - f64).abs(), (f32 - f64).abs()
+    rms = lambda e: float((e ** 2).mean().sqrt())
+    ent = float(-(att * att.clamp_min(1e-300).log()).sum(-1).mean()) if att is not None else float("nan")
+    top = float(att.max(-1).values.mean()) if att is not None else float("nan")
+    print(f"ViT-L [{numerics}], {B} crops, query / key weights x 3 (layer-12 attention: mean entropy {ent:.2f} of {np.log(257):.2f}, mean top weight {top:.3f}): "
+          f"unit-norm features vs float64 (rms {rms(f64):.3e}): ours max {float(e_m.max()):.2e} rms {rms(e_m):.2e} | torch f32 (GPU) max {float(e_r.max()):.2e} rms {rms(e_r):.2e}")
+    from gigapose_amd import _lib
+    _lib.check_status()
+    assert ent != ent or ent < 4.5, "the attention is not peaked: the test would not see attention errors"
+    assert rms(e_m) < 2.0 * rms(e_r) + 1e-8 and float(e_m.max()) < 4e-6

@@ -37,7 +37,7 @@ def build(verbose=False):
     """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
     import subprocess
 
-    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], capture_output=True, text=True)
+    r = subprocess.run(["make", "-j8", "-C", os.path.join(_HERE, "csrc")], capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout, r.stderr)
     if r.returncode != 0:

@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL so both use one HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgigapose_hip.so")
+LIB_PATH = os.environ.get("GIGAPOSE_LIB") or os.path.join(_HERE, "libgigapose_hip.so")   # GIGAPOSE_LIB: a probe build of the same sources (tools/)
 _lib = None
 
 

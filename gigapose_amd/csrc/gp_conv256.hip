@@ -31,6 +31,40 @@ typedef unsigned int cu32x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr float kActScale = 8.0f, kOutScale = 1.0f / (8.0f * 64.0f);
+
+// Thin plane arithmetic of the tile epilogues (round 4, as gp_split256.hip's): the same bits with fewer vector instructions.
+//   cv_sum_planes: (float)h + (float)l of a residual's two planes -- exact in f32 -- as ONE v_fma_mix_f32 reading both f16 halves in place;
+//   cv_hi_pair / cv_lo_pair: a pair's hi plane by v_cvt_pk_f16_f32, its lo plane f16(v - hi) by v_fma_mixlo / mixhi_f16 (v - hi is exact);
+//   cv_absmax: v_maximum3_f32 over |v| (propagates NaN) as the range guard.
+template <int HALF>
+__device__ __forceinline__ float cv_sum_planes(unsigned h, unsigned l)
+{
+    float r;
+    if (HALF == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(l));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(l));
+    return r;
+}
+__device__ __forceinline__ unsigned cv_hi_pair(float v0, float v1)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 h;
+    h[0] = (_Float16)v0;
+    h[1] = (_Float16)v1;
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ unsigned cv_lo_pair(float v0, float v1, unsigned hi)
+{
+    unsigned lo;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(lo)
+        : "v"(v0), "v"(v1), "v"(hi));
+    return lo;
+}
+__device__ __forceinline__ float cv_absmax(float m, float v0, float v1)
+{
+    return __builtin_elementwise_maximum(m, __builtin_elementwise_maximum(__builtin_fabsf(v0), __builtin_fabsf(v1)));
+}
 constexpr int CT = 256, CBK = 32, CNT = 512;
 constexpr int CROW = 32, CPLANE = CT * CROW;  // halfs
 constexpr int CBUF = 4 * CPLANE;              // A hi, A lo, B hi, B lo (B uses 64 NI of its 256 rows)
@@ -304,7 +338,7 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
             const int ln = tid_ & 63, l31 = ln & 31;
             float* wl = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + (tid_ >> 6) * 16384);
             constexpr int WC = 32 * NIW, QPR = 8 * NIW;  // f32 columns / 4-column quads per row of the wave tile
-            int bad = 0;
+            float mx = 0.f;  // range guard: largest |8 x| written (v_maximum3_f32 propagates NaN)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -342,12 +376,11 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
                                 for (int e = 0; e < 4; ++e) v[e] = v[e] * al4[e] + be4[e];
                             }
                             const size_t o = (size_t)pix * a.Cout + co;
-                            if (a.rhi) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const c16x4 h4 = __builtin_bit_cast(c16x4, rh[u]), l4 = __builtin_bit_cast(c16x4, rl[u]);
-                                    v[e] = ((float)h4[e] + (float)l4[e]) * (1.0f / kActScale) + v[e];
-                                }
+                            if (a.rhi) {  // + residual: (h + l) / 8, exact, then ONE rounding -- the bits of ((float)h + (float)l) * (1 / 8) + v
+                                v[0] = __builtin_fmaf(cv_sum_planes<0>(rh[u][0], rl[u][0]), 1.0f / kActScale, v[0]);
+                                v[1] = __builtin_fmaf(cv_sum_planes<1>(rh[u][0], rl[u][0]), 1.0f / kActScale, v[1]);
+                                v[2] = __builtin_fmaf(cv_sum_planes<0>(rh[u][1], rl[u][1]), 1.0f / kActScale, v[2]);
+                                v[3] = __builtin_fmaf(cv_sum_planes<1>(rh[u][1], rl[u][1]), 1.0f / kActScale, v[3]);
                             }
                             if (a.relu)
 #pragma unroll
@@ -357,23 +390,21 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) a.of32[((size_t)b * a.Cout + co + e) * OHW + rem] = v[e];
                             } else {
-                                c16x4 oh, ol;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const float s8 = v[e] * kActScale;
-                                    const _Float16 hh = (_Float16)s8;
-                                    oh[e] = hh;
-                                    ol[e] = (_Float16)(s8 - (float)hh);
-                                    bad |= !(fabsf(s8) <= kSplitPlaneLimit);
-                                }
-                                *reinterpret_cast<c16x4*>(a.ohi + o) = oh;
-                                *reinterpret_cast<c16x4*>(a.olo + o) = ol;
+                                const float s0 = v[0] * kActScale, s1 = v[1] * kActScale, s2 = v[2] * kActScale, s3 = v[3] * kActScale;
+                                cu32x2 oh, ol;
+                                oh[0] = cv_hi_pair(s0, s1);
+                                oh[1] = cv_hi_pair(s2, s3);
+                                ol[0] = cv_lo_pair(s0, s1, oh[0]);
+                                ol[1] = cv_lo_pair(s2, s3, oh[1]);
+                                mx = cv_absmax(cv_absmax(mx, s0, s1), s2, s3);
+                                *reinterpret_cast<cu32x2*>(a.ohi + o) = oh;
+                                *reinterpret_cast<cu32x2*>(a.olo + o) = ol;
                             }
                         }
                     }
                 }
             }
-            if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE_CONV);
+            if (!(mx <= kSplitPlaneLimit)) gp_raise(a.status, GP_ST_SPLIT_RANGE_CONV);  // !(<=): NaN counts
             __syncthreads();  // LDS buffer 0 is re-staged by the next segment's prologue
         }
         if (a.trace) { const unsigned long long t = wall_clock64(); tr_tail += t - tr_t0; tr_t0 = t; }
@@ -730,7 +761,7 @@ __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
             const int ln = tid_ & 63, l31 = ln & 31;
             float* wl = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + (tid_ >> 6) * EPI_STRIDE);
             constexpr int WC = 32 * NIW, QPR = 8 * NIW;
-            int bad = 0;
+            float mx = 0.f;  // range guard: largest |8 x| written (v_maximum3_f32 propagates NaN)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -766,12 +797,11 @@ __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
                                 for (int e = 0; e < 4; ++e) v[e] = v[e] * al4[e] + be4[e];
                             }
                             const size_t o = (size_t)pix * a.Cout + co;
-                            if (a.rhi) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const c16x4 h4 = __builtin_bit_cast(c16x4, rh[u]), l4 = __builtin_bit_cast(c16x4, rl[u]);
-                                    v[e] = ((float)h4[e] + (float)l4[e]) * (1.0f / kActScale) + v[e];
-                                }
+                            if (a.rhi) {  // + residual: (h + l) / 8, exact, then ONE rounding -- the bits of ((float)h + (float)l) * (1 / 8) + v
+                                v[0] = __builtin_fmaf(cv_sum_planes<0>(rh[u][0], rl[u][0]), 1.0f / kActScale, v[0]);
+                                v[1] = __builtin_fmaf(cv_sum_planes<1>(rh[u][0], rl[u][0]), 1.0f / kActScale, v[1]);
+                                v[2] = __builtin_fmaf(cv_sum_planes<0>(rh[u][1], rl[u][1]), 1.0f / kActScale, v[2]);
+                                v[3] = __builtin_fmaf(cv_sum_planes<1>(rh[u][1], rl[u][1]), 1.0f / kActScale, v[3]);
                             }
                             if (a.relu)
 #pragma unroll
@@ -781,23 +811,21 @@ __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) a.of32[((size_t)bb * a.Cout + co + e) * OHW + rem] = v[e];
                             } else {
-                                c16x4 oh, ol;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const float s8 = v[e] * kActScale;
-                                    const _Float16 hh = (_Float16)s8;
-                                    oh[e] = hh;
-                                    ol[e] = (_Float16)(s8 - (float)hh);
-                                    bad |= !(fabsf(s8) <= kSplitPlaneLimit);
-                                }
-                                *reinterpret_cast<c16x4*>(a.ohi + o) = oh;
-                                *reinterpret_cast<c16x4*>(a.olo + o) = ol;
+                                const float s0 = v[0] * kActScale, s1 = v[1] * kActScale, s2 = v[2] * kActScale, s3 = v[3] * kActScale;
+                                cu32x2 oh, ol;
+                                oh[0] = cv_hi_pair(s0, s1);
+                                oh[1] = cv_hi_pair(s2, s3);
+                                ol[0] = cv_lo_pair(s0, s1, oh[0]);
+                                ol[1] = cv_lo_pair(s2, s3, oh[1]);
+                                mx = cv_absmax(cv_absmax(mx, s0, s1), s2, s3);
+                                *reinterpret_cast<cu32x2*>(a.ohi + o) = oh;
+                                *reinterpret_cast<cu32x2*>(a.olo + o) = ol;
                             }
                         }
                     }
                 }
             }
-            if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE_CONV);
+            if (!(mx <= kSplitPlaneLimit)) gp_raise(a.status, GP_ST_SPLIT_RANGE_CONV);  // !(<=): NaN counts
             __syncthreads();  // the operand buffers are re-staged by the next segment's prologue
         }
         if (a.trace) { const unsigned long long t_ = wall_clock64(); tr_tail += t_ - tr_t0; tr_t0 = t_; }

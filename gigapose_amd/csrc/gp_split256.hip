@@ -466,57 +466,6 @@ __device__ __forceinline__ void epilogue_f32_lds(const ArgsP& a, f32x16 (&acc)[2
     }
 }
 
-// planes O[j][i] (x 8, hi + lo): round h = columns 64 h .. 64 h + 63 of the wave tile, all 64 rows: per plane 64 token
-// rows of 128 bytes, the 8-byte pieces a lane produces XOR-placed by the token (2-way on the writes, the 16-byte reads
-// conflict-free), then 16 bytes per lane: 8 lanes cover the 128 contiguous bytes a token row gets from this wave.
-template <int EPI>
-__device__ __forceinline__ void epilogue_planes_lds(const ArgsP& a, f32x16 (&acc)[2][4], char* __restrict__ wl, int i_base, int j_base, int ln)
-{
-    const int l31 = ln & 31, half = ln >> 5;
-    const float bias_l = a.bias[i_base + ln];
-    int bad = 0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn) {
-            const int ni = 2 * h + nn, jl = 32 * nn + l31;
-            char* wrow = wl + jl * 128;
-            const int sw = (jl & 7) << 1;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    g16x4 oh, ol;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float b0 = lane_bcast(bias_l, 32 * mi + 8 * r4 + e), b1 = lane_bcast(bias_l, 32 * mi + 8 * r4 + 4 + e);
-                        const float x = acc[mi][ni][4 * r4 + e] * a.out_scale + (half ? b1 : b0);
-                        const float v = (EPI == PEPI_GELU_PLANES ? gelu_x(x) : x) * kActScale;
-                        const _Float16 hh = (_Float16)v;
-                        oh[e] = hh;
-                        ol[e] = (_Float16)(v - (float)hh);
-                        bad |= !(fabsf(v) <= kSplitPlaneLimit);  // !(<=): NaN counts
-                    }
-                    const int c8 = 8 * mi + 2 * r4 + half;  // 8-byte piece of the 128-byte row: rows 4 c8 .. 4 c8 + 3
-                    *reinterpret_cast<g16x4*>(wrow + ((c8 ^ sw) << 3)) = oh;
-                    *reinterpret_cast<g16x4*>(wrow + 8192 + ((c8 ^ sw) << 3)) = ol;
-                }
-        }
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            _Float16* O = pl ? a.olo : a.ohi;
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int jl = 8 * it + (ln >> 3), c16 = ln & 7;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(wl + pl * 8192 + jl * 128 + ((c16 ^ (jl & 7)) << 4));
-                const size_t o = (size_t)(unsigned)(j_base + 64 * h + jl) * (unsigned)a.ldo + (unsigned)(i_base + 8 * c16);
-                *reinterpret_cast<u32x4*>(O + o) = v;
-            }
-        }
-    }
-    if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE);
-}
-
 // ---- Thin plane arithmetic (round 4).  The round-3 segment probes put the arithmetic half of a plane epilogue at 8.5 vector
 // instructions per element (readlane + select for the bias, multiply, add, x 8, two conversions, a subtraction, a third
 // conversion, a compare) and showed that it adds to the matrix work instead of hiding behind it.  Here: the per-row constants come
@@ -577,8 +526,69 @@ __device__ __forceinline__ float gelu_fast_x8(float x)  // 8 * gelu_fast(x), bit
     return (0.5f * kActScale) * x * (x >= 0.f ? 2.0f - c : c);
 }
 
+// The plane epilogues 6 / 7: planes O[j][i] (x 8, hi + lo) of bias_i + out_scale acc [6: through GELU].  Round h = columns 64 h .. 64 h + 63
+// of the wave tile, all 64 rows: per plane 64 token rows of 128 bytes in the wave's 16 KiB of LDS, the 8-byte pieces a lane produces
+// XOR-placed by the token (2-way on the writes, the 16-byte reads conflict-free), then 16 bytes per lane: 8 lanes cover the 128
+// contiguous bytes a token row gets from this wave.  Thin arithmetic (round 4; 0.27 ms per step over the round-3 form, same bits:
+// profiles/r04_thin_epilogue_ab.txt): bias rows from 16-byte loads of exactly the rows a lane holds (no readlane + select), ONE fma for
+// scale + bias + the planes' x 8 (acc * out_scale is an exact power-of-two scaling, so fma(acc, 8 out_scale, 8 b) rounds where
+// (acc * out_scale + b) * 8 did), the pair conversions above, v_maximum3_f32 as the range guard, buffer stores.
+template <int EPI>
+__device__ __forceinline__ void epilogue_planes_thin(const ArgsP& a, f32x16 (&acc)[2][4], char* __restrict__ wl, int i_base, int j_base, int ln)
+{
+    const int l31 = ln & 31, half = ln >> 5;
+    constexpr bool kGelu = EPI == PEPI_GELU_PLANES;
+    constexpr float k8 = kGelu ? 1.0f : kActScale;
+    const __amdgpu_buffer_rsrc_t r_hi = __builtin_amdgcn_make_buffer_rsrc((void*)a.ohi, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_lo = __builtin_amdgcn_make_buffer_rsrc((void*)a.olo, 0, 0x7ffffff0, 0x00020000);
+    const unsigned v_pl = ((unsigned)(j_base + (ln >> 3)) * (unsigned)a.ldo + (unsigned)(i_base + 8 * (ln & 7))) * 2u;
+    const float A = a.out_scale * k8;
+    float mx = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 bq = *reinterpret_cast<const f32x4*>(a.bias + i_base + 32 * mi + 8 * r4 + 4 * half);
+                if (!kGelu) bq = bq * k8;
+                const int c8 = 8 * mi + 2 * r4 + half;  // 8-byte piece of the 128-byte row: rows 4 c8 .. 4 c8 + 3
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) {
+                    const int ni = 2 * h + nn, jl = 32 * nn + l31;
+                    char* wrow = wl + jl * 128;
+                    const int sw = (jl & 7) << 1;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = __builtin_fmaf(acc[mi][ni][4 * r4 + e], A, bq[e]);
+                        v[e] = kGelu ? gelu_fast_x8(x) : x;
+                    }
+                    u32x2 oh, ol;
+                    oh[0] = pack_hi_pair(v[0], v[1]);
+                    oh[1] = pack_hi_pair(v[2], v[3]);
+                    ol[0] = lo_pair(v[0], v[1], oh[0]);
+                    ol[1] = lo_pair(v[2], v[3], oh[1]);
+                    mx = absmax3(absmax3(mx, v[0], v[1]), v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(wrow + ((c8 ^ sw) << 3)) = oh;
+                    *reinterpret_cast<u32x2*>(wrow + 8192 + ((c8 ^ sw) << 3)) = ol;
+                }
+            }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int jl = 8 * it + (ln >> 3), c16 = ln & 7;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(wl + pl * 8192 + jl * 128 + ((c16 ^ (jl & 7)) << 4));
+                __builtin_amdgcn_raw_buffer_store_b128(v, pl ? r_lo : r_hi, v_pl, (unsigned)(64 * h + 8 * it) * (unsigned)a.ldo * 2u, 0);
+            }
+        }
+    }
+    if (!(mx <= kSplitPlaneLimit)) gp_raise(a.status, GP_ST_SPLIT_RANGE);  // !(<=): NaN counts (v_maximum3 propagates it)
+}
+
 // Consumer of a folded LayerNorm (8 / 9): planes of  r_j (acc - mu_j s_i) + b'_i  [9: through GELU], the LDS turn and the stores of
-// epilogue_planes_lds.  tab: (mu, r) of this wave's 128 tokens (LDS, written by the tile prologue).
+// epilogue_planes_thin.  tab: (mu, r) of this wave's 128 tokens (LDS, written by the tile prologue).
 template <int EPI>
 __device__ __forceinline__ void epilogue_planes_lnf(const ArgsP& a, f32x16 (&acc)[2][4], char* __restrict__ wl, const g32x2* __restrict__ tab,
                                                     const float* __restrict__ rowc, int i_base, int j_base, int ln)
@@ -1366,7 +1376,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
             else if constexpr (EPI == PEPI_RES_PLANES_STATS)
                 epilogue_res_planes(a, acc, reinterpret_cast<float*>(wl), ln_lds + 2 * (TB * wr + 128 * wc), i0 + 64 * wr, j0 + 128 * wc, tid_ & 63);
             else if constexpr (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES)
-                epilogue_planes_lds<EPI>(a, acc, wl, i0 + 64 * wr, j0 + 128 * wc, tid_ & 63);
+                epilogue_planes_thin<EPI>(a, acc, wl, i0 + 64 * wr, j0 + 128 * wc, tid_ & 63);
             else
                 epilogue_f32_lds<EPI>(a, acc, reinterpret_cast<float*>(wl), i0 + 64 * wr, j0 + 128 * wc, tid_ & 63);
             __syncthreads();  // LDS buffer 0 is re-staged by the next segment's prologue

@@ -62,8 +62,24 @@ __global__ __launch_bounds__(256) void ist_gather_kernel(
     const int si = (int)(sy * GP_G + sx);
     const float* tf = tar_feat + (size_t)b * D * GP_P + ti;
     const float* sf = src_bank + (((size_t)lab * N + (size_t)view) * D) * GP_P + si;
-    for (int c = 0; c < D; ++c) X[(size_t)c * R + rc] = tf[(size_t)c * GP_P];
-    for (int c = 0; c < D; ++c) X[(size_t)(D + c) * R + rc] = sf[(size_t)c * GP_P];
+    // sixteen gathers in flight per lane (one load per dependent store left the kernel at the latency of 512 round trips: 186 us for
+    // 67 MB of live rows); D is a multiple of 16 (the launcher requires 2 D % 32 == 0 in split numerics, 2 D % 16 == 0 otherwise)
+    for (int c0 = 0; c0 < D; c0 += 16) {
+        float a[16], bq[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = min(c0 + u, D - 1);
+            a[u] = tf[(size_t)c * GP_P];
+            bq[u] = sf[(size_t)c * GP_P];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (c0 + u < D) {
+                X[(size_t)(c0 + u) * R + rc] = a[u];
+                X[(size_t)(D + c0 + u) * R + rc] = bq[u];
+            }
+        }
+    }
 }
 
 // Final Linear(H -> nout) (+ tanh) and the -1000 fill of invalid rows (ist_net.py:109-119).
@@ -82,10 +98,14 @@ __global__ __launch_bounds__(256) void ist_head_kernel(const float* __restrict__
     for (int o = 0; o < NOUT; ++o) acc[o] = 0.f;
     const int rc = pos[r];  // compact row (-1: no correspondence -> -1000 below; row 0 is read, finite or not, and discarded)
     const size_t rr = rc >= 0 ? (size_t)rc : 0;
-    for (int h = 0; h < H; ++h) {
-        const float x = Hid[(size_t)h * R + rr];
+    for (int h0 = 0; h0 < H; h0 += 16) {  // sixteen loads in flight, then the fmas IN ORDER (the chain is unchanged); H % 128 == 0
+        float x[16];
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) acc[o] = __builtin_fmaf(W3[o * H + h], x, acc[o]);
+        for (int u = 0; u < 16; ++u) x[u] = Hid[(size_t)(h0 + u) * R + rr];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) acc[o] = __builtin_fmaf(W3[o * H + h0 + u], x[u], acc[o]);
     }
     // validity as the reference computes it (ist_net.py:114-115): both coordinates != -1
     const bool sv = (src_pts[2 * r] != -1) && (src_pts[2 * r + 1] != -1);

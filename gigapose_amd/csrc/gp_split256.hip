@@ -401,66 +401,112 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)  // value held by
 // in two rounds, so that every global access is 16 bytes per lane over full 128-byte lines (64 instead of 512
 // instructions per lane for the residual epilogue).  Wave-private: no workgroup barrier between the rounds (LDS
 // operations of one wave execute in order).  Same arithmetic per element as before: results are bit-identical.
-template <int EPI>
-__device__ __forceinline__ void epilogue_f32_lds(const ArgsP& a, f32x16 (&acc)[2][4], float* __restrict__ wl, int i_base, int j_base, int ln)
+template <int EPI, int NJ = 4>
+__device__ __forceinline__ void epilogue_f32_lds(const ArgsP& a, f32x16 (&acc)[2][NJ], float* __restrict__ wl, int i_base, int j_base, int ln)
 {
     const int l31 = ln & 31, half = ln >> 5;
     constexpr bool kBiasI = EPI == XEPI_BIAS_I || EPI == XEPI_BIAS_I_GELU || EPI == XEPI_BIAS_I_SCALE_RES || EPI == XEPI_BIAS_I_RELU;
-    float bias_l = 0.f, scale_l = 0.f;  // lane l holds the value of row i_base + l
-    if (kBiasI) bias_l = a.bias[i_base + ln];
-    if (EPI == XEPI_BIAS_I_SCALE_RES) scale_l = a.scale[i_base + ln];
-    f32x4 bias_j = {0.f, 0.f, 0.f, 0.f};
-    if (EPI == XEPI_BIAS_J) bias_j = *reinterpret_cast<const f32x4*>(a.bias + j_base + 4 * l31);
-    const unsigned j = (unsigned)(j_base + 4 * l31);
+    if constexpr (NJ == 2) {
+        // 256 x 128 tiles (launches far below one tile per slot): the wave tile is 64 x 64, a round is wl[32][64], 16 lanes cover a row
+        // and a wave four rows per item, eight items per round.  The per-row constants are 4-byte loads of the row a lane finishes
+        // (these launches are bound by their latency chain, not by instruction issue).  Per element the arithmetic of the 256-wide form.
+        const int l15 = ln & 15, q4 = ln >> 4;
+        const unsigned j = (unsigned)(j_base + 4 * l15);
+        f32x4 bias_j = {0.f, 0.f, 0.f, 0.f};
+        if (EPI == XEPI_BIAS_J) bias_j = *reinterpret_cast<const f32x4*>(a.bias + j);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        // round mi: rows 32 mi .. 32 mi + 31 of the wave tile as wl[32][128] (writes: a lane group covers 32 consecutive
-        // words of a row; reads: 16 bytes per lane, a wave covers two whole rows -- both conflict-free without padding)
+        for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) wl[frag_row(r, ln) * 128 + 32 * ni + l31] = acc[mi][ni][r];
-        // residual rows of this round in two batches of eight 16-byte loads, all in flight before the first is used: D may be
-        // the residual buffer itself (x += ...), so hipcc keeps every load behind the previous item's store -- one exposed
-        // memory round trip per item, 8-10 us of an 18-22 us tile epilogue (profiles/r02_planes_timeline.txt, proj / fc2).
-        // Safe in place: item `it` reads and writes only its own row piece.
-#pragma unroll
-        for (int it0 = 0; it0 < 16; it0 += 8) {
+                for (int r = 0; r < 16; ++r) wl[frag_row(r, ln) * 64 + 32 * ni + l31] = acc[mi][ni][r];
             f32x4 rs[8];
-            if (EPI == XEPI_BIAS_I_SCALE_RES) {
+            float bs[8], ss[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const unsigned i = (unsigned)(i_base + 32 * mi + 2 * (it0 + u) + half);
-                    rs[u] = *reinterpret_cast<const f32x4*>(a.res + i * (unsigned)a.ldr + j);
-                }
-                asm volatile("" : "+v"(rs[0]), "+v"(rs[1]), "+v"(rs[2]), "+v"(rs[3]), "+v"(rs[4]), "+v"(rs[5]), "+v"(rs[6]), "+v"(rs[7]));
+            for (int u = 0; u < 8; ++u) {  // every load of the round first: D may be the residual buffer itself (see below)
+                const unsigned i = (unsigned)(i_base + 32 * mi + 4 * u + q4);
+                bs[u] = kBiasI ? a.bias[i] : 0.f;
+                ss[u] = EPI == XEPI_BIAS_I_SCALE_RES ? a.scale[i] : 0.f;
+                if (EPI == XEPI_BIAS_I_SCALE_RES) rs[u] = *reinterpret_cast<const f32x4*>(a.res + i * (unsigned)a.ldr + j);
             }
+            if (EPI == XEPI_BIAS_I_SCALE_RES)
+                asm volatile("" : "+v"(rs[0]), "+v"(rs[1]), "+v"(rs[2]), "+v"(rs[3]), "+v"(rs[4]), "+v"(rs[5]), "+v"(rs[6]), "+v"(rs[7]));
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int it = it0 + u, row = 2 * it + half;
-                const f32x4 t = *reinterpret_cast<const f32x4*>(wl + row * 128 + 4 * l31);
+                const int row = 4 * u + q4;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(wl + row * 64 + 4 * l15);
                 const unsigned i = (unsigned)(i_base + 32 * mi + row);
-                float b = 0.f, sc = 0.f;
-                if (kBiasI) {
-                    const float b0 = lane_bcast(bias_l, 32 * mi + 2 * it), b1 = lane_bcast(bias_l, 32 * mi + 2 * it + 1);
-                    b = half ? b1 : b0;
-                }
-                if (EPI == XEPI_BIAS_I_SCALE_RES) {
-                    const float s0 = lane_bcast(scale_l, 32 * mi + 2 * it), s1 = lane_bcast(scale_l, 32 * mi + 2 * it + 1);
-                    sc = half ? s1 : s0;
-                }
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = t[e] * a.out_scale;
-                    if (kBiasI) v = v + b;
+                    if (kBiasI) v = v + bs[u];
                     if (EPI == XEPI_BIAS_J) v = v + bias_j[e];
                     if (EPI == XEPI_BIAS_I_GELU) v = gelu_x(v);
                     if (EPI == XEPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
-                    if (EPI == XEPI_BIAS_I_SCALE_RES) v = rs[u][e] + sc * v;
+                    if (EPI == XEPI_BIAS_I_SCALE_RES) v = rs[u][e] + ss[u] * v;
                     o[e] = v;
                 }
                 *reinterpret_cast<f32x4*>(a.D + i * (unsigned)a.ldd + j) = o;
+            }
+        }
+    } else {
+        float bias_l = 0.f, scale_l = 0.f;  // lane l holds the value of row i_base + l
+        if (kBiasI) bias_l = a.bias[i_base + ln];
+        if (EPI == XEPI_BIAS_I_SCALE_RES) scale_l = a.scale[i_base + ln];
+        f32x4 bias_j = {0.f, 0.f, 0.f, 0.f};
+        if (EPI == XEPI_BIAS_J) bias_j = *reinterpret_cast<const f32x4*>(a.bias + j_base + 4 * l31);
+        const unsigned j = (unsigned)(j_base + 4 * l31);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            // round mi: rows 32 mi .. 32 mi + 31 of the wave tile as wl[32][128] (writes: a lane group covers 32 consecutive
+            // words of a row; reads: 16 bytes per lane, a wave covers two whole rows -- both conflict-free without padding)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) wl[frag_row(r, ln) * 128 + 32 * ni + l31] = acc[mi][ni][r];
+            // residual rows of this round in two batches of eight 16-byte loads, all in flight before the first is used: D may be
+            // the residual buffer itself (x += ...), so hipcc keeps every load behind the previous item's store -- one exposed
+            // memory round trip per item, 8-10 us of an 18-22 us tile epilogue (profiles/r02_planes_timeline.txt, proj / fc2).
+            // Safe in place: item `it` reads and writes only its own row piece.
+#pragma unroll
+            for (int it0 = 0; it0 < 16; it0 += 8) {
+                f32x4 rs[8];
+                if (EPI == XEPI_BIAS_I_SCALE_RES) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned i = (unsigned)(i_base + 32 * mi + 2 * (it0 + u) + half);
+                        rs[u] = *reinterpret_cast<const f32x4*>(a.res + i * (unsigned)a.ldr + j);
+                    }
+                    asm volatile("" : "+v"(rs[0]), "+v"(rs[1]), "+v"(rs[2]), "+v"(rs[3]), "+v"(rs[4]), "+v"(rs[5]), "+v"(rs[6]), "+v"(rs[7]));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int it = it0 + u, row = 2 * it + half;
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(wl + row * 128 + 4 * l31);
+                    const unsigned i = (unsigned)(i_base + 32 * mi + row);
+                    float b = 0.f, sc = 0.f;
+                    if (kBiasI) {
+                        const float b0 = lane_bcast(bias_l, 32 * mi + 2 * it), b1 = lane_bcast(bias_l, 32 * mi + 2 * it + 1);
+                        b = half ? b1 : b0;
+                    }
+                    if (EPI == XEPI_BIAS_I_SCALE_RES) {
+                        const float s0 = lane_bcast(scale_l, 32 * mi + 2 * it), s1 = lane_bcast(scale_l, 32 * mi + 2 * it + 1);
+                        sc = half ? s1 : s0;
+                    }
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = t[e] * a.out_scale;
+                        if (kBiasI) v = v + b;
+                        if (EPI == XEPI_BIAS_J) v = v + bias_j[e];
+                        if (EPI == XEPI_BIAS_I_GELU) v = gelu_x(v);
+                        if (EPI == XEPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
+                        if (EPI == XEPI_BIAS_I_SCALE_RES) v = rs[u][e] + sc * v;
+                        o[e] = v;
+                    }
+                    *reinterpret_cast<f32x4*>(a.D + i * (unsigned)a.ldd + j) = o;
+                }
             }
         }
     }
@@ -533,8 +579,8 @@ __device__ __forceinline__ float gelu_fast_x8(float x)  // 8 * gelu_fast(x), bit
 // profiles/r04_thin_epilogue_ab.txt): bias rows from 16-byte loads of exactly the rows a lane holds (no readlane + select), ONE fma for
 // scale + bias + the planes' x 8 (acc * out_scale is an exact power-of-two scaling, so fma(acc, 8 out_scale, 8 b) rounds where
 // (acc * out_scale + b) * 8 did), the pair conversions above, v_maximum3_f32 as the range guard, buffer stores.
-template <int EPI>
-__device__ __forceinline__ void epilogue_planes_thin(const ArgsP& a, f32x16 (&acc)[2][4], char* __restrict__ wl, int i_base, int j_base, int ln)
+template <int EPI, int NJ = 4>
+__device__ __forceinline__ void epilogue_planes_thin(const ArgsP& a, f32x16 (&acc)[2][NJ], char* __restrict__ wl, int i_base, int j_base, int ln)
 {
     const int l31 = ln & 31, half = ln >> 5;
     constexpr bool kGelu = EPI == PEPI_GELU_PLANES;
@@ -545,7 +591,7 @@ __device__ __forceinline__ void epilogue_planes_thin(const ArgsP& a, f32x16 (&ac
     const float A = a.out_scale * k8;
     float mx = 0.f;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NJ / 2; ++h) {  // NJ = 2 (256 x 128 tiles): one round
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -1067,9 +1113,14 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
     }
 }
 
-template <int EPI, bool TIMING = false, bool PAR = false>
+// NJ: 32-row matrix tiles of B per wave -- 4: the 256 x 256 tile; 2: a 256 x 128 tile (wave tile 64 x 64, half the rows of the B
+// planes staged and half the matrix instructions per k-step) for launches whose 256 x 256 tiles fill at most half the slots: twice
+// the tiles, so half the slots per tile and half-size partial accumulators, or no split at all (round 4; B <= 16 crops at ViT-L).
+template <int EPI, bool TIMING = false, bool PAR = false, int NJ = 4>
 __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
 {
+    static_assert(NJ == 4 || (NJ == 2 && !kEpiLnf<EPI> && EPI != PEPI_RES_PLANES_STATS), "half-width tiles: epilogues 0-7 only");
+    constexpr int TJ = 64 * NJ;  // rows of B (columns j) per tile
     unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     const unsigned long long k_c0 = TIMING ? __builtin_readcyclecounter() : 0, k_w0 = TIMING ? wall_clock64() : 0;
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * TBUF + 2048];  // 128 KiB of operand buffers (+ 4 KiB: the strip's padded rows)
@@ -1118,14 +1169,14 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
     // staging: thread = (row tid >> 2 [+128], 16-byte k-chunk tid & 3) of each of the four planes
     const __amdgpu_buffer_rsrc_t r_ahi = __builtin_amdgcn_make_buffer_rsrc((void*)a.ahi, 0, a.tiles_i * TB * a.K * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_alo = __builtin_amdgcn_make_buffer_rsrc((void*)a.alo, 0, a.tiles_i * TB * a.K * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_bhi = __builtin_amdgcn_make_buffer_rsrc((void*)a.bhi, 0, a.tiles_j * TB * a.K * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_blo = __builtin_amdgcn_make_buffer_rsrc((void*)a.blo, 0, a.tiles_j * TB * a.K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_bhi = __builtin_amdgcn_make_buffer_rsrc((void*)a.bhi, 0, a.tiles_j * TJ * a.K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_blo = __builtin_amdgcn_make_buffer_rsrc((void*)a.blo, 0, a.tiles_j * TJ * a.K * 2, 0x00020000);
     const unsigned voff = (unsigned)(tid >> 2) * (unsigned)a.K * 2u + (unsigned)(tid & 3) * 16u;
     const unsigned half_rows = 128u * (unsigned)a.K * 2u;  // byte distance of row + 128
     const int wofs = toff(tid >> 2, tid & 3);
     u32x4 rg[8];
     // fragment addressing
-    const int ar_ = 64 * wr + (lane & 31), br_ = 128 * wc + (lane & 31), kh_ = lane >> 5;
+    const int ar_ = 64 * wr + (lane & 31), br_ = 32 * NJ * wc + (lane & 31), kh_ = lane >> 5;
     const int arow = ar_ * TROW, brow = br_ * TROW;
     const int ak0 = ((kh_ ^ ((ar_ >> 2) & 3)) << 3), ak1 = (((kh_ + 2) ^ ((ar_ >> 2) & 3)) << 3);
     const int bk0 = ((kh_ ^ ((br_ >> 2) & 3)) << 3), bk1 = (((kh_ + 2) ^ ((br_ >> 2) & 3)) << 3);
@@ -1145,9 +1196,9 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
         const int band = q / per_band, rr = q - band * per_band;
         const int first_i = band * a.group;
         const int gsz = min(a.group, a.tiles_i - first_i);
-        const int i0 = (first_i + rr % gsz) * TB, j0 = (rr / gsz) * TB;
+        const int i0 = (first_i + rr % gsz) * TB, j0 = (rr / gsz) * TJ;
 
-        f32x16 acc[2][4];
+        f32x16 acc[2][NJ];
         if (!PAR && is_rest) {
             if (tid == 0) {
                 int spins = 0;
@@ -1169,10 +1220,10 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < NJ; ++ni)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rf, (unsigned)tid * 16u, (unsigned)(((mi * 4 + ni) * 4 + r4) * TNT) * 16u, 0);
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rf, (unsigned)tid * 16u, (unsigned)(((mi * NJ + ni) * 4 + r4) * TNT) * 16u, 0);
                         const f32x4 vf = __builtin_bit_cast(f32x4, v);  // whole-vector cast (element-wise __builtin_bit_cast of vector lanes miscompiles: every r4 got lane group 0)
                         acc[mi][ni][r4 * 4 + 0] = vf[0]; acc[mi][ni][r4 * 4 + 1] = vf[1];
                         acc[mi][ni][r4 * 4 + 2] = vf[2]; acc[mi][ni][r4 * 4 + 3] = vf[3];
@@ -1181,7 +1232,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < NJ; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         }
@@ -1201,9 +1252,9 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
             rg[2] = __builtin_amdgcn_raw_buffer_load_b128(r_alo, voff, sA, 0);
             rg[3] = __builtin_amdgcn_raw_buffer_load_b128(r_alo, voff, sA + half_rows, 0);
             rg[4] = __builtin_amdgcn_raw_buffer_load_b128(r_bhi, voff, sB, 0);
-            rg[5] = __builtin_amdgcn_raw_buffer_load_b128(r_bhi, voff, sB + half_rows, 0);
+            if (NJ == 4) rg[5] = __builtin_amdgcn_raw_buffer_load_b128(r_bhi, voff, sB + half_rows, 0);
             rg[6] = __builtin_amdgcn_raw_buffer_load_b128(r_blo, voff, sB, 0);
-            rg[7] = __builtin_amdgcn_raw_buffer_load_b128(r_blo, voff, sB + half_rows, 0);
+            if (NJ == 4) rg[7] = __builtin_amdgcn_raw_buffer_load_b128(r_blo, voff, sB + half_rows, 0);
         };
         auto stage = [&](int buf) {
             _Float16* L = lds + buf * TBUF + wofs;
@@ -1212,9 +1263,9 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
             *reinterpret_cast<u32x4*>(L + P_ALO) = rg[2];
             *reinterpret_cast<u32x4*>(L + P_ALO + 128 * TROW) = rg[3];
             *reinterpret_cast<u32x4*>(L + P_BHI) = rg[4];
-            *reinterpret_cast<u32x4*>(L + P_BHI + 128 * TROW) = rg[5];
+            if (NJ == 4) *reinterpret_cast<u32x4*>(L + P_BHI + 128 * TROW) = rg[5];
             *reinterpret_cast<u32x4*>(L + P_BLO) = rg[6];
-            *reinterpret_cast<u32x4*>(L + P_BLO + 128 * TROW) = rg[7];
+            if (NJ == 4) *reinterpret_cast<u32x4*>(L + P_BLO + 128 * TROW) = rg[7];
         };
         gload(0);
         stage(0);
@@ -1239,36 +1290,36 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
             if (TIMING) { t0 = __builtin_readcyclecounter(); tc[5] += 1; }
             const _Float16* L = lds + (s & 1) * TBUF;
             __builtin_amdgcn_s_setprio(1);  // before the fragment reads: they must not queue behind the other group's staging
-            g16x8 ah[2], al[2], bh[4], bl[4], ch[2], cl[2], dh[4], dl[4];
+            g16x8 ah[2], al[2], bh[NJ], bl[NJ], ch[2], cl[2], dh[NJ], dl[NJ];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) ah[mi] = *reinterpret_cast<const g16x8*>(L + P_AHI + arow + mi * 32 * TROW + ak0);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) bh[ni] = *reinterpret_cast<const g16x8*>(L + P_BHI + brow + ni * 32 * TROW + bk0);
+            for (int ni = 0; ni < NJ; ++ni) bh[ni] = *reinterpret_cast<const g16x8*>(L + P_BHI + brow + ni * 32 * TROW + bk0);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) bl[ni] = *reinterpret_cast<const g16x8*>(L + P_BLO + brow + ni * 32 * TROW + bk0);
+            for (int ni = 0; ni < NJ; ++ni) bl[ni] = *reinterpret_cast<const g16x8*>(L + P_BLO + brow + ni * 32 * TROW + bk0);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) al[mi] = *reinterpret_cast<const g16x8*>(L + P_ALO + arow + mi * 32 * TROW + ak0);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) { X_MFMA(ah, bh, 0, ni); X_MFMA(ah, bh, 1, ni); }
+            for (int ni = 0; ni < NJ; ++ni) { X_MFMA(ah, bh, 0, ni); X_MFMA(ah, bh, 1, ni); }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) { X_MFMA(ah, bl, 0, ni); X_MFMA(ah, bl, 1, ni); }
+            for (int ni = 0; ni < NJ; ++ni) { X_MFMA(ah, bl, 0, ni); X_MFMA(ah, bl, 1, ni); }
             // second k16 block's fragments replace the dead ones (ah, bl) under the MFMAs in flight
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) ch[mi] = *reinterpret_cast<const g16x8*>(L + P_AHI + arow + mi * 32 * TROW + ak1);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) dh[ni] = *reinterpret_cast<const g16x8*>(L + P_BHI + brow + ni * 32 * TROW + bk1);
+            for (int ni = 0; ni < NJ; ++ni) dh[ni] = *reinterpret_cast<const g16x8*>(L + P_BHI + brow + ni * 32 * TROW + bk1);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) { X_MFMA(al, bh, 0, ni); X_MFMA(al, bh, 1, ni); }
+            for (int ni = 0; ni < NJ; ++ni) { X_MFMA(al, bh, 0, ni); X_MFMA(al, bh, 1, ni); }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) dl[ni] = *reinterpret_cast<const g16x8*>(L + P_BLO + brow + ni * 32 * TROW + bk1);
+            for (int ni = 0; ni < NJ; ++ni) dl[ni] = *reinterpret_cast<const g16x8*>(L + P_BLO + brow + ni * 32 * TROW + bk1);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) cl[mi] = *reinterpret_cast<const g16x8*>(L + P_ALO + arow + mi * 32 * TROW + ak1);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) { X_MFMA(ch, dh, 0, ni); X_MFMA(ch, dh, 1, ni); }
+            for (int ni = 0; ni < NJ; ++ni) { X_MFMA(ch, dh, 0, ni); X_MFMA(ch, dh, 1, ni); }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) { X_MFMA(ch, dl, 0, ni); X_MFMA(ch, dl, 1, ni); }
+            for (int ni = 0; ni < NJ; ++ni) { X_MFMA(ch, dl, 0, ni); X_MFMA(ch, dl, 1, ni); }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) { X_MFMA(cl, dh, 0, ni); X_MFMA(cl, dh, 1, ni); }
+            for (int ni = 0; ni < NJ; ++ni) { X_MFMA(cl, dh, 0, ni); X_MFMA(cl, dh, 1, ni); }
             __builtin_amdgcn_s_setprio(0);
             if (TIMING) { t1 = __builtin_readcyclecounter(); tc[0] += t1 - t0; t0 = t1; }
         };
@@ -1304,14 +1355,14 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < NJ; ++ni)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         f32x4 vf;
                         vf[0] = acc[mi][ni][r4 * 4 + 0]; vf[1] = acc[mi][ni][r4 * 4 + 1];
                         vf[2] = acc[mi][ni][r4 * 4 + 2]; vf[3] = acc[mi][ni][r4 * 4 + 3];
                         const u32x4 v = __builtin_bit_cast(u32x4, vf);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rf, (unsigned)tid * 16u, (unsigned)(((mi * 4 + ni) * 4 + r4) * TNT) * 16u, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rf, (unsigned)tid * 16u, (unsigned)(((mi * NJ + ni) * 4 + r4) * TNT) * 16u, 0);
                     }
             // (write-through `sc1` stores through inline asm, which the guide prices at 3.0 us against 8.2 us per 64 KB-per-workgroup
             // publish, measured 17 -> 14 us per 256 KB here: all slots publish at once and the 48 MB are bandwidth -- not kept)
@@ -1352,13 +1403,13 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
                                                                                          (int)(kFragFloats * sizeof(float)), 0x00020000);
                     constexpr int RQ = 4;  // 16-byte loads in flight per lane (then their 16 adds); more spills in the GELU build
 #pragma unroll
-                    for (int q0 = 0; q0 < 32; q0 += RQ) {
+                    for (int q0 = 0; q0 < 8 * NJ; q0 += RQ) {
                         u32x4 v[RQ];
 #pragma unroll
                         for (int u = 0; u < RQ; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rf, (unsigned)tid * 16u, (unsigned)((q0 + u) * TNT) * 16u, 0);
 #pragma unroll
                         for (int u = 0; u < RQ; ++u) {
-                            const int f = q0 + u, mi = f >> 4, ni = (f >> 2) & 3, r4 = f & 3;
+                            const int f = q0 + u, mi = f / (4 * NJ), ni = (f >> 2) % NJ, r4 = f & 3;
                             const f32x4 vf = __builtin_bit_cast(f32x4, v[u]);
                             acc[mi][ni][r4 * 4 + 0] += vf[0]; acc[mi][ni][r4 * 4 + 1] += vf[1];
                             acc[mi][ni][r4 * 4 + 2] += vf[2]; acc[mi][ni][r4 * 4 + 3] += vf[3];
@@ -1370,15 +1421,15 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
             asm volatile("" : "+v"(tid_));  // keep the epilogue's address arithmetic inside the segment loop
             __syncthreads();                // every wave has read its last operand fragments: the buffers are free
             char* wl = reinterpret_cast<char*>(lds) + (tid_ >> 6) * 16384;
-            if constexpr (kEpiLnf<EPI>)
+            if constexpr (kEpiLnf<EPI> && NJ == 4)
                 epilogue_planes_lnf<EPI>(a, acc, wl, reinterpret_cast<const g32x2*>(ln_lds) + 128 * wc, ln_lds + 2 * TB + 64 * wr, i0 + 64 * wr, j0 + 128 * wc,
                                          tid_ & 63);
-            else if constexpr (EPI == PEPI_RES_PLANES_STATS)
+            else if constexpr (EPI == PEPI_RES_PLANES_STATS && NJ == 4)
                 epilogue_res_planes(a, acc, reinterpret_cast<float*>(wl), ln_lds + 2 * (TB * wr + 128 * wc), i0 + 64 * wr, j0 + 128 * wc, tid_ & 63);
             else if constexpr (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES)
-                epilogue_planes_thin<EPI>(a, acc, wl, i0 + 64 * wr, j0 + 128 * wc, tid_ & 63);
+                epilogue_planes_thin<EPI, NJ>(a, acc, wl, i0 + 64 * wr, j0 + 32 * NJ * wc, tid_ & 63);
             else
-                epilogue_f32_lds<EPI>(a, acc, reinterpret_cast<float*>(wl), i0 + 64 * wr, j0 + 128 * wc, tid_ & 63);
+                epilogue_f32_lds<EPI, NJ>(a, acc, reinterpret_cast<float*>(wl), i0 + 64 * wr, j0 + 32 * NJ * wc, tid_ & 63);
             __syncthreads();  // LDS buffer 0 is re-staged by the next segment's prologue
             if constexpr (EPI == PEPI_RES_PLANES_STATS) {
                 // the tile's partial statistics: the four wave rows' 64-channel sums of token j0 + t, added in wave-row order, as ONE
@@ -1485,6 +1536,7 @@ static bool planes_par_usable(int I, int J_main, int K)
     return T < kSlots && T >= 8 && (T / 8) * (K / TBK) >= kSlots / 8;
 }
 static int g_planes_par = 1;  // 0: shapes with fewer tiles than slots are refused (the caller falls back to the 128 x 128 kernel; A/B hook)
+static int g_planes_half = 1; // 0: never the 256 x 128 tiles (A/B hook, gp_gemm_planes256_set_half_tiles)
 // A tile is split over at most K / 32 / kParMinSteps slots: below 16 k-steps per slot the partial accumulators (256 KB each, published by
 // all non-owners at once, then read by the owner) cost more than the shorter k loop saves -- proj (K = 1024) at 16 crops 69 -> 62 us with
 // two instead of four slots per tile, at 8 crops 74 -> 55 us with two or four instead of eight (PAR_MIN_STEPS=.. tools/probe_planes_timeline.py).
@@ -1573,6 +1625,19 @@ int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bh
             default: GP_REQUIRE(false, "gp_gemm_planes256_trace: epilogue %d has no traced build", epilogue);
         }
         GP_CHECK_LAUNCH("gp_gemm_planes256_trace");
+        return GP_OK;
+    }
+    // 256 x 128 tiles where the 256 x 256 ones fill at most half the slots (ViT-L below ~16 crops): proj / fc2 split every tile over
+    // half as many slots with half-size partial accumulators, q|k|v and fc1 stop splitting / fill the chip with whole tiles.
+    if (a.par && g_planes_half && 2ll * a.tiles_i * a.tiles_j <= kSlots &&
+        (epilogue == XEPI_BIAS_I_SCALE_RES || epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES)) {
+        a.tiles_j = J_main / (TB / 2);
+        switch (epilogue) {
+            case XEPI_BIAS_I_SCALE_RES: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES, false, true, 2>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            case PEPI_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_GELU_PLANES, false, true, 2>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            default: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES, false, true, 2>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        }
+        GP_CHECK_LAUNCH("gp_gemm_planes256/par128");
         return GP_OK;
     }
     if (a.par) {  // fewer tiles than slots: the parallel split-K build (its own instantiation: the serial hand-over kernel keeps its registers)
@@ -1729,6 +1794,12 @@ int gp_gemm_planes256_trace(const void* a_hi, const void* a_lo, const void* b_hi
 int gp_gemm_planes256_set_dp(int mode)  // bit 0: data-parallel rounds (default on); bit 1: test hook, head fragments are never published
 {
     g_planes_dp = mode & 63;  // bits 2..5: probe mask of epilogue 10 (epilogue_res_planes)
+    return GP_OK;
+}
+
+int gp_gemm_planes256_set_half_tiles(int on)  // 0: launches below half a tile per slot keep the 256 x 256 tiles (A/B hook)
+{
+    g_planes_half = on ? 1 : 0;
     return GP_OK;
 }
 

@@ -252,6 +252,8 @@ class Dinov2ViT(nn.Module):
                 _lib.lib().gp_vit_set_planes(int(os.environ["GIGAPOSE_VIT_PLANES"]))
             if "GIGAPOSE_PLANES_PAR" in os.environ:  # A/B probe: 0 = fewer tiles than slots (B < 64 at ViT-L) -> 128 x 128 kernels; n >= 2: >= n k-steps per slot of a split tile
                 _lib.lib().gp_gemm_planes256_set_par(int(os.environ["GIGAPOSE_PLANES_PAR"]))
+            if "GIGAPOSE_PLANES_HALF" in os.environ:  # A/B probe: 0 = no 256 x 128 tiles below half a tile per slot
+                _lib.lib().gp_gemm_planes256_set_half_tiles(int(os.environ["GIGAPOSE_PLANES_HALF"]))
             if "GIGAPOSE_PLANES_DP" in os.environ:   # A/B probe: 0 = every plane-GEMM tile cut stream-K style
                 _lib.lib().gp_gemm_planes256_set_dp(int(os.environ["GIGAPOSE_PLANES_DP"]))
             _lib.lib().gp_vit_set_ln_fold(self.ln_fold)   # needs the operands packed above (n_split = 28 per layer)

@@ -245,6 +245,9 @@ int gp_gemm_planes256_set_par(int on); /* default 1: shapes with 8 <= tiles < 25
                                           its K in parallel (partial accumulators added in a fixed order by the slot holding the last k
                                           range, at least 16 k-steps per slot); 0: such shapes are refused and gp_vit_forward_split falls back to the 128 x 128
                                           kernels; n >= 2 (probe hook): at least n k-steps per slot of a split tile */
+int gp_gemm_planes256_set_half_tiles(int on); /* default 1: launches whose 256 x 256 tiles fill at most half of the 256 slots (ViT-L below
+                                                 ~16 crops; epilogues 3 / 6 / 7) run on 256 x 128 tiles -- half the slots per split tile,
+                                                 half-size partial accumulators, q|k|v and fc1 unsplit; 0: always 256 x 256 (A/B hook) */
 /* Ragged J (257 tokens per crop are never a multiple of 256): only rows < J_valid of B carry data (J, the padded row
  * count of the buffers, stays a multiple of 256).  The 256 x 256 tiles cover floor(J_valid / 256) * 256 rows -- at
  * B = 64 crops exactly one / two / four whole tiles per CU, no stream-K hand-over -- and the remaining < 256 rows are

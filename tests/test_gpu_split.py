@@ -543,7 +543,41 @@ def test_planes256_ragged_rows(I, J, jv, K):
 # B = 16 (J_valid = 4112), proj at B = 8 and B = 33, a 9-tile problem (one XCD holds two tiles, seven hold one)
 PAR_SHAPES = [(1024, 4352, 4112, 1024), (1024, 4352, 4112, 4096), (3072, 4352, 4112, 1024), (4096, 4352, 4112, 1024),
               (1024, 2304, 2056, 1024), (1024, 8704, 8481, 1024), (768, 768, 768, 1024),
-              (1024, 8448, 8224, 1024), (1024, 8448, 8224, 4096)]   # proj / fc2 at B = 32: two slots per tile
+              (1024, 8448, 8224, 1024), (1024, 8448, 8224, 4096),   # proj / fc2 at B = 32: two slots per tile
+              (3072, 2304, 2056, 1024), (4096, 2304, 2056, 1024)]   # q|k|v / fc1 at B = 8: 256 x 128 tiles, unsplit (below)
+
+
+@pytest.mark.parametrize("I,J,jv,K", [(1024, 2304, 2056, 1024), (1024, 2304, 2056, 4096), (3072, 2304, 2056, 1024), (4096, 2304, 2056, 1024),
+                                      (1024, 4352, 4112, 4096)])
+def test_planes256_half_width_tiles_vs_full_width(I, J, jv, K):
+    """Launches whose 256 x 256 tiles fill at most half the slots take 256 x 128 tiles (epilogues 3 / 6 / 7; ViT-L at 8 crops: all four
+    GEMMs of a layer, at 16: proj / fc2).  Same products, a different partition of K over the slots of a tile: the two forms agree to the
+    summation-order bound of the strip test, each is deterministic, and the A/B hook selects between them."""
+    torch.manual_seed(I + jv + K + 1)
+    A = torch.randn(I, K, device=DEV) * 0.05
+    Bm = torch.randn(J, K, device=DEV) * 1.3
+    bias, scale = torch.randn(I, device=DEV), torch.randn(I, device=DEV)
+    res = torch.randn(I, J, device=DEV)
+    mag = A.double().abs() @ Bm[:jv].double().abs().t()
+    lib = _lib.lib()
+    out = {}
+    try:
+        for half in (1, 0):
+            lib.gp_gemm_planes256_set_half_tiles(half)
+            d3 = planes256_gemm(A, Bm, 3, bias, scale, res, j_valid=jv)
+            assert torch.equal(d3, planes256_gemm(A, Bm, 3, bias, scale, res, j_valid=jv)), "two launches differ"
+            out[half] = (d3, planes256_gemm(A, Bm, 6, bias, j_valid=jv), planes256_gemm(A, Bm, 7, bias, j_valid=jv))
+    finally:
+        lib.gp_gemm_planes256_set_half_tiles(1)
+    d_h, d_f = out[1][0][:, :jv].double(), out[0][0][:, :jv].double()
+    bound = 4e-7 * scale[:, None].abs().double() * mag + 2.4e-7 * d_f.abs()
+    assert ((d_h - d_f).abs() <= bound).all(), f"epilogue 3: {((d_h - d_f).abs() / bound).max().item():.2f} x the bound"
+    n_diff = int((d_h != d_f).sum())
+    print(f"half-width tiles I={I} J_valid={jv} K={K}: epilogue 3 differs from the 256-wide form in {n_diff} of {d_f.numel()} values (round-off)")
+    for k, epi in ((1, 6), (2, 7)):
+        v_h = (out[1][k][0][:jv].double() + out[1][k][1][:jv].double()).t()
+        v_f = (out[0][k][0][:jv].double() + out[0][k][1][:jv].double()).t()
+        assert ((v_h - v_f).abs() <= 8.0 * 4e-7 * mag + 1e-5 * v_f.abs()).all(), f"epilogue {epi}"
 
 
 @pytest.mark.parametrize("I,J,jv,K", PAR_SHAPES)

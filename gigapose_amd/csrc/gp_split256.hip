@@ -1627,10 +1627,14 @@ int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bh
         GP_CHECK_LAUNCH("gp_gemm_planes256_trace");
         return GP_OK;
     }
-    // 256 x 128 tiles where the 256 x 256 ones fill at most half the slots (ViT-L below ~16 crops): proj / fc2 split every tile over
-    // half as many slots with half-size partial accumulators, q|k|v and fc1 stop splitting / fill the chip with whole tiles.
-    if (a.par && g_planes_half && 2ll * a.tiles_i * a.tiles_j <= kSlots &&
-        (epilogue == XEPI_BIAS_I_SCALE_RES || epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES)) {
+    // 256 x 128 tiles where the 256 x 256 ones fill at most half the slots (ViT-L below ~16 crops; epilogues 3 / 6 / 7): the parallel
+    // split-K build on twice the tiles -- proj / fc2 split every tile over half as many slots with half-size partial accumulators,
+    // q|k|v and fc1 stop splitting / fill the chip with whole tiles.  (Between 128 and 256 whole tiles, twice as many half-width tiles
+    // cut stream-K style over all slots by the serial hand-over build was measured too: ViT-L forward at 12 / 16 / 40 / 48 crops
+    // 8.55 -> 8.95, 10.39 -> 10.44, 22.95 -> 22.5, 25.19 -> 25.55 ms -- the hand-overs cost what the balance gains; not kept.)
+    const long long T256 = (long long)a.tiles_i * a.tiles_j;
+    const bool epi_half = epilogue == XEPI_BIAS_I_SCALE_RES || epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES;
+    if (a.par && g_planes_half && epi_half && 2 * T256 <= kSlots) {
         a.tiles_j = J_main / (TB / 2);
         switch (epilogue) {
             case XEPI_BIAS_I_SCALE_RES: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES, false, true, 2>), dim3(kSlots), dim3(TNT), 0, st, a); break;

@@ -237,6 +237,10 @@ __global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* 
     constexpr int C = 128 * NK, TP = 132;  // LDS row pitch in words: 16-byte aligned pieces, tokens 33 sixteen-byte slots apart
     __shared__ float red[16][32];
     __shared__ __attribute__((aligned(16))) unsigned int tile[2][32 * TP];
+    // gamma | beta once per block through LDS (requested with the activations, visible after the first barrier): read from global
+    // memory inside the chunk loop they were eight dependent L2 round trips per block -- hidden by the other blocks of a CU at 64
+    // crops, 4 of the 13 us of a launch at 8 (65 blocks on 256 CUs)
+    __shared__ __attribute__((aligned(16))) float gb[2][C];
     const int tok = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const size_t tok0 = (size_t)blockIdx.x * 32;
     float xv[NK][8];
@@ -248,6 +252,10 @@ __global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* 
             xv[k][e] = X[(size_t)(128 * k + 8 * sl + e) * Mpad + tok0 + tok];
             s += xv[k][e];
         }
+    for (int c = threadIdx.x; c < C; c += 512) {
+        gb[0][c] = gamma[c];
+        gb[1][c] = beta[c];
+    }
     red[sl][tok] = s;
     __syncthreads();
     float tot = 0.f;
@@ -276,8 +284,8 @@ __global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* 
     for (int k = 0; k < NK; ++k) {
         unsigned int* T = tile[k & 1];
         const int c = 128 * k + 8 * sl;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gb[0] + c), g1 = *reinterpret_cast<const f32x4*>(gb[0] + c + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(gb[1] + c), b1 = *reinterpret_cast<const f32x4*>(gb[1] + c + 4);
         unsigned int w[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {

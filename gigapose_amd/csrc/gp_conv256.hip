@@ -83,6 +83,7 @@ struct ConvPArgs {
     int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, relu, K;
     int tiles_i, tiles_j;
     int* flags; float* partial; int epoch; int* status;
+    int par_cap;  // conv_halo_kernel<.., true>: most slots a tile is split over
     int stem;  // 1: the 7 x 7 / stride 2 stem on a zero-framed 4-channel image, see gp_conv2d_stem_planes
     unsigned long long* trace;  // probe (gp_conv2d_planes_set_trace): per slot 8 words -- segments, k-steps, 100 MHz ticks in prologue / k loop / tail
 };
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
     const int n_dp = rounds_dp * slots_x;
     const long long U = (long long)(n_t - n_dp) * ncb;
     long long u0 = U * n / slots_x, u1 = U * (n + 1) / slots_x;
-    const int par_S = PAR ? min(max(1, slots_x / max(n_t, 1)), ncb) : 1;
+    const int par_S = PAR ? min(min(max(1, slots_x / max(n_t, 1)), ncb), max(1, a.par_cap)) : 1;
     if (PAR) {
         const int tile = n / par_S, part = n - tile * par_S;
         u0 = u1 = 0;
@@ -917,10 +918,12 @@ int gp_planes_from_cm(const float* X, int C, int npix, void* hi, void* lo, void*
 
 static int g_conv_halo = 1;  // bit 0: 3 x 3 / stride 1 layers take the halo kernel; bit 1 (with it): its parallel split below 256 tiles (A/B hook)
 static int g_conv_par = 1;
+static int g_conv_par_min_cb = 1;  // channel blocks (9 k-steps each) per slot of a split tile at least
 int gp_conv2d_planes_set_halo(int on)
 {
     g_conv_halo = (on & 1) ? 1 : 0;
-    g_conv_par = (on == 1 || (on & 2)) ? 1 : 0;   // 1 = both (default), 0 = neither, 5 = halo without the parallel split
+    g_conv_par = ((on & 15) == 1 || (on & 2)) ? 1 : 0;   // 1 = both (default), 0 = neither, 5 = halo without the parallel split
+    g_conv_par_min_cb = (on >> 4) > 0 ? (on >> 4) : 1;   // probe: on = 1 + 16 n -> at least n channel blocks per slot of a split tile
     return GP_OK;
 }
 
@@ -940,6 +943,7 @@ static int conv_halo_launch(ConvPArgs& a, float* scratch, hipStream_t st)
     const long long n_tiles = (long long)a.tiles_i * a.tiles_j, units = n_tiles * ncb * 9;
     int slots_x = 32;
     const bool par = g_conv_par && n_tiles < 8 * slots_x && n_tiles >= 8 && ncb >= 2;  // fewer tiles than slots: parallel split over channel blocks
+    a.par_cap = max(1, ncb / g_conv_par_min_cb);
     while (!par && slots_x > 1 && n_tiles < 8 * slots_x && units / (8 * slots_x) < 32) slots_x >>= 1;
     a.flags = reinterpret_cast<int*>(scratch);
     a.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes);
@@ -985,6 +989,7 @@ int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const
     GP_REQUIRE(((uintptr_t)x_hi % 16 == 0) && ((uintptr_t)x_lo % 16 == 0) && ((uintptr_t)w_hi % 16 == 0) && ((uintptr_t)w_lo % 16 == 0) &&
                    ((uintptr_t)alpha % 16 == 0) && ((uintptr_t)beta % 16 == 0), "gp_conv2d_planes: misaligned operand");
     a.stem = 0;
+    a.par_cap = 1;
     a.trace = g_conv_trace;
     if (conv_halo_usable(H, W, Cin, Cout, KH, KW, stride, pad)) return conv_halo_launch(a, scratch, (hipStream_t)stream);
     const int ni = Cout >= 256 ? 4 : Cout / 64;  // 128 -> 2, 192 -> 3, >= 256 -> 4
@@ -1037,7 +1042,7 @@ int gp_conv2d_stem_planes(const void* x_hi, const void* x_lo, const void* w_hi, 
     a.xhi = (const _Float16*)x_hi; a.xlo = (const _Float16*)x_lo; a.whi = (const _Float16*)w_hi; a.wlo = (const _Float16*)w_lo;
     a.alpha = alpha; a.beta = beta; a.rhi = nullptr; a.rlo = nullptr; a.ohi = (_Float16*)out_hi; a.olo = (_Float16*)out_lo; a.of32 = nullptr;
     a.B = B; a.H = S + 6; a.W = S + 8; a.Cin = 4; a.OH = S / 2; a.OW = S / 2; a.Cout = Cout; a.KH = 7; a.KW = 8; a.stride = 2; a.pad = 0;
-    a.relu = relu; a.K = 7 * 32; a.stem = 1;
+    a.relu = relu; a.K = 7 * 32; a.stem = 1; a.par_cap = 1;
     a.trace = g_conv_trace;
     const long long npix = (long long)B * a.OH * a.OW;
     GP_REQUIRE(npix % CT == 0 && (long long)B * a.H * a.W * 8 < (1ll << 31) && npix * Cout < (1ll << 31), "gp_conv2d_stem_planes: B*OH*OW=%lld must be a multiple of 256", npix);

@@ -341,7 +341,8 @@ void gp_conv2d_planes_set_trace(unsigned long long* device_buf); /* probe: per s
 int gp_planes_from_cm(const float* X, int C, int npix, void* hi, void* lo, void* stream);
 /* 3 x 3 / stride 1 / pad 1 convolutions on images whose sides are multiples of 16 run conv_halo_kernel (16 x 16 pixel blocks whose
  * 18 x 18 halo is staged in LDS once per 32 input channels; the nine taps read it at shifted rows) -- same arguments, results equal
- * to conv_planes_kernel's to f32 round-off (summation order (channel block, tap) instead of (tap, channel block)).  0 = A/B hook. */
+ * to conv_planes_kernel's to f32 round-off (summation order (channel block, tap) instead of (tap, channel block)).  0 = A/B hook;
+ * 5 = without the parallel split of layers with fewer tiles than slots; 1 + 16 n (probe): at least n channel blocks per slot of a split tile. */
 int gp_conv2d_planes_set_halo(int on);
 int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* alpha, const float* beta,
                      const void* res_hi, const void* res_lo, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,

@@ -210,3 +210,50 @@ def test_parallel_split_plan_covers_every_unit_once_with_the_owner_last(T, nstep
             assert min(q[3] - q[2] for q in ps) >= min(min_steps, nstep // S), "a split tile's slot fell below the k-step floor"
     if min_steps == 16 and nstep == 32:
         assert max(S_of.values()) <= 2                                     # K = 1024: at most two slots per tile (proj / v below 64 crops)
+
+
+# ---- the tile-shape policy of gp_gemm_planes256_launch below 64 crops (round 4): 256 x 128 tiles (NJ = 2) for epilogues 3 / 6 / 7 when the
+# 256 x 256 tiles fill at most half the 256 slots; the parallel split then runs on twice the tiles with half-size partial accumulators.
+def vit_large_layer_plans(crops, half_tiles=True):
+    """-> {gemm: (tile columns, tiles, S, slots busy, partial MB moved)} for q|k|v, proj, fc1, fc2 of a ViT-L layer at `crops` crops."""
+    j_main = (257 * crops) // 256 * 256
+    out = {}
+    for name, I, K, can_split in (("qkv", 3072, 1024, True), ("proj", 1024, 1024, True), ("fc1", 4096, 1024, False), ("fc2", 1024, 4096, True)):
+        t256 = (I // 256) * (j_main // 256)
+        if t256 >= 256:
+            out[name] = (256, t256, 1, 256, 0.0)
+            continue
+        half = half_tiles and 2 * t256 <= 256
+        T, width = (2 * t256, 128) if half else (t256, 256)
+        plan, S_of = par_plan(T, K // 32, 16 if can_split else 10 ** 9)      # the GELU build keeps whole tiles (S = 1)
+        S = max(S_of.values())
+        partial_mb = sum(1 for (_, _, _, part, s) in plan.values() if part < s - 1) * 256 * width * 4 / 1e6
+        out[name] = (width, T, S, len(plan), partial_mb)
+    return out
+
+
+def test_half_width_tile_policy_at_eight_and_sixteen_crops():
+    """The launch plans DESIGN.md section 4 (round 4) quotes: at 8 crops every GEMM of a layer takes the 256 x 128 tiles -- q|k|v and fc1 become
+    whole tiles, proj two slots per tile on half the chip, fc2 four slots per tile with 25 MB of partials instead of 59 MB; at 16 crops only
+    proj / fc2 do; from 32 crops on nothing changes for q|k|v / fc1 and proj / fc2 fill the chip with whole half-width tiles."""
+    new, old = vit_large_layer_plans(8), vit_large_layer_plans(8, half_tiles=False)
+    assert new["qkv"][:4] == (128, 192, 1, 192) and old["qkv"][:4] == (256, 96, 2, 192)
+    assert new["fc1"][:4] == (128, 256, 1, 256) and old["fc1"][:4] == (256, 128, 1, 128)
+    assert new["proj"][:4] == (128, 64, 2, 128) and old["proj"][:4] == (256, 32, 2, 64)
+    assert new["fc2"][:4] == (128, 64, 4, 256) and old["fc2"][:4] == (256, 32, 8, 256)
+    assert abs(new["fc2"][4] - 25.2) < 0.1 and abs(old["fc2"][4] - 58.7) < 0.1
+    p16 = vit_large_layer_plans(16)
+    assert p16["qkv"][:2] == (256, 192) and p16["fc1"][:2] == (256, 256) and p16["proj"][:4] == (128, 128, 2, 256) and p16["fc2"][:4] == (128, 128, 2, 256)
+    p32 = vit_large_layer_plans(32)
+    assert p32["qkv"][0] == 256 and p32["fc1"][0] == 256 and p32["proj"][:4] == (128, 256, 1, 256) and p32["fc2"][:4] == (128, 256, 1, 256)
+    assert all(v[0] == 256 for v in vit_large_layer_plans(64).values())
+
+
+@pytest.mark.parametrize("crops", [4, 8, 12, 16, 24, 32, 48])
+def test_half_width_tile_plans_cover_every_unit(crops):
+    for name, (width, T, S, busy, _) in vit_large_layer_plans(crops).items():
+        if T >= 256:
+            continue
+        nstep = 128 if name == "fc2" else 32
+        plan, _ = par_plan(T, nstep, 16 if name != "fc1" else 10 ** 9)
+        assert sum(s1 - s0 for (_, s0, s1, _, _) in plan.values()) == T * nstep and busy == len(plan) <= 256

@@ -411,6 +411,19 @@ def main():
                     batch_curve[f"b{bsz}"] = r
                 batch_curve["workload"] = text3 + "; crops/s at B = 8 / 16 / 32 (5 steps each) and their ratio to the B = 64 rate of the same bank"
                 batch_curve[f"b{args.batch}"] = {"value": r64["value"], "batch": args.batch, "ms_per_step": r64["ms_per_step"]}
+                # the same three with the IST backbone on a second HIP stream (GigaPose.overlap_ist; off by default): below 64 crops
+                # neither chain fills the chip
+                keep = model.overlap_ist
+                try:
+                    model.overlap_ist = True
+                    for bsz in (8, 16, 32):
+                        r = time_batch("config3", tset3, 8, bsz, 5)
+                        r["per_crop_rate_vs_b64"] = round(r["value"] / per_crop_64, 3)
+                        batch_curve[f"b{bsz}_two_streams"] = r
+                except Exception as e:
+                    batch_curve["two_streams_error"] = repr(e)
+                finally:
+                    model.overlap_ist = keep
             except Exception as e:
                 batch_curve["error"] = repr(e)
             drop("config3")

@@ -108,10 +108,13 @@ class GigaPose(_Base):
         self.test_dataset_name = None
         self.last_predictions = None  # full (unfiltered) predictions of the last eval_retrieval call
         self.template_shard = None    # (rank, world, group) when the template bank is sharded
-        # IST backbone on a side stream, concurrently with ViT + matching?  Measured (BENCH_r01, profiles/r02_*): both chains are
+        # IST backbone on a side stream, concurrently with ViT + matching?  At 64 crops (BENCH_r01, profiles/r02_*) both chains are
         # matrix-core / power bound, so the overlap only stretches every kernel (attention 3.4 -> 7.7 ms, GEMMs 30.6 -> 36.4 ms per
-        # step inside the two-stream region) for a 0-1 % gain in step time -- off by default, kept as a switch.
-        self.overlap_ist = False
+        # step inside the two-stream region) for a 0-1 % gain in step time.  Below that neither chain fills the chip and the two
+        # streams do: 825 -> 884 crops/s at 8 crops, 1136 -> 1168 at 16, 1349 -> 1370 at 32 (round 4, tools/gpu_r04_overlap.sh).  Same
+        # kernels, same results.  False (default) / True / "auto" (two streams up to 32 crops); GIGAPOSE_OVERLAP_IST=0 / 1 / auto.
+        env = os.environ.get("GIGAPOSE_OVERLAP_IST", "0").strip().lower()
+        self.overlap_ist = "auto" if env == "auto" else env in ("1", "true", "on")
         self._side_stream = None
         if numerics is not None:
             self.set_numerics(numerics)
@@ -253,7 +256,7 @@ class GigaPose(_Base):
             labels = labels.pin_memory().to(tar_img.device, non_blocking=True)
         labels0 = (labels.to(tar_img.device) - 1).to(torch.int32).contiguous()
         side = None
-        if self.overlap_ist and tar_img.is_cuda:
+        if tar_img.is_cuda and (self.overlap_ist is True or (self.overlap_ist == "auto" and tar_img.shape[0] <= 32)):
             # IST backbone on a second HIP stream: both chains are matrix-core bound, the overlap fills
             # the partial last wave of workgroups ("tail") of each other's launches
             main = torch.cuda.current_stream()

@@ -257,3 +257,31 @@ def test_template_sharded_path_over_rccl_equals_unsharded(monkeypatch, numerics)
     assert set(plain) == set(shard)
     for n in plain:
         assert torch.equal(plain[n], shard[n]), f"{n} differs between the sharded and the unsharded path"
+
+
+@pytest.mark.parametrize("numerics", ["chain", "split"])
+def test_ist_backbone_on_a_second_stream_gives_the_same_predictions(monkeypatch, numerics):
+    """`overlap_ist` (GIGAPOSE_OVERLAP_IST = 1 / auto): the IST backbone runs on a side stream next to ViT + matching -- below 64 crops the
+    two chains together fill the chip (+7 % at 8 crops).  Same kernels with deterministic reductions: every tensor of predict() is equal."""
+    from gigapose_amd import factory
+
+    monkeypatch.setenv("GIGAPOSE_NUMERICS", numerics)
+    dev = torch.device("cuda", 0)
+    tset = factory.TemplateSet(2, 9, seed=70)
+    model = factory.build_model("dinov2_vits14", k=4, device=dev, seed=6)
+    model.template_datasets = {"syn": tset}
+    model.set_template_data("syn")
+    assert model.overlap_ist is False
+    out = {}
+    for B in (5, 40):
+        q = tset.crops(71 + B, B, dev)
+        for mode in (False, True, "auto"):
+            model.overlap_ist = mode
+            for _ in range(2):   # twice: the side stream is created on first use
+                p = model.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
+            torch.cuda.synchronize()
+            out[(B, mode)] = {n: v.cpu() for n, v in p.tensors.items()}
+        for mode in (True, "auto"):
+            for n, v in out[(B, False)].items():
+                assert torch.equal(v, out[(B, mode)][n]), f"{n} differs with overlap_ist = {mode!r} at {B} crops"
+    model.overlap_ist = False

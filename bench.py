@@ -24,6 +24,9 @@ import time
 # dependent launches, and each starts 1-2 us earlier (measured A/B on one box: 45.95 -> 45.65 ms per step).  A HIP runtime
 # setting, read when the runtime is loaded -- hence before `import torch`; an exported value wins.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# N > 1: the host driver of this pool supports dmabuf IPC only; without it RCCL's buffer registration across ranks fails with
+# `hipIpcGetMemHandle: invalid argument`.  Exported on the GPU boxes already; kept here so that the line does not depend on the shell.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch

@@ -31,3 +31,14 @@ def test_chain_is_opt_in_by_env_and_by_yaml_key(monkeypatch):
         _lib.default_numerics()
     with pytest.raises(ValueError):
         m.set_numerics("bf16")
+
+
+def test_second_stream_switch_is_off_by_default_and_read_from_the_environment(monkeypatch):
+    """GigaPose.overlap_ist: False unless GIGAPOSE_OVERLAP_IST says 1 / auto (small batches)."""
+    from gigapose_amd import factory
+
+    monkeypatch.delenv("GIGAPOSE_OVERLAP_IST", raising=False)
+    assert factory.build_model("dinov2_vits14", k=2, device="cpu").overlap_ist is False
+    for text, want in (("1", True), ("auto", "auto"), ("AUTO", "auto"), ("0", False), ("", False), ("on", True)):
+        monkeypatch.setenv("GIGAPOSE_OVERLAP_IST", text)
+        assert factory.build_model("dinov2_vits14", k=2, device="cpu").overlap_ist == want

@@ -36,6 +36,61 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense f32-input MFMA peak (MI355X_MICROARCH.md)
 FLOP_PER_CROP = {"dinov2_vitl14": 162.0e9, "dinov2_vits14": 12.25e9, "dinov2_vitb14": 0.0}
+REFERENCE_OVER_PORT = round(0.953 / 1.021, 3)  # unmodified reference / oracle.torch_port, same crops + threads + process (profiles/r03_cpu_reference_vs_port.txt)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started WITHOUT a launcher: start the N ranks ourselves, exactly as the task statement's launcher line
+    does (one process per GPU, 127.0.0.1 rendezvous on a free port), relay their output and exit with their status."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: no launcher environment (RANK / WORLD_SIZE unset) -- spawning " + " ".join(cmd) + "\n")
+    return subprocess.call(cmd, env=dict(os.environ, GIGAPOSE_BENCH_SPAWNED="1"))
+
+
+def sustained_matrix_clock_mhz(lib, dev):
+    """The shader clock INSIDE the dominant kernel, measured now on this box: 30 back-to-back launches of gemm_planes256_kernel at the
+    fc2 shape of the headline workload heat the socket to the state the timed region runs in, then the TIMING build of the same
+    kernel (gp_gemm_planes256_timing, tools/probe_planes256.py) reports its own cycle counter against the 100 MHz wall clock over
+    one launch.  ~15 ms, after the timed region.  None if the probe entry is missing."""
+    from gigapose_amd import _lib
+
+    try:
+        lib.gp_gemm_split256_workspace_bytes.restype = ctypes.c_size_t
+        nb = lib.gp_gemm_split256_workspace_bytes()
+        ws = torch.zeros(nb // 4, device=dev)
+        I, J, K = 1024, 16640, 4096
+        W = torch.randn(I, K, device=dev) * 0.03
+        Xt = torch.randn(J, K, device=dev)
+
+        def planes(t, scale):
+            hi = torch.empty(t.shape, dtype=torch.float16, device=dev)
+            lo = torch.empty_like(hi)
+            _lib.call("gp_split_planes", _lib.ptr(t), ctypes.c_size_t(t.numel()), _lib.f(scale), _lib.ptr(hi), _lib.ptr(lo), _lib.stream_ptr())
+            return hi, lo
+
+        whi, wlo = planes(W, 64.0)
+        xhi, xlo = planes(Xt, 8.0)
+        D = torch.empty(I, J, device=dev)
+        out = (ctypes.c_ulonglong * 8)()
+        for _ in range(30):
+            _lib.call("gp_gemm_planes256", _lib.ptr(whi), _lib.ptr(wlo), _lib.ptr(xhi), _lib.ptr(xlo), _lib.ptr(D), _lib.i(J), _lib.ptr(None),
+                      _lib.ptr(None), _lib.i(0), _lib.i(I), _lib.i(J), _lib.i(K), _lib.i(0), _lib.ptr(None), _lib.ptr(None), _lib.ptr(None),
+                      _lib.i(0), _lib.f(1.0 / 512.0), _lib.ptr(ws), ctypes.c_size_t(nb), _lib.stream_ptr())
+        lib.gp_gemm_planes256_timing(_lib.ptr(whi), _lib.ptr(wlo), _lib.ptr(xhi), _lib.ptr(xlo), _lib.ptr(D), J, I, J, K, _lib.ptr(ws), out,
+                                     _lib.stream_ptr())
+        torch.cuda.synchronize()
+        if out[7] == 0:
+            return None
+        return round(out[6] / (out[7] / 100.0), 1)   # cycles / microseconds
+    except Exception:
+        return None
 
 
 def cpu_baseline(variant, n_templates, k, sample_crops=32, threads=None):
@@ -73,9 +128,17 @@ def cpu_baseline(variant, n_templates, k, sample_crops=32, threads=None):
     torch_port.eval_retrieval(hf, ist, bank_ae, bank_ist, masks, geom, q, k, dets_per_forward=4)
     dt = time.time() - t0
     return {"value": round(sample_crops / dt, 4), "unit": "query-crops/sec", "cores": threads, "kind": "port",
+            "host_logical_cpus": os.cpu_count(), "cpus_in_affinity_mask": avail,
+            # the anchor to the UNMODIFIED reference (which cannot travel to the GPU box): both timed in one process on the same
+            # 32 crops / threads in the build container by oracle/time_reference.py -> profiles/r03_cpu_reference_vs_port.txt
+            "reference_over_port": REFERENCE_OVER_PORT,
+            "reference_equivalent_value": round(REFERENCE_OVER_PORT * sample_crops / dt, 4),
+            "reference_over_port_source": "profiles/r03_cpu_reference_vs_port.txt: unmodified reference 0.953 crops/s vs this port 1.021 crops/s "
+                                          "(8 threads, 32 crops x 162 templates, ViT-L/14 stand-in, same process, build container)",
             "sample": f"{sample_crops} crops x {n_templates} templates, {variant}, oracle/torch_port.py (torch-CPU restatement of the "
                       f"reference's eval_retrieval, f32, sub-batches of 4, IST backbone x k as the reference recomputes it), "
-                      f"torch threads = {threads}, {dt:.1f} s"}
+                      f"torch threads = {threads} (the host reports {os.cpu_count()} logical CPUs, {avail} in this process's affinity mask; "
+                      f"more than 16 torch threads measured slower), {dt:.1f} s"}
 
 
 class _StubLib:
@@ -174,6 +237,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and os.environ.get("GIGAPOSE_BENCH_SPAWNED") != "1":
+        raise SystemExit(spawn_ranks(args.gpus))   # plain `python bench.py --gpus N`: be our own launcher
     if world != args.gpus:
         # one rank per GPU, launched as the task statement says; any other pairing would time a different job than the line reports
         raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}; launch with: python -m torch.distributed.run "
@@ -290,6 +355,7 @@ def main():
     # either way; in sharded mode every rank still matches all W * B crops against its 1 / W of the bank, so it saves memory,
     # not matcher work.  The switch is the same on every rank (it depends on world / mode only): the collectives stay paired.
     other_modes = None
+    stuck_group = False
     if (world > 1 or os.environ.get("GIGAPOSE_BENCH_BOTH_MODES") == "1") and mode in ("sharded", "replicas"):   # env: exercise the block at world 1
         alt = "replicas" if mode == "sharded" else "sharded"
         err = None
@@ -309,10 +375,23 @@ def main():
         if world > 1:
             # a rank that failed alone has left its peers inside a collective of the second pass: say so on every rank instead of
             # hanging -- the flag exchange itself cannot pair with a data-path collective (those are finished or dead by now)
+            # (bounded: a peer that is STILL inside a data-path collective never reaches this exchange -- give up after 60 s and
+            # report instead of hanging the headline line)
             flag = torch.tensor([1 if err else 0], device=dev, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if int(flag.item()) and not err:
-                other_modes = {alt: {"error": "another rank failed in this mode"}}
+            work = dist.all_reduce(flag, op=dist.ReduceOp.MAX, async_op=True)
+            deadline = time.time() + 60.0
+            while not work.is_completed() and time.time() < deadline:
+                time.sleep(0.01)
+            if not work.is_completed():
+                other_modes = {alt: {"error": (err or "") + " | failure-flag exchange timed out after 60 s (a peer is stuck in a collective)"}}
+                if rank == 0:   # the headline measurement is complete: print it and leave without joining the dead group
+                    stuck_group = True
+                else:
+                    os._exit(0)
+            else:
+                work.wait()
+                if int(flag.item()) and not err:
+                    other_modes = {alt: {"error": "another rank failed in this mode"}}
     other = None
     if world == 1 and not dist.is_initialized() and not args.no_other and not stub:
         other = {}
@@ -335,8 +414,8 @@ def main():
         # split128: what the automatic range fallback lands in (gigaPose.py: _widen_split_range) when a checkpoint's activations
         # leave the x8 f16 planes' range (|x| >= 8190): ViT linear layers + IST convolutions on the two-accumulator 128 x 128
         # kernels (GIGAPOSE_SPLIT_GEMM=128 + GIGAPOSE_SPLIT_CONV=128), everything else as in split
+        vit, ist = model.ae_net.dinov2_model, model.ist_net.backbone   # bound BEFORE the try: the finally below restores them
         try:
-            vit, ist = model.ae_net.dinov2_model, model.ist_net.backbone
             vit.set_split_gemm("128")
             ist.conv_kernel = "128"
             ist.invalidate()
@@ -463,21 +542,30 @@ def main():
             traffic = round(pmc[fam]["hbm_bytes_per_launch"])
     except Exception:
         pass
-    F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
+    F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md); assumes the 2.4 GHz maximum clock
+    PEAK_CLOCK_MHZ = 2400.0
     if args.numerics == "split":
         g = kern_timed.get("gemm_split", {})   # the sampled launches of THE timed region
-        alg = g.get("TFLOP/s", 0.0)
-        achieved = round(3.0 * alg, 2)  # executed on the matrix core: 3 f16 MFMAs per f32-equivalent product block
+        alg = g.get("TFLOP/s", 0.0)            # algorithmic 2 I J K flops of the launches / their event-timed duration
+        executed = round(3.0 * alg, 2)         # what the matrix core executes: 3 f16 MFMAs per f32-equivalent product block
+        clk = None if stub else sustained_matrix_clock_mhz(lib, dev)
         roofline = {"kernel": "gemm_planes256_kernel (ViT linear layers; 3 x v_mfma_f32_32x32x16_f16 per k-block on f16-split f32 "
-                              "operands held as hi / lo planes, f32 accumulate)", "bound": "mfma", "achieved": achieved, "peak": F16_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / F16_MFMA_PEAK_TFLOPS, 4),
-                    "algorithmic_tflops_f32_equivalent": alg, "frac_algorithmic": round(alg / F16_MFMA_PEAK_TFLOPS, 4),
-                    "frac_of_split_bound": round(3.0 * alg / F16_MFMA_PEAK_TFLOPS, 4),
-                    "note": "achieved = 3 x algorithmic 2IJK flops / launch time (the three f16 products per f32-equivalent "
-                            "product all execute on the matrix core; frac_algorithmic = the 2IJK flops alone against the same "
-                            "peak); the f32-input MFMA peak this mode replaces is 157.3. The kernel runs power-limited: 1.60 GHz "
-                            "measured in-kernel against the 2.4 GHz the peak assumes, matrix pipe 86 % busy in its k loop "
-                            "(profiles/r02_probe_planes256.txt)",
+                              "operands held as hi / lo planes, f32 accumulate)", "bound": "mfma",
+                    # achieved / frac: USEFUL work against the roofline, as SURVEY 8(d) defines it (162 GFLOP / crop figure -> 2 I J K per
+                    # launch); the split emulation's 3 executed flops per useful flop are reported beside it, not in it
+                    "achieved": alg, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(alg / F16_MFMA_PEAK_TFLOPS, 4),
+                    "achieved_is": "algorithmic f32-equivalent flops (2 I J K per launch) / event-timed launch duration",
+                    "executed_tflops": executed,
+                    "mfma_util_executed": round(executed / F16_MFMA_PEAK_TFLOPS, 4),
+                    "sustained_matrix_clock_mhz": clk,
+                    "mfma_util_at_sustained_clock": (round(executed / (F16_MFMA_PEAK_TFLOPS * clk / PEAK_CLOCK_MHZ), 4) if clk else None),
+                    "frac_vs_f32_input_mfma_peak": round(alg / F32_MFMA_PEAK_TFLOPS, 3),
+                    "note": "frac = useful (algorithmic) flops / f16 dense peak.  mfma_util_executed = 3 x that: the three f16 products per "
+                            "f32-equivalent product all execute on the matrix core (north_star's MFMA-utilisation reading).  "
+                            "mfma_util_at_sustained_clock = executed / (peak x sustained_matrix_clock_mhz / 2400): the kernel runs at the "
+                            "socket's power limit; the clock is measured by the kernel's own cycle counter right after the timed region "
+                            "(bench.py: sustained_matrix_clock_mhz).  frac_vs_f32_input_mfma_peak: the same useful flops against the 157.3 "
+                            "TFLOP/s f32-input MFMA peak the reference's dtype would otherwise be bound by",
                     "traffic": traffic}
     else:
         g = kern_timed.get("gemm_kmajor", {})
@@ -485,6 +573,24 @@ def main():
         roofline = {"kernel": "gemm_kmajor_kernel (ViT linear layers + IST MLP; f32-input MFMA 32x32x2)", "bound": "mfma",
                     "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic}
+    if args.numerics == "split" and not stub and "match_split" in kern:
+        try:
+            from gigapose_amd.matching import patch_grid_mask
+
+            bank = model.match_banks["syn"]
+            bm = getattr(bank, "shard", bank).masks                                     # (O, N, 256)
+            qlive = (patch_grid_mask(q["tar_mask"]) != 0).sum(-1)                        # (B,)
+            tlive = (bm[(q["labels"].to(bm.device) - 1).long()] != 0).sum(-1)            # (B, N)
+            blocks = (((qlive + 31) // 32)[:, None] * ((tlive + 31) // 32)).float().mean().item()
+            m = kern["match_split"]
+            m["nominal_TFLOP/s"] = m["TFLOP/s"]                                         # 2 x 256 x 256 x C per tile, masked-out patches included
+            m["live_block_fraction"] = round(blocks / 64.0, 4)                          # 32 x 32 blocks the kernel multiplies / 64
+            m["executed_TFLOP/s"] = round(3.0 * m["TFLOP/s"] * blocks / 64.0, 2)        # f16 MFMA flops actually issued
+            m["mfma_util_executed"] = round(m["executed_TFLOP/s"] / F16_MFMA_PEAK_TFLOPS, 4)
+            m["note"] = ("TFLOP/s is NOMINAL (every patch of the 256 x 256 tile); the kernel multiplies only the 32 x 32 blocks that hold live "
+                         "(unmasked) patches: executed = 3 x nominal x live_block_fraction")
+        except Exception as e:
+            kern["match_split"]["executed_note"] = "not computed: " + repr(e)
     roofline.update({
         "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE); algorithmic operand + result bytes per launch: DESIGN.md section 4",
         "traffic_source": "STATIC: read from profiles/pmc_traffic.json, the rocprofv3 --pmc passes of this same command recorded by "
@@ -510,7 +616,8 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: {args.variant} random-init, {args.objects} object(s) x {args.templates} templates, "
                                f"batch={args.batch} crops per GPU, k={args.k}, full path ViT->match->IST->RANSAC->pose",
                    "numerics": args.numerics, "global_batch": world * args.batch, "parallelism": f"{mode}{world}" if (world > 1 or (mode == "sharded" and dist.is_initialized())) else "single",
-                   "streams": "ViT+match on stream 0, IST backbone on stream 1" if model.overlap_ist else "single stream",
+                   "streams": ("ViT+match on stream 0, IST backbone on stream 1"
+                               if (model.overlap_ist is True or (model.overlap_ist == "auto" and args.batch <= 32)) else "single stream"),
                    "rccl_ranks": world if dist.is_initialized() else 0,   # = N under the launcher: one rank per GPU
                    "per_rank_ms_per_step": per_rank_ms,                  # each rank's own K steps before the closing barrier (a straggler GPU shows here)
                    "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
@@ -533,7 +640,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.variant, args.templates, args.k)
         except Exception as e:  # the baseline is a reported extra; never lose the GPU number
             out["cpu_baseline"] = {"error": repr(e)}
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if stuck_group:
+        os._exit(0)   # a peer never left a collective: destroy_process_group() would wait for it
     if dist.is_initialized():
         dist.destroy_process_group()
 

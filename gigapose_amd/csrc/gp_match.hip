@@ -110,7 +110,7 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
                                                int compact = 1,   // PERM: the tile holds the live patches only (see below)
                                                MatchWaveTile wt = MatchWaveTile{0, 0, 0, 0, 0, 0, 0})  // PERM: this wave's rectangle
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: selects per-wave code paths
     if constexpr (!PERM) wt = match_wave_tile_grid(wave);
     // ---- sim *= src_mask; sim *= tar_mask; sim[sim < thr] = 0   (matching.py:234-236)
     const int s_lane = 32 * wt.c0 + (lane & 31);
@@ -585,8 +585,11 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     // the nrb x ncb live blocks are cut into at most eight RECTANGLES (1-2 row blocks x 1-4 column blocks, one per wave), chosen so
     // that the two waves of a SIMD together hold as few blocks as possible: 7 instead of 12 at 5 x 5.  Each dot product is the same
     // instruction sequence wherever it is computed: outputs stay bit-identical.
-    const int nrb = (live_t + 31) >> 5, ncb = (live_s + 31) >> 5;
-    const MatchWaveTile wt = match_wave_tile_unpack(kMatchRect[nrb][ncb][wave]);
+    // wave-uniform BY CONSTRUCTION (readfirstlane): the k-loop instantiation below is picked per wave and holds barriers, so its
+    // selector must live in a scalar register -- a selector the compiler has to treat as divergent (LDS reads + a table load) would
+    // put __syncthreads under a divergent switch
+    const int nrb = __builtin_amdgcn_readfirstlane((live_t + 31) >> 5), ncb = __builtin_amdgcn_readfirstlane((live_s + 31) >> 5);
+    const MatchWaveTile wt = match_wave_tile_unpack((unsigned)__builtin_amdgcn_readfirstlane((int)kMatchRect[nrb][ncb][wave]));
 
     // staging: thread = (row tid >> 2 [+128], 16-byte k-chunk tid & 3) of each plane; one descriptor per plane of THIS tile
     const unsigned plane_bytes = (unsigned)GP_P * (unsigned)C * 2u;

@@ -527,6 +527,65 @@ def main():
                 other_configs["config5"] = {"error": repr(e)}
         model.testing_metric.bank_dtype = None
         model.template_datasets = {"syn": tset}
+    # The drop-in flow (N = 1 only): what `trainer.test` of the reference's test.py drives -- ONE image per test_step (reference
+    # test.py:55-60), 8 detections per image here, 64 images.  accumulated: the product default (GigaPose.accumulate_crops = 64: whole
+    # images queued, one predict per 64 pending crops, per-image npz files written while the next flush runs); per_image: the
+    # reference's flow (accumulate_crops = 0: one predict + file per image).  Wall clock from the first test_step to the last file.
+    dropin_flow = None
+    if world == 1 and not dist.is_initialized() and not args.no_configs and not stub:
+        try:
+            import shutil
+            import tempfile
+
+            import pandas as pd
+
+            from gigapose_amd.tensor_collection import PandasTensorCollection
+
+            model.set_numerics(args.numerics)
+            model.template_datasets = {"syn": tset}
+            model.set_template_data("syn")
+            model.test_dataset_name = "syn"
+            n_img, n_det = 64, 8
+            images = []
+            for im in range(n_img):
+                qi = tset.crops(5000 + im, n_det, dev)
+                lab = qi["labels"].numpy()
+                b = PandasTensorCollection(infos=pd.DataFrame(dict(label=[str(l) for l in lab], scene_id=[1] * n_det, view_id=[im] * n_det)),
+                                           **{k: qi[k] for k in ["tar_img", "tar_mask", "tar_K", "tar_M"]})
+                objs = sorted(set(int(l) for l in lab))
+                b.test_list = PandasTensorCollection(infos=pd.DataFrame(dict(im_id=[im] * len(objs), scene_id=[1] * len(objs), obj_id=objs,
+                                                                             inst_count=[int((lab == o).sum()) for o in objs],
+                                                                             detection_time=[0.0] * len(objs))))
+                images.append(b)
+            keep_dir, keep_acc = model.log_dir, model.accumulate_crops
+            dropin_flow = {"workload": f"{n_img} images x {n_det} detections through GigaPose.test_step (one image per call, as the reference's "
+                                       f"test.py feeds it) + the final flush; headline bank ({args.objects} object(s) x {args.templates} templates), "
+                                       "per-image npz files written", "numerics": args.numerics}
+            for name, acc in (("accumulated", 64), ("per_image", 0)):
+                tmp = tempfile.mkdtemp(prefix="gigapose_flow_")
+                try:
+                    model.log_dir, model.accumulate_crops = tmp, acc
+                    os.makedirs(os.path.join(tmp, "predictions"), exist_ok=True)
+                    for b in images[:8]:          # warm-up: one flush / eight images
+                        model.test_step(b, 9999)
+                    model.flush_pending()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for im, b in enumerate(images):
+                        model.test_step(b, im)
+                    model.flush_pending()
+                    torch.cuda.synchronize()
+                    dtf = time.perf_counter() - t0
+                    n_files = len([f for f in os.listdir(os.path.join(tmp, "predictions")) if f.endswith(".npz")])
+                    dropin_flow[name] = {"value": round(n_img * n_det / dtf, 2), "unit": "query-crops/sec", "accumulate_crops": acc,
+                                         "ms_per_image": round(1e3 * dtf / n_img, 3), "npz_files_written": n_files - 1}
+                finally:
+                    shutil.rmtree(tmp, ignore_errors=True)
+            model.log_dir, model.accumulate_crops = keep_dir, keep_acc
+            dropin_flow["accumulated_over_b64_rate"] = round(dropin_flow["accumulated"]["value"] / (world * args.batch * args.steps / dt), 3)
+            dropin_flow["accumulated_over_per_image"] = round(dropin_flow["accumulated"]["value"] / dropin_flow["per_image"]["value"], 3)
+        except Exception as e:
+            dropin_flow = {"error": repr(e)}
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -633,6 +692,8 @@ def main():
         out["other_configs"] = other_configs
     if batch_curve:
         out["batch_curve"] = batch_curve
+    if dropin_flow:
+        out["dropin_flow"] = dropin_flow
     if stub:
         out["data"] = "STUB (GIGAPOSE_BENCH_STUB=1): control-flow test of bench.py on CPU / gloo, no kernels -- not a measurement"
     if world == 1 and not args.no_cpu_baseline and not stub:

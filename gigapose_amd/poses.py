@@ -53,7 +53,10 @@ class ObjectPoseRecovery(torch.nn.Module):
         self.template_Ms = template_Ms.contiguous().float()        # (O,N,3,3)
         self.template_poses = template_poses.contiguous().float()  # (O,N,4,4)
         self.ransac = RANSAC(pixel_threshold=pixel_threshold)
+        # True: read the crop-transform flag back after every call (a host sync, as the reference's assert is); False: never;
+        # "deferred": leave the device flag in self.deferred_flag for a caller that synchronises later (GigaPose's flush pipeline)
         self.check_asserts = True
+        self.deferred_flag = None
 
     @torch.no_grad()
     def forward_recovery(self, tar_label, tar_K, tar_M, pred_src_views, pred_M):
@@ -70,7 +73,9 @@ class ObjectPoseRecovery(torch.nn.Module):
                   _lib.ptr(pred_M.contiguous().float()), _lib.ptr(self.template_K), _lib.ptr(self.template_Ms),
                   _lib.ptr(self.template_poses), _lib.i(B), _lib.i(O), _lib.i(N), _lib.i(k), _lib.ptr(poses),
                   _lib.ptr(flag), _lib.stream_ptr())
-        if self.check_asserts and B > 0:
+        if self.check_asserts == "deferred":
+            self.deferred_flag = flag
+        elif self.check_asserts and B > 0:
             # reference lib3d/torch.py:54-55 asserts the crop transform is isotropic scale + translation
             assert int(flag.item()) == 0, "tar_M must be an isotropic scale + translation"
         return poses

@@ -34,14 +34,35 @@ def image_batch(tset, seed, n, view_id):
     return batch, q
 
 
-def test_reference_test_py_flow_from_the_reference_model_config(tmp_path):
-    cfg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "model_cfg_resolved.json")))
-    cfg["log_dir"] = str(tmp_path)
-    cfg["test_setting"] = "localization"                                  # test.py:46
-    model = df.instantiate(cfg).to(DEV)                                   # test.py:47  instantiate(cfg.model)
-    syn.fill_state_dict(model.ae_net.dinov2_model, 11)                    # no network for gigaPose_v1.ckpt: deterministic random weights
-    syn.fill_state_dict(model.ist_net, 12)
-    model.set_numerics("split")
+_MODELS = {}
+
+
+def build_from_reference_cfg(log_dir, numerics, accumulate):
+    """instantiate(cfg.model) from the reference's own (resolved, target-swapped) config.  One ViT-L instance per numerics for the
+    whole module (303 M random parameters each); a later call only re-points log_dir and the accumulation key."""
+    if numerics not in _MODELS:
+        cfg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "model_cfg_resolved.json")))
+        cfg["log_dir"] = str(log_dir)
+        cfg["test_setting"] = "localization"                              # test.py:46
+        cfg["accumulate_crops"] = accumulate                              # INTEGRATION.md: optional key next to `numerics`
+        model = df.instantiate(cfg).to(DEV)                               # test.py:47  instantiate(cfg.model)
+        assert model.accumulate_crops == accumulate
+        syn.fill_state_dict(model.ae_net.dinov2_model, 11)                # no network for gigaPose_v1.ckpt: deterministic random weights
+        syn.fill_state_dict(model.ist_net, 12)
+        model.set_numerics(numerics)
+        _MODELS[numerics] = model
+    model = _MODELS[numerics]
+    model.log_dir, model.accumulate_crops = str(log_dir), accumulate
+    os.makedirs(os.path.join(model.log_dir, "predictions"), exist_ok=True)
+    return model
+
+
+@pytest.mark.parametrize("numerics,accumulate", [("split", 64), ("split", 0), ("chain", 64), ("chain", 0)])
+def test_reference_test_py_flow_from_the_reference_model_config(tmp_path, numerics, accumulate):
+    """Both numerics (the product default `split` AND the verification mode), with the cross-image accumulation of test_step on (the
+    default: 64) and off (the reference's one-predict-per-image flow)."""
+    model = build_from_reference_cfg(tmp_path, numerics, accumulate)
+    assert model.accumulate_crops == accumulate
     tset = factory.TemplateSet(2, 12, seed=90)
     model.template_datasets = {"syn": tset}                               # test.py:67-74
     model.test_dataset_name = "syn"
@@ -58,8 +79,13 @@ def test_reference_test_py_flow_from_the_reference_model_config(tmp_path):
     assert len(top1) == 5 + 9 and len(multi) == (5 + 9) * 5 and set(top1.im_id) == {3, 4}
     # the csv carries the poses of a direct predict() on the same detections (localization mode keeps all of them here)
     row = 0
+    if accumulate:   # one predict over both images (5 + 9 < 64 crops: flushed by on_test_epoch_end) -- the same batch composition
+        cat = {k: torch.cat([q[k] for _, q in batches]) for k in ["tar_img", "tar_mask", "tar_K", "tar_M", "labels"]}
+        p_all = model.predict(cat["tar_img"], cat["tar_mask"], cat["tar_K"], cat["tar_M"], cat["labels"], "syn")
+    first = 0
     for (batch, q), n in zip(batches, (5, 9)):
-        p = model.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
+        p = p_all[list(range(first, first + n))] if accumulate else model.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
+        first += n
         poses, labels = p.pred_poses[:, 0].cpu().numpy(), q["labels"].numpy()
         sel = []
         for o in sorted(set(int(l) for l in labels)):                     # filter_and_save groups by object id (gigaPose.py:408-425)
@@ -73,3 +99,66 @@ def test_reference_test_py_flow_from_the_reference_model_config(tmp_path):
             assert int(top1.obj_id[row]) == int(labels[d])
             row += 1
     assert row == len(top1)
+
+
+def _run_flow(log_dir, numerics, accumulate, sizes, n_obj=2, n_tmpl=12):
+    model = build_from_reference_cfg(log_dir, numerics, accumulate)
+    tset = factory.TemplateSet(n_obj, n_tmpl, seed=90)
+    model.template_datasets = {"syn": tset}
+    model.test_dataset_name = "syn"
+    model.max_num_dets_per_forward = 4
+    model.run_id = "r0"
+    batches = [image_batch(tset, 300 + i, n, view_id=20 + i)[0] for i, n in enumerate(sizes)]
+    df.trainer_test(model, batches)
+    pred_dir = os.path.join(str(log_dir), "predictions")
+    files = {}
+    for i in range(len(sizes)):
+        with np.load(os.path.join(pred_dir, f"{i}.npz")) as z:
+            files[i] = {k: z[k] for k in z.files}
+    csvs = {f: pd.read_csv(os.path.join(pred_dir, f)) for f in sorted(os.listdir(pred_dir)) if f.endswith(".csv")}
+    return files, csvs
+
+
+SIZES = [5, 9, 3, 7, 12, 4, 8]
+
+
+def test_accumulated_test_steps_write_the_files_of_the_per_image_flow_chain(tmp_path):
+    """Crops are independent until filter_and_save (reference gigaPose.py:408-425), and in `chain` numerics every dot product is
+    a fixed fmaf chain whatever the batch: the npz files and the BOP csv written by the accumulated flow (whole images, one predict
+    per >= 16 pending crops here) equal the per-image flow's BYTE FOR BYTE except the `time` field / column (the flush's device time
+    apportioned by crop count instead of the image's own wall time)."""
+    a_files, a_csv = _run_flow(tmp_path / "per_image", "chain", 0, SIZES)
+    b_files, b_csv = _run_flow(tmp_path / "accumulated", "chain", 16, SIZES)
+    for i, n in enumerate(SIZES):
+        assert sorted(a_files[i]) == sorted(b_files[i])
+        for key in a_files[i]:
+            assert a_files[i][key].dtype == b_files[i][key].dtype and a_files[i][key].shape == b_files[i][key].shape
+            if key != "time":
+                assert a_files[i][key].tobytes() == b_files[i][key].tobytes(), f"image {i}: {key}"
+        assert (b_files[i]["time"] > 0).all() and len(set(b_files[i]["time"].tolist())) == 1
+    assert list(a_csv) == list(b_csv) and len(a_csv) == 2
+    for name in a_csv:
+        ca, cb = a_csv[name], b_csv[name]
+        assert list(ca.columns) == list(cb.columns) and len(ca) == len(cb)
+        for col in ca.columns:
+            if col != "time":
+                assert ca[col].tolist() == cb[col].tolist(), f"{name}: column {col}"
+
+
+def test_accumulated_test_steps_in_split_numerics(tmp_path):
+    """`split` (the product default): a crop's ViT round-off depends on the GEMM partition its batch selects (tile / ragged strip /
+    parallel split-K), as any GPU BLAS does -- the accumulated flow's files agree with the per-image flow's within f32 round-off:
+    same detections kept, inlier scores equal for nearly all hypotheses, poses within 1e-4 where the score is."""
+    a_files, _ = _run_flow(tmp_path / "per_image", "split", 0, SIZES)
+    b_files, _ = _run_flow(tmp_path / "accumulated", "split", 64, SIZES)
+    same = total = 0
+    for i in range(len(SIZES)):
+        for key in ("scene_id", "im_id", "object_id", "detection_time"):
+            np.testing.assert_array_equal(a_files[i][key], b_files[i][key])
+        eq = a_files[i]["scores"] == b_files[i]["scores"]
+        same += int(eq.sum())
+        total += eq.size
+        pa, pb = a_files[i]["poses"][eq], b_files[i]["poses"][eq]
+        close = np.abs(pa - pb).reshape(len(pa), -1).max(1) <= 1e-4 * (1 + np.abs(pa).reshape(len(pa), -1).max(1))
+        assert close.mean() >= 0.9, f"image {i}: {int((~close).sum())} of {len(close)} equal-score hypotheses moved (a RANSAC tie at 14.000 px moves a few)"
+    assert same >= 0.9 * total, f"{same} / {total} hypothesis scores equal"

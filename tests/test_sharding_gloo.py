@@ -209,6 +209,42 @@ def test_sharded_matcher_class_world4_uneven_shards():
     assert len(owners) >= 3, "the winners come from fewer than three shards: the four-way merge was not exercised"
 
 
+@pytest.mark.timeout(600)
+def test_sharded_matcher_class_world8_x_162_templates_the_north_star_partition():
+    """north_star's own partition (the reference has no counterpart): 8 ranks x 162 templates per object -> two shards of
+    21 and six of 20 (rank r starts at ceil(162 r / 8)); two crops per rank over two objects; exchange #1 (all-gather of query rows), the per-shard match +
+    local top-k, exchange #2 (all-to-all of candidate records) and the 8-way merge must equal the unsharded top-5 over all 162 bit for
+    bit, and the winners must come from at least four different shards."""
+    world, k, N = 8, 5, 162
+    sizes = [sharding.shard_bounds(N, world, r)[1] - sharding.shard_bounds(N, world, r)[0] for r in range(world)]
+    # SURVEY 8(e): rank r holds templates [ceil(162 r / 8), ceil(162 (r + 1) / 8)): two shards of 21, six of 20
+    assert [sharding.shard_bounds(N, world, r)[0] for r in range(world)] == [-(-N * r // world) for r in range(world)]
+    assert sorted(sizes, reverse=True) == [21, 21, 20, 20, 20, 20, 20, 20]
+    case = syn.matcher_case(seed=80, B=16, O=2, N=N, C=32)
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    keep = {v: os.environ.get(v) for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+    os.environ.update(OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")   # eight ranks on the build container's eight cores: one thread each
+    try:
+        mp.spawn(_class_worker, args=(world, _free_port(), case, k, ret), nprocs=world, join=True)
+    finally:
+        for v, old in keep.items():
+            os.environ.pop(v, None) if old is None else os.environ.__setitem__(v, old)
+    full = oracle.local_similarity_test(case["src_feats"], case["tar_feat"], case["src_masks"], case["tar_mask"], case["labels"], k)
+    winners = set()
+    for rank in range(world):
+        own = slice(rank * 2, rank * 2 + 2)
+        r = ret[rank]
+        assert ret[f"reject{rank}"]
+        for name in ["id_src", "tar_pts", "src_pts"]:
+            np.testing.assert_array_equal(r[name], full[name][own], err_msg=f"rank {rank}: {name}")
+        for name in ["score_src", "score_pts"]:
+            np.testing.assert_array_equal(r[name].view(np.uint32), full[name][own].view(np.uint32), err_msg=f"rank {rank}: {name}")
+        winners.update(int(t) for t in r["id_src"].ravel())
+    owners = {next(w for w in range(world) if sharding.shard_bounds(N, world, w)[0] <= t < sharding.shard_bounds(N, world, w)[1]) for t in winners}
+    assert len(owners) >= 4, f"the winners come from {len(owners)} shards only: the eight-way merge was not exercised"
+
+
 def test_pack_unpack_query_roundtrip():
     rs = np.random.RandomState(1)
     qm = torch.from_numpy(rs.rand(3, 256).astype(np.float32))

@@ -42,6 +42,26 @@ struct GpLnFold {
     int ld; float eps;
 };
 
+// Plane producers (LayerNorm, the plane epilogues 6 / 7 of gp_split256.hip, attention): the power of two a tensor is multiplied
+// by before it is split into its f16 hi / lo planes (default 8: |x| < 8190), and -- calibration passes only -- where to record
+// max |x| of what was written (f32 bits, atomic max; gp_vit_forward_split2).  Per tensor, chosen by the host (vit.py).
+struct GpPlaneOut {
+    float scale;   // power of two
+    float* amax;   // device float or null
+};
+__device__ __forceinline__ void gp_record_amax(float* amax, float mx_scaled, float inv_scale)
+{
+    // mx_scaled >= 0 or NaN.  Wave maximum first (one atomic per wave); non-negative floats order like their bit patterns, a NaN's
+    // pattern lies above every finite one
+    float m = mx_scaled;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float o = __shfl_xor(m, off);
+        m = (o > m || o != o) ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(m * inv_scale));
+}
+
 // set by every entry point on failure; read through gp_last_error()
 void gp_set_error(const char* fmt, ...);
 

@@ -386,6 +386,8 @@ struct ArgsP {
     float* st_main; float* st_strip;               // producer (10): statistics of the rows it writes
     int st_ld; float ln_eps;
     int j_valid;                                   // rows of B that carry data (the last strip fragment may reach beyond them)
+    float plane_scale;                             // plane epilogues 6 / 7: the output tensor's power-of-two scale (default kActScale = 8)
+    float* amax;                                   // calibration launches: max |x| of the planes written (null otherwise)
 };
 
 __device__ __forceinline__ float lane_bcast(float v, int lane)  // value held by `lane` (compile-time constant) -> SGPR
@@ -555,7 +557,8 @@ __device__ __forceinline__ float sum8_lanes(float v)
     v = v + dpp_mov<0x141>(v);  // row_half_mirror: lane i <- lane 7 - i of its group of 8 (every lane of a quad holds the quad's sum)
     return v;
 }
-__device__ __forceinline__ float gelu_fast_x8(float x)  // 8 * gelu_fast(x), bit for bit (the factor folded into the exact 0.5 x)
+// 2 hs * gelu_fast(x), bit for bit (the plane scale folded into the exact 0.5 x); hs = half the plane scale (4 for the default x 8)
+__device__ __forceinline__ float gelu_fast_x8(float x, float hs = 0.5f * kActScale)
 {
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
@@ -569,7 +572,7 @@ __device__ __forceinline__ float gelu_fast_x8(float x)  // 8 * gelu_fast(x), bit
     p = fmaf(p, t, 0.17245176856740801f);
     p = fmaf(p, t, 0.18564199446374482f);
     const float c = p * t * __expf(-z * z);
-    return (0.5f * kActScale) * x * (x >= 0.f ? 2.0f - c : c);
+    return hs * x * (x >= 0.f ? 2.0f - c : c);
 }
 
 // The plane epilogues 6 / 7: planes O[j][i] (x 8, hi + lo) of bias_i + out_scale acc [6: through GELU].  Round h = columns 64 h .. 64 h + 63
@@ -584,7 +587,7 @@ __device__ __forceinline__ void epilogue_planes_thin(const ArgsP& a, f32x16 (&ac
 {
     const int l31 = ln & 31, half = ln >> 5;
     constexpr bool kGelu = EPI == PEPI_GELU_PLANES;
-    constexpr float k8 = kGelu ? 1.0f : kActScale;
+    const float k8 = kGelu ? 1.0f : a.plane_scale, hs = 0.5f * a.plane_scale;  // the output tensor's power-of-two scale (8 by default)
     const __amdgpu_buffer_rsrc_t r_hi = __builtin_amdgcn_make_buffer_rsrc((void*)a.ohi, 0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_lo = __builtin_amdgcn_make_buffer_rsrc((void*)a.olo, 0, 0x7ffffff0, 0x00020000);
     const unsigned v_pl = ((unsigned)(j_base + (ln >> 3)) * (unsigned)a.ldo + (unsigned)(i_base + 8 * (ln & 7))) * 2u;
@@ -608,7 +611,7 @@ __device__ __forceinline__ void epilogue_planes_thin(const ArgsP& a, f32x16 (&ac
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float x = __builtin_fmaf(acc[mi][ni][4 * r4 + e], A, bq[e]);
-                        v[e] = kGelu ? gelu_fast_x8(x) : x;
+                        v[e] = kGelu ? gelu_fast_x8(x, hs) : x;
                     }
                     u32x2 oh, ol;
                     oh[0] = pack_hi_pair(v[0], v[1]);
@@ -631,6 +634,7 @@ __device__ __forceinline__ void epilogue_planes_thin(const ArgsP& a, f32x16 (&ac
         }
     }
     if (!(mx <= kSplitPlaneLimit)) gp_raise(a.status, GP_ST_SPLIT_RANGE);  // !(<=): NaN counts (v_maximum3 propagates it)
+    if (a.amax) gp_record_amax(a.amax, mx, 1.0f / a.plane_scale);          // calibration launches only (wave-uniform branch)
 }
 
 // Consumer of a folded LayerNorm (8 / 9): planes of  r_j (acc - mu_j s_i) + b'_i  [9: through GELU], the LDS turn and the stores of
@@ -1010,6 +1014,7 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
             // per-element arithmetic of the tile epilogues, direct stores (a few KB per launch)
             const int j = j0 + l31;
             int bad = 0;
+            float strip_mx = 0.f;          // 6 / 7: max |scaled value| this lane wrote (calibration launches record it)
             float st_s = 0.f, st_q = 0.f;  // 10: this lane's 16 channels of token j
             // the folded-LayerNorm epilogues fetch their extra operands HERE, after the K loop (one exposed round trip per fragment,
             // a few fragments per launch): requested before it they are 40 more registers next to the loop's 128 and the kernel spills
@@ -1074,11 +1079,12 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float x = acc[4 * r4 + e] * a.out_scale + pre_bias[r4][e];
-                        const float v = (EPI == PEPI_GELU_PLANES ? gelu_x(x) : x) * kActScale;
+                        const float v = (EPI == PEPI_GELU_PLANES ? gelu_x(x) : x) * a.plane_scale;
                         const _Float16 hh = (_Float16)v;
                         oh[e] = hh;
                         ol[e] = (_Float16)(v - (float)hh);
                         bad |= !(fabsf(v) <= kSplitPlaneLimit);
+                        strip_mx = __builtin_elementwise_maximum(strip_mx, __builtin_fabsf(v));
                     }
                     const size_t o = (size_t)(unsigned)j * (unsigned)a.ldo + (unsigned)i;
                     *reinterpret_cast<g16x4*>(a.ohi + o) = oh;
@@ -1108,6 +1114,7 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
                 }
             }
             if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE);
+            if ((EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES) && a.amax) gp_record_amax(a.amax, strip_mx, 1.0f / a.plane_scale);
         }
         __syncthreads();  // `red` and *next_f are rewritten for the next fragment
     }
@@ -1516,7 +1523,7 @@ int gp_gemm_split256_launch(const float* act, int ld_act, const void* whi, const
 int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
                                 void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
                                 const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace,
-                                const GpLnFold* ln);
+                                const GpLnFold* ln, const GpPlaneOut* po = nullptr);
 static int g_planes_dp = 1;  // 1: data-parallel rounds before the stream-K remainder (0: everything stream-K; A/B hook)
 
 // internal entry (gp_vit.hip): D[i][j] = epi( out_scale * sum_k A[i][k] B[j][k] ), A / B = pre-split planes (see above)
@@ -1553,10 +1560,11 @@ bool gp_gemm_planes256_usable(int I, int J, int J_valid, int K)
 
 int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
                              void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
-                             const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace)
+                             const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace,
+                             const GpPlaneOut* po = nullptr)
 {
     return gp_gemm_planes256_launch_ln(ahi, alo, bhi, blo, D, ldd, ohi, olo, ldo, I, J, J_valid, K, epilogue, bias, scale, res, ldr, out_scale,
-                                       scratch, st, trace, nullptr);
+                                       scratch, st, trace, nullptr, po);
 }
 
 // + the folded-LayerNorm epilogues (8, 9: consumer -- ln->ln_main / ln_strip hold the statistics of B's rows, bias = b', scale = s;
@@ -1564,7 +1572,7 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
 int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
                                 void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
                                 const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace,
-                                const GpLnFold* ln)
+                                const GpLnFold* ln, const GpPlaneOut* po)
 {
     GP_REQUIRE(gp_gemm_planes256_usable(I, J, J_valid, K),
                "gp_gemm_planes256: I=%d, J=%d must be multiples of 256 with >= 8 tiles below J_valid=%d, K=%d of 32", I, J, J_valid, K);
@@ -1599,6 +1607,14 @@ int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bh
             reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, out_scale, g_planes_dp, trace, gp_status_buffer(),
             J_main, strip_fj, (long long)(I / TB) * (J_main / TB) < kSlots ? max(1, (K / TBK) / g_planes_par_min_steps) : 0};
     a.j_valid = (J_valid > 0 && J_valid < J) ? J_valid : J;
+    a.plane_scale = kActScale;
+    a.amax = nullptr;
+    if (po) {   // per-tensor output scale of the plane epilogues 6 / 7 (the folded-LayerNorm epilogues keep the default)
+        GP_REQUIRE(po->scale > 0.f && (epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES || (po->scale == kActScale && !po->amax)),
+                   "gp_gemm_planes256: a plane scale other than 8 needs epilogue 6 or 7 (got %d)", epilogue);
+        a.plane_scale = po->scale;
+        a.amax = po->amax;
+    }
     if (ln) {
         a.ln_main = ln->ln_main; a.ln_strip = ln->ln_strip; a.st_main = ln->st_main; a.st_strip = ln->st_strip;
         a.st_ld = ln->ld; a.ln_eps = ln->eps;
@@ -1750,6 +1766,20 @@ int gp_gemm_planes256_ragged(const void* a_hi, const void* a_lo, const void* b_h
     if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
     return gp_gemm_planes256_launch(a_hi, a_lo, b_hi, b_lo, D, ldd, out_hi, out_lo, ldo, I, J, J_valid, K, epilogue, bias, scale, residual, ldr,
                                     out_scale, scratch, (hipStream_t)stream, nullptr);
+}
+
+/* gp_gemm_planes256_ragged with the output tensor's plane scale (a power of two; epilogues 6 / 7; the consumer GEMM then runs with
+ * out_scale = 1 / (plane_scale * 64)) and, for calibration passes, a device float that receives max |x| of the planes written. */
+int gp_gemm_planes256_scaled(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
+                             void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
+                             const float* residual, int ldr, float out_scale, float plane_scale, float* amax, float* scratch,
+                             size_t scratch_bytes, void* stream)
+{
+    GP_REQUIRE(scratch && scratch_bytes >= gp_gemm_split256_scratch_bytes(), "gp_gemm_planes256_scaled: scratch too small");
+    if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
+    const GpPlaneOut po{plane_scale, amax};
+    return gp_gemm_planes256_launch(a_hi, a_lo, b_hi, b_lo, D, ldd, out_hi, out_lo, ldo, I, J, J_valid, K, epilogue, bias, scale, residual, ldr,
+                                    out_scale, scratch, (hipStream_t)stream, nullptr, &po);
 }
 
 int gp_gemm_planes256_ln(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi, void* out_lo,

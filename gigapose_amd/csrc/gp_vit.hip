@@ -27,12 +27,13 @@ bool gp_gemm_split256_usable(int I, int J, int K);
 bool gp_gemm_planes256_usable(int I, int J, int J_valid, int K);
 int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
                              void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
-                             const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace = nullptr);
+                             const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace = nullptr,
+                             const GpPlaneOut* po = nullptr);
 
 int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
                                 void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
                                 const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace,
-                                const GpLnFold* ln);
+                                const GpLnFold* ln, const GpPlaneOut* po = nullptr);
 
 namespace {
 
@@ -155,13 +156,14 @@ constexpr float kPlaneScale = 8.0f;  // == kActScale of gp_split256.hip
 __global__ __launch_bounds__(1024) void layernorm_planes_kernel(const float* __restrict__ X, _Float16* __restrict__ Yhi,
                                                                  _Float16* __restrict__ Ylo, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, int C, int Mpad, float eps,
-                                                                 int* __restrict__ status)
+                                                                 int* __restrict__ status, float plane_scale, float* __restrict__ amax)
 {
     __shared__ float red[16][64];
     const int tok = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int per = C >> 4, c0 = sl * per;
     const float* x = X + (size_t)c0 * Mpad + (size_t)blockIdx.x * 64 + tok;
     int bad = 0;  // range guard of the x 8 planes (gp_common.h: GP_ST_SPLIT_RANGE)
+    float vmax = 0.f;
     float s = 0.f;
 #pragma unroll 8
     for (int i = 0; i < per; ++i) s += x[(size_t)i * Mpad];
@@ -200,10 +202,11 @@ __global__ __launch_bounds__(1024) void layernorm_planes_kernel(const float* __r
         for (int e = 0; e < 8; ++e) {
             const int cl = 8 * sl + e, c = 128 * k + cl;
             const float y = (xb[(size_t)c * Mpad] - mean) * rstd * gamma[c] + beta[c];
-            const float v = y * kPlaneScale;
+            const float v = y * plane_scale;
             const _Float16 hh = (_Float16)v;
             const _Float16 ll = (_Float16)(v - (float)hh);
             bad |= !(fabsf(v) <= kSplitPlaneLimit);  // !(<=): a NaN / inf residual stream counts
+            vmax = __builtin_elementwise_maximum(vmax, __builtin_fabsf(v));
             T[cl * 65 + tok] = (unsigned int)__builtin_bit_cast(unsigned short, hh) |
                                ((unsigned int)__builtin_bit_cast(unsigned short, ll) << 16);
         }
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(1024) void layernorm_planes_kernel(const float* __r
         *reinterpret_cast<v16x8*>(Ylo + row + 128 * k) = l;
     }
     if (bad) gp_raise(status, GP_ST_SPLIT_RANGE);
+    if (amax) gp_record_amax(amax, vmax, 1.0f / plane_scale);
 }
 
 // Second version: X is read ONCE.  Block = 32 tokens x 16 channel slices (512 threads, two blocks per CU); thread (tok, sl)
@@ -232,7 +236,7 @@ template <int NK>
 __global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* __restrict__ X, _Float16* __restrict__ Yhi,
                                                                     _Float16* __restrict__ Ylo, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, int Mpad, float eps,
-                                                                    int* __restrict__ status)
+                                                                    int* __restrict__ status, float plane_scale, float* __restrict__ amax)
 {
     constexpr int C = 128 * NK, TP = 132;  // LDS row pitch in words: 16-byte aligned pieces, tokens 33 sixteen-byte slots apart
     __shared__ float red[16][32];
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* 
     const int g2 = threadIdx.x & 15, t2 = threadIdx.x >> 4;  // store phase: 16 lanes = the 16 eight-channel pieces of token t2
     const size_t row = (tok0 + t2) * C + 8 * g2;
     int bad = 0;
+    float vmax = 0.f;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         unsigned int* T = tile[k & 1];
@@ -290,10 +295,11 @@ __global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float y = (xv[k][e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
-            const float v = y * kPlaneScale;
+            const float v = y * plane_scale;   // the tensor's power-of-two scale (8 unless calibrated otherwise): exact
             const _Float16 hh = (_Float16)v;
             const _Float16 ll = (_Float16)(v - (float)hh);
             bad |= !(fabsf(v) <= kSplitPlaneLimit);  // !(<=): a NaN / inf residual stream counts
+            if (amax) vmax = __builtin_elementwise_maximum(vmax, __builtin_fabsf(v));   // calibration passes only (uniform branch)
             w[e] = (unsigned int)__builtin_bit_cast(unsigned short, hh) | ((unsigned int)__builtin_bit_cast(unsigned short, ll) << 16);
         }
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -314,6 +320,7 @@ __global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* 
         *reinterpret_cast<v16x8*>(Ylo + row + 128 * k) = l;
     }
     if (bad) gp_raise(status, GP_ST_SPLIT_RANGE);
+    if (amax) gp_record_amax(amax, vmax, 1.0f / plane_scale);
 }
 
 // ---- Folded LayerNorm (gp_split256.hip, epilogues 8-10): entry and exit of the token-major residual stream.
@@ -418,15 +425,15 @@ static int g_ln_planes_reg = 1;  // A/B hook (gp_vit_set_ln_reg): 0 = the three-
 extern "C" void gp_vit_set_ln_reg(int on) { g_ln_planes_reg = on ? 1 : 0; }
 
 int launch_layernorm_planes(const float* X, _Float16* hi, _Float16* lo, const float* g, const float* b, int C, int Mpad, float eps,
-                            hipStream_t st)
+                            hipStream_t st, float plane_scale = kPlaneScale, float* amax = nullptr)
 {
     GpProfScope prof(GP_PROF_LN, 8.0 * C * Mpad, st);
     if (g_ln_planes_reg && C == 1024 && Mpad % 32 == 0)
-        hipLaunchKernelGGL(layernorm_planes_reg_kernel<8>, dim3(Mpad / 32), dim3(512), 0, st, X, hi, lo, g, b, Mpad, eps, gp_status_buffer());
+        hipLaunchKernelGGL(layernorm_planes_reg_kernel<8>, dim3(Mpad / 32), dim3(512), 0, st, X, hi, lo, g, b, Mpad, eps, gp_status_buffer(), plane_scale, amax);
     else if (g_ln_planes_reg && C == 768 && Mpad % 32 == 0)
-        hipLaunchKernelGGL(layernorm_planes_reg_kernel<6>, dim3(Mpad / 32), dim3(512), 0, st, X, hi, lo, g, b, Mpad, eps, gp_status_buffer());
+        hipLaunchKernelGGL(layernorm_planes_reg_kernel<6>, dim3(Mpad / 32), dim3(512), 0, st, X, hi, lo, g, b, Mpad, eps, gp_status_buffer(), plane_scale, amax);
     else
-        hipLaunchKernelGGL(layernorm_planes_kernel, dim3(Mpad / 64), dim3(1024), 0, st, X, hi, lo, g, b, C, Mpad, eps, gp_status_buffer());
+        hipLaunchKernelGGL(layernorm_planes_kernel, dim3(Mpad / 64), dim3(1024), 0, st, X, hi, lo, g, b, C, Mpad, eps, gp_status_buffer(), plane_scale, amax);
     return 0;
 }
 
@@ -658,8 +665,8 @@ constexpr int ATH = 512;  // threads: eight waves = the eight full 32-query tile
 
 __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __restrict__ QKVhi, const _Float16* __restrict__ QKVlo,
                                                                _Float16* __restrict__ Ohi, _Float16* __restrict__ Olo, int B, int H,
-                                                               int C, int Mpad, int probe)
-{
+                                                               int C, int Mpad, int probe, float inv_s2)
+{   // inv_s2 = 1 / s^2, s = the power-of-two scale the q | k | v planes carry (1 / 64 for the default x 8); the output planes carry s too
     __shared__ __attribute__((aligned(16))) _Float16 sm[2 * AKEYS * AKS + 2 * 64 * AVS];  // 157,696 bytes
     __shared__ __attribute__((aligned(16))) float xq[64], xs[T_TOK + 3], xred[2][8], xo[8][64];  // the 257th query's VALU path
     _Float16* sKh = sm;
@@ -750,7 +757,7 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a = __builtin_fmaf((float)h8[e] + (float)l8[e], xq[8 * c8 + e], a);
             }
-            sv = a * (0.125f / 64.0f);
+            sv = a * (0.125f * inv_s2);
         }
         float mx = sv;
 #pragma unroll
@@ -814,7 +821,7 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
     // units at the largest |v| that matters, i.e. ~1e-6 relative in p) -- the same error the reference's f32 softmax has in
     // x = (q.k) * scale before its exp; the compensated exp_neg of the f32 kernels costs 6 more VALU instructions per
     // element, and this loop is bound by VALU issue (SQ_ACTIVE_INST_VALU 52 % vs matrix pipe 26 %, profiles/r02_pmc_attention.txt).
-    const float s_scale = (0.125f / 64.0f) * 1.4426950408889634f;
+    const float s_scale = (0.125f * inv_s2) * 1.4426950408889634f;
 
 #pragma unroll 1
     for (int ch = 0; ch < 3; ++ch) {
@@ -1137,14 +1144,28 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
                          const float* const* weights, int n_weights, const void* const* split, int n_split,
                          float* workspace, size_t workspace_bytes, float* out_features, int normalize,
                          int stop_after_layers, void* stream);
+int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
+                          const float* const* weights, int n_weights, const void* const* split, int n_split,
+                          float* workspace, size_t workspace_bytes, float* out_features, int normalize,
+                          int stop_after_layers, const float* plane_scales, float* plane_amax, void* stream);
 
+int gp_attention_split_scaled(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
+                              float qkv_scale, void* stream);
 int gp_attention_split(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
                        void* stream)
 {
+    return gp_attention_split_scaled(qkv_hi, qkv_lo, out_hi, out_lo, B, heads, dim, Mpad, kPlaneScale, stream);
+}
+
+/* q | k | v planes (and the output planes) carry the power-of-two `qkv_scale` instead of the default 8 */
+int gp_attention_split_scaled(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
+                              float qkv_scale, void* stream)
+{
+    GP_REQUIRE(qkv_scale > 0.f, "gp_attention_split: bad plane scale");
     GP_REQUIRE(qkv_hi && qkv_lo && out_hi && out_lo && B > 0 && heads > 0 && dim == heads * 64 && Mpad >= B * T_TOK,
                "gp_attention_split: bad arguments");
     hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(ATH), 0, (hipStream_t)stream,
-                       (const _Float16*)qkv_hi, (const _Float16*)qkv_lo, (_Float16*)out_hi, (_Float16*)out_lo, B, heads, dim, Mpad, g_attn_probe);
+                       (const _Float16*)qkv_hi, (const _Float16*)qkv_lo, (_Float16*)out_hi, (_Float16*)out_lo, B, heads, dim, Mpad, g_attn_probe, 1.0f / (qkv_scale * qkv_scale));
     GP_CHECK_LAUNCH("gp_attention_split");
     return GP_OK;
 }
@@ -1191,7 +1212,36 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
                          float* workspace, size_t workspace_bytes, float* out_features, int normalize,
                          int stop_after_layers, void* stream)
 {
+    return gp_vit_forward_split2(images, B, dim, depth, heads, mlp_dim, ln_eps, weights, n_weights, split, n_split, workspace, workspace_bytes,
+                                 out_features, normalize, stop_after_layers, nullptr, nullptr, stream);
+}
+
+/* gp_vit_forward_split with PER-TENSOR plane scales (round 5).  The plane path keeps four activation tensors per layer as f16 hi / lo
+ * planes of s x: LayerNorm-1 output (PS_LN1), q | k | v and the attention output (PS_QKV: the attention output is a convex combination
+ * of v rows, so it shares their range), LayerNorm-2 output (PS_LN2), GELU output (PS_GELU).  s was a compile-time 8 (|x| < 8190): one
+ * outlier anywhere in a real checkpoint -- DINOv2 is known for a few massive activations -- sent the WHOLE ViT to the two-accumulator
+ * 128 x 128 kernels (-43 %).  Now s is a power of two per (layer, tensor):
+ *   plane_scales  host array [depth][4] (PS_* order), or null = all 8 (bit-identical to gp_vit_forward_split);
+ *   plane_amax    device array [depth][4] of f32 or null: a CALIBRATION pass -- every plane producer records max |x| of what it wrote
+ *                 (atomic max on the f32 bits; zero it first), from which the host picks the scales (vit.py: calibrate_plane_scales).
+ * A smaller scale only moves the f16 subnormal floor of the lo plane up (absolute error 2^-25 / s per element instead of 2^-28); the
+ * consumers undo it exactly (out_scale = 1 / (64 s)), so with all scales 8 nothing changes.  Shapes that do not take the plane path
+ * (f32 activations, 128 x 128 kernels: range 65504) ignore both arrays. */
+int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
+                          const float* const* weights, int n_weights, const void* const* split, int n_split,
+                          float* workspace, size_t workspace_bytes, float* out_features, int normalize,
+                          int stop_after_layers, const float* plane_scales, float* plane_amax, void* stream)
+{
     hipStream_t st = (hipStream_t)stream;
+    enum { PS_LN1 = 0, PS_QKV, PS_LN2, PS_GELU, PS_PER_LAYER = 4 };
+    bool default_scales = true;
+    if (plane_scales)
+        for (int i = 0; i < depth * PS_PER_LAYER; ++i) {
+            int ex = 0;
+            GP_REQUIRE(plane_scales[i] > 0.f && frexpf(plane_scales[i], &ex) == 0.5f && plane_scales[i] <= 64.f && plane_scales[i] >= 1.0f / 1024.0f,
+                       "gp_vit_forward_split2: plane scale %d = %g is not a power of two in [2^-10, 64]", i, (double)plane_scales[i]);
+            default_scales = default_scales && plane_scales[i] == kPlaneScale;
+        }
     GP_REQUIRE(B >= 0 && dim > 0 && depth > 0 && heads > 0, "gp_vit_forward: bad config");
     if (B == 0) return GP_OK;
     GP_REQUIRE(dim == heads * 64, "gp_vit_forward: head dim must be 64 (dim=%d heads=%d)", dim, heads);
@@ -1251,7 +1301,8 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
     // producer epilogue reads one and writes the other: no load waits for a store); its raw planes (what the next GEMM multiplies)
     // are written by proj into the (dead) q|k|v region and by fc2 into the (dead) attention-output region.
     const bool fold = planes && have_fold && g_ln_fold && g_vit_planes == 2 && nl > 0 && C % 256 == 0 && (C == 1024 || C == 768) &&
-                      gp_gemm_planes256_usable(3 * C, Mpad, Mtok, C);
+                      gp_gemm_planes256_usable(3 * C, Mpad, Mtok, C) && default_scales && !plane_amax;   // the folded epilogues keep the x 8
+    GP_REQUIRE(g_vit_planes == 2 || !planes || (default_scales && !plane_amax), "gp_vit_forward_split2: plane scales need the full plane path (gp_vit_set_planes(2))");
     if (fold) {
         float* X2 = reinterpret_cast<float*>(reinterpret_cast<char*>(SK) + fold_offset(gp_gemm_streamk_bytes()));
         float* st_main = X2 + (size_t)C * Mpad;
@@ -1291,7 +1342,7 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
                 return rc;
             {
                 GpProfScope prof(GP_PROF_ATTN, 4.0 * B * heads * 257.0 * 257.0 * 64.0, st);
-                hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(ATH), 0, st, Ahi, Alo, Hhi, Hlo, B, heads, C, Mpad, 0);
+                hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(ATH), 0, st, Ahi, Alo, Hhi, Hlo, B, heads, C, Mpad, 0, 1.0f / 64.0f);
             }
             GP_CHECK_LAUNCH("gp_vit_forward/attention_split");
             // x = x + ls1 * proj(attn): token-major f32 + raw planes (into the q | k | v region) + statistics
@@ -1317,11 +1368,18 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
         _Float16* Hlo = Hhi + (size_t)C * Mpad;
         _Float16* Fhi = reinterpret_cast<_Float16*>(F);
         _Float16* Flo = Fhi + (size_t)mlp_dim * Mpad;
-        const float os = 1.0f / (8.0f * 64.0f);  // activations x 8, weights x 64
+        const float ps_default[PS_PER_LAYER] = {kPlaneScale, kPlaneScale, kPlaneScale, kPlaneScale};
         for (int l = 0; l < nl; ++l) {
             const float* const* w = weights + W_HEADER + l * L_PER_LAYER;
             const void* const* sq = split + l * sp_stride + S_PER_LAYER;  // x64 weight planes [out][in]
-            launch_layernorm_planes(X, Hhi, Hlo, w[L_LN1_G], w[L_LN1_B], C, Mpad, ln_eps, st);
+            // this layer's plane scales (powers of two) and, in a calibration pass, where each tensor's max |x| goes
+            const float* ps = plane_scales ? plane_scales + l * PS_PER_LAYER : ps_default;
+            float* am = plane_amax ? plane_amax + l * PS_PER_LAYER : nullptr;
+            const float os = 1.0f / (kPlaneScale * 64.0f);  // g_vit_planes == 1 (probe path): activations x 8, weights x 64
+            const float os_ln1 = 1.0f / (ps[PS_LN1] * 64.0f), os_qkv = 1.0f / (ps[PS_QKV] * 64.0f), os_ln2 = 1.0f / (ps[PS_LN2] * 64.0f),
+                        os_gelu = 1.0f / (ps[PS_GELU] * 64.0f);   // a consumer undoes its B operand's scale and the weights' x 64, exactly
+            const GpPlaneOut po_qkv{ps[PS_QKV], am ? am + PS_QKV : nullptr}, po_gelu{ps[PS_GELU], am ? am + PS_GELU : nullptr};
+            launch_layernorm_planes(X, Hhi, Hlo, w[L_LN1_G], w[L_LN1_B], C, Mpad, ln_eps, st, ps[PS_LN1], am ? am + PS_LN1 : nullptr);
             GP_CHECK_LAUNCH("gp_vit_forward/layernorm_planes");
             if (g_vit_planes == 2) {
                 // Q | K | V as planes [Mpad][3C] (aliasing the f32 QK + Vt buffers): W_qk / W_v (A) x tokens (B), plane epilogue
@@ -1334,20 +1392,20 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
                                        gp_gemm_planes256_usable(3 * C, Mpad, Mtok, C);
                 if (fused_qkv) {
                     if ((rc = gp_gemm_planes256_launch(sq[S_QK_HI], sq[S_QK_LO], Hhi, Hlo, nullptr, 0, Ahi, Alo, 3 * C, 3 * C, Mpad, Mtok, C,
-                                                       7 /*BIAS_I -> planes*/, w[L_QK_B], nullptr, nullptr, 0, os, SK, st)))
+                                                       7 /*BIAS_I -> planes*/, w[L_QK_B], nullptr, nullptr, 0, os_ln1, SK, st, nullptr, &po_qkv)))
                         return rc;
                 } else {
                     if ((rc = gp_gemm_planes256_launch(sq[S_QK_HI], sq[S_QK_LO], Hhi, Hlo, nullptr, 0, Ahi, Alo, 3 * C, 2 * C, Mpad, Mtok, C,
-                                                       7 /*BIAS_I -> planes*/, w[L_QK_B], nullptr, nullptr, 0, os, SK, st)))
+                                                       7 /*BIAS_I -> planes*/, w[L_QK_B], nullptr, nullptr, 0, os_ln1, SK, st, nullptr, &po_qkv)))
                         return rc;
                     if ((rc = gp_gemm_planes256_launch(sq[S_V_HI], sq[S_V_LO], Hhi, Hlo, nullptr, 0, Ahi + 2 * C, Alo + 2 * C, 3 * C, C, Mpad, Mtok, C,
-                                                       7 /*BIAS_I -> planes*/, w[L_V_B], nullptr, nullptr, 0, os, SK, st)))
+                                                       7 /*BIAS_I -> planes*/, w[L_V_B], nullptr, nullptr, 0, os_ln1, SK, st, nullptr, &po_qkv)))
                         return rc;
                 }
                 {
                     GpProfScope prof(GP_PROF_ATTN, 4.0 * B * heads * 257.0 * 257.0 * 64.0, st);
                     hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(ATH), 0, st, Ahi, Alo, Hhi, Hlo, B,
-                                       heads, C, Mpad, 0);
+                                       heads, C, Mpad, 0, 1.0f / (ps[PS_QKV] * ps[PS_QKV]));
                 }
                 GP_CHECK_LAUNCH("gp_vit_forward/attention_split");
             } else {
@@ -1366,19 +1424,19 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
             }
             GP_CHECK_LAUNCH("gp_vit_forward/attention_planes");
             }
-            // x = x + ls1 * proj(attn)
+            // x = x + ls1 * proj(attn)   (the attention output carries the q | k | v scale; g_vit_planes == 1: the default x 8)
             if ((rc = gp_gemm_planes256_launch(sq[S_PROJ_HI], sq[S_PROJ_LO], Hhi, Hlo, X, Mpad, nullptr, nullptr, 0, C, Mpad, Mtok, C,
-                                               3 /*BIAS_I_SCALE_RES*/, w[L_PROJ_B], w[L_LS1], X, Mpad, os, SK, st)))
+                                               3 /*BIAS_I_SCALE_RES*/, w[L_PROJ_B], w[L_LS1], X, Mpad, g_vit_planes == 2 ? os_qkv : os, SK, st)))
                 return rc;
-            launch_layernorm_planes(X, Hhi, Hlo, w[L_LN2_G], w[L_LN2_B], C, Mpad, ln_eps, st);
+            launch_layernorm_planes(X, Hhi, Hlo, w[L_LN2_G], w[L_LN2_B], C, Mpad, ln_eps, st, ps[PS_LN2], am ? am + PS_LN2 : nullptr);
             GP_CHECK_LAUNCH("gp_vit_forward/layernorm_planes");
             // gelu(fc1(.)) straight to planes [Mpad][mlp_dim]
             if ((rc = gp_gemm_planes256_launch(sq[S_FC1_HI], sq[S_FC1_LO], Hhi, Hlo, nullptr, 0, Fhi, Flo, mlp_dim, mlp_dim, Mpad, Mtok, C,
-                                               6 /*GELU -> planes*/, w[L_FC1_B], nullptr, nullptr, 0, os, SK, st)))
+                                               6 /*GELU -> planes*/, w[L_FC1_B], nullptr, nullptr, 0, os_ln2, SK, st, nullptr, &po_gelu)))
                 return rc;
             // x = x + ls2 * fc2(.)
             if ((rc = gp_gemm_planes256_launch(sq[S_FC2_HI], sq[S_FC2_LO], Fhi, Flo, X, Mpad, nullptr, nullptr, 0, C, Mpad, Mtok, mlp_dim,
-                                               3 /*BIAS_I_SCALE_RES*/, w[L_FC2_B], w[L_LS2], X, Mpad, os, SK, st)))
+                                               3 /*BIAS_I_SCALE_RES*/, w[L_FC2_B], w[L_LS2], X, Mpad, os_gelu, SK, st)))
                 return rc;
         }
     }

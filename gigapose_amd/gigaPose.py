@@ -176,6 +176,41 @@ class GigaPose(_Base):
                 self.set_template_data(name)
         return bool(changed)
 
+    def _calibrate_planes(self, images):
+        """Run the ViT's plane-scale calibration (vit.py: calibrate_plane_scales) over `images` (a tensor, or an iterable of tensors);
+        with a sharded bank the ranks calibrate together (maxima all-reduced: every rank must hold the same scales).  Returns True if a
+        scale changed.  A calibration pass that itself trips a guard rail (non-finite activations) raises."""
+        vit = getattr(self.ae_net, "dinov2_model", None)
+        if vit is None or not hasattr(vit, "calibrate_plane_scales"):
+            return False
+        group = self.template_shard[2] if self.template_shard is not None else None
+        changed = False
+        for x in ([images] if torch.is_tensor(images) else images):
+            changed = vit.calibrate_plane_scales(x.to(self.device), group=group) or changed
+        _lib.raise_status(_lib.take_status() & ~_lib.SPLIT_RANGE_BITS)   # hand-over bits of the pass raise; its range bits are what it measures
+        return changed
+
+    def _needs_calibration(self):
+        vit = getattr(self.ae_net, "dinov2_model", None)
+        return (vit is not None and getattr(vit, "numerics", None) == "split" and getattr(vit, "split_gemm", "128") != "128"
+                and hasattr(vit, "calibrate_plane_scales") and vit.plane_amax is None)
+
+    def _recover_range(self, bits, images):
+        """A plane value left f16's range (GP_STATUS_SPLIT_RANGE).  First remedy (round 5): re-calibrate the per-tensor plane scales on
+        the inputs that tripped the guard -- the scales of the offending tensors drop by powers of two, every GEMM stays on the fast
+        kernels, banks are kept (a feature computed under another scale differs by f32 round-off, as it does between two batch
+        shapes).  If no scale changed (already covered: not a range problem of the ViT planes) fall back to the wide kernels
+        (_widen_split_range).  Returns True if the caller should run again."""
+        import warnings
+
+        if bits & 4 and images is not None:
+            vit = self.ae_net.dinov2_model
+            if getattr(vit, "numerics", None) == "split" and getattr(vit, "split_gemm", "128") != "128" and self._calibrate_planes(images):
+                warnings.warn("split numerics: a ViT activation left the range of its f16 planes; plane scales re-calibrated on the offending "
+                              f"inputs: {vit.plane_scale_report()} (tensor: (max |x|, scale)); all GEMMs stay on the 256 x 256 kernels.", RuntimeWarning)
+                return True
+        return self._widen_split_range(bits)
+
     def _collect_status(self):
         """Read + clear the guard-rail bits at a point where the host synchronises anyway.  With a sharded template bank the
         decision they drive (range fallback = re-onboarding + a second pass through the collectives) must be taken by ALL ranks
@@ -212,6 +247,9 @@ class GigaPose(_Base):
         dev = self.device
         if torch.device(dev).type == "cuda":
             _lib.status_word(dev)
+        if self._needs_calibration() and len(template_dataset):
+            # first bank of this model: the templates are the calibration set of the ViT's per-tensor plane scales (vit.py)
+            self._calibrate_planes(template_dataset[idx].rgb for idx in range(len(template_dataset)))
         cols = {n: [] for n in ["mask", "K", "M", "poses", "ae_features", "ist_features"]}
         lo, hi = 0, None
         if self.template_shard is not None:
@@ -244,10 +282,14 @@ class GigaPose(_Base):
                                                               template_poses=data["poses"])
         torch.cuda.synchronize()
         bits = self._collect_status()
-        if bits & _lib.SPLIT_RANGE_BITS and self._widen_split_range(bits):
-            if dataset_name in self.template_datas:              # _widen_split_range rebuilt every bank, this one included
-                return
-            return self.set_template_data(dataset_name)          # once more with the wide-range kernels (then any bit raises)
+        if bits & _lib.SPLIT_RANGE_BITS:
+            vit_was = getattr(getattr(self.ae_net, "dinov2_model", None), "split_gemm", None)
+            if self._recover_range(bits, (template_dataset[idx].rgb for idx in range(len(template_dataset)))):
+                widened = getattr(getattr(self.ae_net, "dinov2_model", None), "split_gemm", None) != vit_was or bool(bits & 16)
+                if widened and dataset_name in self.template_datas:   # _widen_split_range rebuilt every bank, this one included
+                    return
+                self.template_datas.pop(dataset_name, None)
+                return self.set_template_data(dataset_name)      # once more (re-calibrated planes, or the wide-range kernels); then any bit raises
         _lib.raise_status(bits)
         self.onboarding_time = (time.time() - t0) / max(1, len(template_dataset))
 
@@ -320,8 +362,8 @@ class GigaPose(_Base):
                                    sort_pred_by_inliers)
         torch.cuda.synchronize()
         bits = self._collect_status()  # guard rails: lost hand-off / split range / label range -> GigaPoseHipError, never silent garbage
-        if bits & _lib.SPLIT_RANGE_BITS and self._widen_split_range(bits):
-            return self.eval_retrieval(batch, idx_batch, dataset_name, sort_pred_by_inliers)   # re-onboards, runs again; a second trip raises
+        if bits & _lib.SPLIT_RANGE_BITS and self._recover_range(bits, batch.tar_img):
+            return self.eval_retrieval(batch, idx_batch, dataset_name, sort_pred_by_inliers)   # re-calibrated (or re-onboarded wide): run again; a further trip raises
         _lib.raise_status(bits)
         predictions.infos = batch.infos
         total_time = time.time() - t0
@@ -431,7 +473,7 @@ class GigaPose(_Base):
         gigaPose.py:400-449) with `time` = the flush's device time apportioned by crop count."""
         job["ev"][1].synchronize()
         bits = int(job["host"]["status"][0])           # this flush's own bits (snapshot + clear in stream order, _run_flush)
-        if bits & _lib.SPLIT_RANGE_BITS and self._widen_split_range(bits):
+        if bits & _lib.SPLIT_RANGE_BITS and self._recover_range(bits, [b.tar_img for b, _ in job["images"]]):
             # the kernels of the NEXT flush (already queued) ran with the narrow planes too: redo both, in order
             nxt, self._in_flight = self._in_flight, None
             self._drain_device()

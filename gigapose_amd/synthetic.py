@@ -207,6 +207,53 @@ def fill_state_dict(module, seed):
     return module
 
 
+# DINOv2-like outliers for a random-init stand-in.  Trained ViTs without register tokens are known for a handful of
+# "massive activations": a few residual channels two orders of magnitude above the rest, produced by one or two MLP layers whose
+# hidden units fire at 1e3-1e4, and LayerNorm gains that blow single channels up.  The split numerics' f16 planes hold |s x| <= 65504
+# (s = 8 by default): these are the tensors that need a smaller per-tensor scale.  Values chosen so that the default scale TRIPS the
+# range guard in three different kinds of plane tensor: a LayerNorm output (norm2 gain on a residual outlier channel: ~1e4), q|k|v and
+# the attention output (a value-projection bias of 9e3: the same for every token, so the softmax logits stay sane), and a GELU output
+# (two hidden units at 1.2e4).  The outliers sit on the MLP / value side on purpose: a LayerNorm-1 outlier would put ~1e5 into the
+# attention logits, where two correct f32 implementations already disagree.
+OUTLIER_SPEC = dict(residual_channels=(5, 300, 911), residual_value=150.0,
+                    ln2_layers=(4, 15), ln2_channels=(5, 700), ln2_gain=600.0,
+                    v_layers=(9,), v_channels=(33, 520), v_bias=9.0e3,
+                    fc1_layers=(6, 18), fc1_units=(7, 900), fc1_bias=1.2e4)
+
+
+def plant_dinov2_outliers(model, spec=None):
+    """Plant OUTLIER_SPEC into a DINOv2 ViT in place: a gigapose_amd.vit.Dinov2ViT (hub naming) or a transformers.Dinov2Model
+    (HF naming: the float64 oracle of the tests).  Layer indices wrap around the model's depth.  Returns the model."""
+    import torch
+
+    sp = dict(OUTLIER_SPEC, **(spec or {}))
+    hf = hasattr(model, "embeddings")
+    with torch.no_grad():
+        if hf:
+            layers, pe_bias = model.encoder.layer, model.embeddings.patch_embeddings.projection.bias
+        else:
+            layers, pe_bias = model.blocks, model.patch_embed.proj.bias
+        depth, dim = len(layers), pe_bias.shape[0]
+        for c in sp["residual_channels"]:
+            pe_bias[c % dim] += sp["residual_value"]
+        for li in sp["ln2_layers"]:
+            for c in sp["ln2_channels"]:
+                layers[li % depth].norm2.weight[c % dim] *= sp["ln2_gain"]
+        for li in sp["v_layers"]:
+            for c in sp["v_channels"]:
+                if hf:
+                    layers[li % depth].attention.attention.value.bias[c % dim] = sp["v_bias"]
+                else:
+                    layers[li % depth].attn.qkv.bias[2 * dim + c % dim] = sp["v_bias"]
+        for li in sp["fc1_layers"]:
+            fc1 = layers[li % depth].mlp.fc1
+            for u in sp["fc1_units"]:
+                fc1.bias[u % fc1.bias.shape[0]] = sp["fc1_bias"]
+    if hasattr(model, "invalidate"):
+        model.invalidate()
+    return model
+
+
 def condition_ist(module):
     """Rescale a random-init ISTNet (reference or mirror; keyed by state-dict names) into the regime a TRAINED one
     works in: the Kaiming-initialised net emits |features| ~ 23, scales of 5 +- 15 (negative ones included) and fully

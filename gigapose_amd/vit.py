@@ -90,6 +90,15 @@ class Dinov2ViT(nn.Module):
         # LayerNorm folded into the neighbouring plane GEMMs (gp_split256.hip, epilogues 8-10): built and tested, measured 1 % slower
         # than the LayerNorm launches it removes (csrc/gp_vit.hip: g_ln_fold) -- off unless GIGAPOSE_LN_FOLD=1 (2: ping-pong stream)
         self.ln_fold = int(os.environ.get("GIGAPOSE_LN_FOLD", "0"))
+        # Per-tensor plane scales of the split plane path (gp_vit_forward_split2; round 5).  Four activation tensors per layer travel as
+        # f16 hi / lo planes of s x -- LayerNorm-1 out, q|k|v (+ attention out), LayerNorm-2 out, GELU out -- with s a power of two
+        # <= 8 chosen per (layer, tensor) from a calibration pass over real inputs (GigaPose onboarding: the templates) so that
+        # max |x| * s * plane_headroom <= 65504.  None = uncalibrated = 8 everywhere (the stand-in weights never need less).  A
+        # checkpoint with DINOv2's massive activations lowers s for the few tensors that hold them; every GEMM stays on the
+        # single-accumulator 256 x 256 kernels (the old remedy moved the WHOLE ViT to the 128 x 128 kernels: -43 %).
+        self.plane_scales = None      # list of depth * 4 floats, or None
+        self.plane_amax = None        # running max |x| per (layer, tensor) over every calibration pass: numpy (depth, 4)
+        self.plane_headroom = float(os.environ.get("GIGAPOSE_PLANE_HEADROOM", "4"))
 
     def set_split_gemm(self, mode):
         if mode not in ("256", "128"):
@@ -180,6 +189,7 @@ class Dinov2ViT(nn.Module):
         if key in state_dict and state_dict[key].shape[1] != self.pos_embed.shape[1]:
             state_dict[key] = self.resample_pos_embed(state_dict[key])
         self._packed = None
+        self.plane_scales = self.plane_amax = None   # new weights: the calibration of the old ones says nothing
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def _apply(self, fn, *a, **k):   # .to() / .float(): packed weight copies follow the parameters
@@ -188,7 +198,9 @@ class Dinov2ViT(nn.Module):
 
     # ---------------------------------------------------------------- weight packing
     def invalidate(self):
+        """Call after editing parameters in place: packed copies and the plane-scale calibration are dropped."""
         self._packed = None
+        self.plane_scales = self.plane_amax = None
 
     @torch.no_grad()
     def _pack(self, device):
@@ -267,9 +279,71 @@ class Dinov2ViT(nn.Module):
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
         return self._ws, need
 
+    # ---------------------------------------------------------------- plane-scale calibration (split numerics, plane path)
+    PLANE_TENSORS = ("ln1", "qkv", "ln2", "gelu")
+    CALIBRATION_SCALE = 2.0 ** -4     # the calibration pass itself runs with range 65504 * 16 ~ 1e6 (precision does not matter there)
+
+    def reset_plane_scales(self):
+        self.plane_scales, self.plane_amax = None, None
+
+    @staticmethod
+    def scale_for(amax, headroom):
+        """Largest power of two s <= 8 with amax * s * headroom <= 65504 (>= 2^-10); amax == 0 (tensor never on the plane path) -> 8."""
+        if not amax > 0.0:
+            return 8.0
+        return float(min(8.0, max(2.0 ** -10, 2.0 ** math.floor(math.log2(65504.0 / (amax * headroom))))))
+
+    @torch.no_grad()
+    def calibrate_plane_scales(self, images, group=None, chunk=64):
+        """One forward over `images` (chunks of <= `chunk`) in calibration mode: every plane producer records max |x| of the tensor it
+        writes (gp_vit_forward_split2: plane_amax); the running maximum over all calibration passes of this model picks the scales.
+        Returns True if a scale changed.  `group`: a torch.distributed group whose ranks calibrate together (sharded template bank:
+        every rank must end up with the same scales) -- the maxima are all-reduced.  A non-finite activation raises."""
+        if self.numerics != "split" or self.split_gemm == "128" or images.shape[0] == 0:
+            return False
+        device = images.device
+        amax = torch.zeros(self.depth * 4, dtype=torch.float32, device=device)
+        keep = self.plane_scales
+        self.plane_scales = [self.CALIBRATION_SCALE] * (self.depth * 4)
+        try:
+            for s0 in range(0, images.shape[0], chunk):
+                self.patch_features(images[s0:s0 + chunk], plane_amax=amax)
+        finally:
+            self.plane_scales = keep
+        if group is not None:
+            import torch.distributed as dist
+
+            if dist.get_world_size(group) > 1:
+                if dist.get_backend(group) == "gloo":
+                    host = amax.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+                    amax = host
+                else:
+                    dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=group)
+        seen = amax.double().cpu().numpy().reshape(self.depth, 4)      # a host synchronisation: calibration is outside every timed region
+        if not bool((seen == seen).all()) or not bool((seen < float("inf")).all()):
+            raise _lib.GigaPoseHipError("plane-scale calibration: a ViT activation is not finite (NaN / inf input or weights)")
+        self.plane_amax = seen if self.plane_amax is None else __import__("numpy").maximum(self.plane_amax, seen)
+        new = [self.scale_for(float(a), self.plane_headroom) for a in self.plane_amax.reshape(-1)]
+        old = self.plane_scales or [8.0] * (self.depth * 4)
+        changed = new != old
+        self.plane_scales = None if all(v == 8.0 for v in new) else new
+        return changed
+
+    def plane_scale_report(self):
+        """{(layer, tensor): (amax, scale)} for every tensor whose scale is not the default 8 (diagnostics, bench.py)."""
+        if self.plane_scales is None or self.plane_amax is None:
+            return {}
+        out = {}
+        for l in range(self.depth):
+            for t, name in enumerate(self.PLANE_TENSORS):
+                if self.plane_scales[4 * l + t] != 8.0:
+                    out[f"L{l}.{name}"] = (float(self.plane_amax[l, t]), self.plane_scales[4 * l + t])
+        return out
+
     # ---------------------------------------------------------------- forward
     @torch.no_grad()
-    def patch_features(self, images, normalize=True, stop_after_layers=-1):
+    def patch_features(self, images, normalize=True, stop_after_layers=-1, plane_amax=None):
         """images (B,3,224,224) f32 -> (B, C, 16, 16): x_prenorm[:, 1:] rearranged 'b (h w) c ->
         b c h w' and (optionally) L2-normalised over C -- i.e. AENet.forward_by_chunk's result."""
         if images.shape[1:] != (3, 224, 224):
@@ -286,10 +360,13 @@ class Dinov2ViT(nn.Module):
             return out
         ws, need = self._workspace(B, device)
         _, tensors, table, split, split_table = self._packed
-        _lib.call("gp_vit_forward_split", _lib.ptr(x), _lib.i(B), _lib.i(self.dim), _lib.i(self.depth),
+        scales = None
+        if self.plane_scales is not None and self.numerics == "split":
+            scales = (ctypes.c_float * len(self.plane_scales))(*self.plane_scales)   # host array, read at launch time
+        _lib.call("gp_vit_forward_split2", _lib.ptr(x), _lib.i(B), _lib.i(self.dim), _lib.i(self.depth),
                   _lib.i(self.heads), _lib.i(self.mlp_dim), _lib.f(1e-6), table, _lib.i(len(tensors)),
                   split_table, _lib.i(len(split)), _lib.ptr(ws), ctypes.c_size_t(need), _lib.ptr(out),
-                  _lib.i(1 if normalize else 0), _lib.i(stop_after_layers), _lib.stream_ptr())
+                  _lib.i(1 if normalize else 0), _lib.i(stop_after_layers), scales, _lib.ptr(plane_amax), _lib.stream_ptr())
         return out
 
     @torch.no_grad()

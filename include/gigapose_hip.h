@@ -297,6 +297,27 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
                          const float* const* weights, int n_weights, const void* const* split, int n_split,
                          float* workspace, size_t workspace_bytes, float* out_features, int normalize,
                          int stop_after_layers, void* stream);
+/* Per-tensor plane scales (round 5; replaces the all-or-nothing fallback to the 128 x 128 kernels when a checkpoint's activations leave
+ * the x 8 planes' range -- DINOv2's massive activations; arithmetic: HF modeling_dinov2.py:342-380, the same forward).  The plane path
+ * keeps four activation tensors per layer as f16 hi / lo planes of s x: [0] LayerNorm-1 output, [1] q | k | v and the attention output,
+ * [2] LayerNorm-2 output, [3] GELU output; s is a power of two PER (layer, tensor):
+ *   plane_scales  HOST array [depth][4] or NULL (= all 8: bit-identical to gp_vit_forward_split); each in [2^-10, 64];
+ *   plane_amax    DEVICE array [depth][4] f32 or NULL; non-NULL = calibration pass: every plane producer records max |x| of what it
+ *                 wrote (atomic max on the f32 bits; the caller zeroes it) -- gigapose_amd/vit.py picks s from it with headroom.
+ * Consumers undo the scale exactly (out_scale = 1 / (64 s)); the range guard (GP_STATUS_SPLIT_RANGE) stays |s x| <= 65504. */
+int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
+                          const float* const* weights, int n_weights, const void* const* split, int n_split,
+                          float* workspace, size_t workspace_bytes, float* out_features, int normalize,
+                          int stop_after_layers, const float* plane_scales, float* plane_amax, void* stream);
+/* stage entries of the same (tests): gp_gemm_planes256_ragged whose plane epilogue (6 / 7) writes s x with s = plane_scale (the
+ * consumer GEMM then takes out_scale = 1 / (64 s)), optionally recording max |x| into the device float `amax`; gp_attention_split on
+ * q | k | v planes that carry qkv_scale instead of 8 (its output planes carry the same scale). */
+int gp_gemm_planes256_scaled(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
+                             void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
+                             const float* residual, int ldr, float out_scale, float plane_scale, float* amax, float* scratch,
+                             size_t scratch_bytes, void* stream);
+int gp_attention_split_scaled(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
+                              float qkv_scale, void* stream);
 
 /* ---- IST backbone: ResNet.forward (src/models/network/resnet.py:364-381, BasicBlock :26-50) -- */
 

@@ -105,6 +105,7 @@ def test_eval_retrieval_matches_reference_golden(golden_dir, numerics, monkeypat
     tiles, match_tiles = {}, model.testing_metric.match_tiles
     model.testing_metric.match_tiles = lambda *a, **kw: tiles.setdefault("out", match_tiles(*a, **kw))   # every tile's record, for the checker
     assert model.test_step(batch, 0) == 0
+    model.flush_pending()   # test_step queues whole images (GigaPose.accumulate_crops, default 64): run + write what is pending
     p = model.last_predictions
     # onboarding produced the same features as the reference's (ViT-S on CPU)
     np.testing.assert_allclose(model.template_datas["syn"].ae_features[0, 0].cpu().numpy(), g["tmpl_ae_feat_sample"],

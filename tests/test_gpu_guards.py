@@ -143,10 +143,15 @@ def _gigapose_with_vit(vit, k=3):
 
 
 def test_range_trip_falls_back_to_the_wide_kernels_automatically():
-    """a checkpoint whose activations leave the x 8 planes' range (|x| >= 8190; planted: one fc1 bias of 1e4)
-    must not make the drop-in fail.  GigaPose notices the guard bit at its synchronisation point, moves the ViT to the
-    two-accumulator 128 x 128 kernels (range 65504), re-onboards and runs again: the result equals a model that was told
-    GIGAPOSE_SPLIT_GEMM=128 from the start, the status word is clean, a warning says what happened.  A NaN still raises."""
+    """a checkpoint whose activations leave the x 8 planes' range (|x| >= 8190; planted: one fc1 bias
+    of 1e4) must not make the drop-in fail -- and (round 5) must not cost the fast kernels either.
+    (a) Default: onboarding calibrates the per-tensor plane scales on the templates (tests/test_gpu_plane_scales.py), the GELU tensor
+        of that layer gets a smaller power of two, nothing trips, every GEMM stays on the 256 x 256 kernels; the predictions agree
+        with a model built on the wide 128 x 128 kernels (both f32-class).
+    (b) The remedy behind it still exists: with the calibration disabled the guard trips, GigaPose moves the ViT to the
+        two-accumulator 128 x 128 kernels (range 65504), re-onboards and runs again -- the result equals a model that was told
+        GIGAPOSE_SPLIT_GEMM=128 from the start bit for bit, the status word is clean, a warning says what happened.
+    A NaN still raises."""
     from test_gpu_e2e import make_batch
 
     def planted():
@@ -163,7 +168,25 @@ def test_range_trip_falls_back_to_the_wide_kernels_automatically():
     want.template_datasets = {"syn": tset}
     want.eval_retrieval(batch, 0, "syn")
     ref = {n: v.cpu() for n, v in want.last_predictions.tensors.items()}
+    import warnings
+
+    # (a) calibrated planes: no trip, no warning, the fast kernels
     model = _gigapose_with_vit(planted())
+    model.template_datasets = {"syn": tset}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model.eval_retrieval(batch, 0, "syn")
+    _lib.check_status()
+    vit = model.ae_net.dinov2_model
+    assert vit.split_gemm == "256" and "L0.gelu" in vit.plane_scale_report() and vit.plane_scale_report()["L0.gelu"][1] <= 1.0
+    got = {n: v.cpu() for n, v in model.last_predictions.tensors.items()}
+    assert torch.equal(ref["id_src"], got["id_src"]), "template ids differ between the calibrated planes and the wide kernels"
+    close = (ref["pred_poses"] - got["pred_poses"]).abs().flatten(1).max(1).values < 1e-3
+    assert close.float().mean() > 0.9
+    # (b) calibration disabled: the wide-kernel fallback
+    model = _gigapose_with_vit(planted())
+    model._needs_calibration = lambda: False
+    model._calibrate_planes = lambda images: False
     assert model.ae_net.dinov2_model.split_gemm == "256"
     model.template_datasets = {"syn": tset}
     with pytest.warns(RuntimeWarning, match="falling back"):
@@ -174,7 +197,6 @@ def test_range_trip_falls_back_to_the_wide_kernels_automatically():
     for n in ref:
         assert torch.equal(ref[n], got[n]), f"{n} differs from the model built with the wide kernels"
     # a second batch runs without another fallback
-    import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         model.eval_retrieval(batch, 1, "syn")

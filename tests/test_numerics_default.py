@@ -33,12 +33,30 @@ def test_chain_is_opt_in_by_env_and_by_yaml_key(monkeypatch):
         m.set_numerics("bf16")
 
 
-def test_second_stream_switch_is_off_by_default_and_read_from_the_environment(monkeypatch):
-    """GigaPose.overlap_ist: False unless GIGAPOSE_OVERLAP_IST says 1 / auto (small batches)."""
+def test_second_stream_switch_defaults_to_auto_and_is_read_from_the_environment(monkeypatch):
+    """GigaPose.overlap_ist: "auto" (IST backbone on a second stream up to 32 crops; round 5 -- the GPU suite runs with it) unless
+    GIGAPOSE_OVERLAP_IST says 0 / 1 (small batches)."""
     from gigapose_amd import factory
 
     monkeypatch.delenv("GIGAPOSE_OVERLAP_IST", raising=False)
-    assert factory.build_model("dinov2_vits14", k=2, device="cpu").overlap_ist is False
+    assert factory.build_model("dinov2_vits14", k=2, device="cpu").overlap_ist == "auto"
     for text, want in (("1", True), ("auto", "auto"), ("AUTO", "auto"), ("0", False), ("", False), ("on", True)):
         monkeypatch.setenv("GIGAPOSE_OVERLAP_IST", text)
         assert factory.build_model("dinov2_vits14", k=2, device="cpu").overlap_ist == want
+
+
+def test_cross_image_accumulation_default_and_keys(monkeypatch):
+    """GigaPose.accumulate_crops: 64 by default; GIGAPOSE_ACCUMULATE_CROPS or the `accumulate_crops:` YAML key (read from **kwargs
+    like `numerics`, so the constructor keeps the reference's signature) override it; 0 = the reference's per-image flow."""
+    import tempfile
+
+    from gigapose_amd import factory
+    from gigapose_amd.gigaPose import GigaPose
+
+    monkeypatch.delenv("GIGAPOSE_ACCUMULATE_CROPS", raising=False)
+    m = factory.build_model("dinov2_vits14", k=2, device="cpu")
+    assert m.accumulate_crops == 64 and m._pending == [] and m._in_flight is None
+    monkeypatch.setenv("GIGAPOSE_ACCUMULATE_CROPS", "0")
+    assert factory.build_model("dinov2_vits14", k=2, device="cpu").accumulate_crops == 0
+    m2 = GigaPose("large", m.ae_net, m.ist_net, None, m.testing_metric, None, 1000, tempfile.mkdtemp(), accumulate_crops=32)
+    assert m2.accumulate_crops == 32

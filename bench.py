@@ -428,7 +428,32 @@ def main():
             vit.set_split_gemm(os.environ.get("GIGAPOSE_SPLIT_GEMM", "256"))
             ist.conv_kernel = os.environ.get("GIGAPOSE_SPLIT_CONV", "256")
             ist.invalidate()
+        # split_outliers: the same model with DINOv2-like planted outliers (gigapose_amd/synthetic.py: OUTLIER_SPEC -- massive GELU
+        # activations in two layers, a value-projection channel at 9e3, LayerNorm gains of 600 on residual outlier channels): the
+        # default x 8 planes would trip the range guard; onboarding calibrates per-tensor plane scales on the templates and every
+        # GEMM stays on the 256 x 256 plane kernels (round 4 landed in split128 for such weights)
+        try:
+            from gigapose_amd import synthetic as syn_
+
+            vit = model.ae_net.dinov2_model
+            keep_sd = {k: v.detach().clone() for k, v in vit.state_dict().items()}
+            syn_.plant_dinov2_outliers(vit)
+            try:
+                odt, odt_serial, okern, _, _ = run_mode("split")
+                e = numerics_entry("split_outliers", odt, odt_serial, okern,
+                                   "planted DINOv2-like outliers; per-tensor plane scales calibrated at onboarding (vit.py: calibrate_plane_scales), "
+                                   "all GEMMs on the 256 x 256 plane kernels")
+                e["plane_scales_not_8"] = {k: {"max_abs": round(a, 1), "scale": sc} for k, (a, sc) in vit.plane_scale_report().items()}
+                e["split_gemm"] = vit.split_gemm
+                other["split_outliers"] = e
+            finally:
+                vit.load_state_dict(keep_sd)
+        except Exception as e:
+            other["split_outliers"] = {"error": repr(e)}
         model.set_numerics(args.numerics)
+        for key in ("split128", "split_outliers"):
+            if isinstance(other.get(key), dict) and "value" in other[key]:
+                other[key]["relative_to_headline"] = round(other[key]["value"] / (args.batch * args.steps / dt), 3)
     # BASELINE configs 3 and 5 at size on this one GPU (N = 1 only): same path, headline numerics, fewer steps.  Config 5's
     # bank is the fp16 (hi-plane-only) one its text asks for; at N = 8 it would be sharded 8-way (1/8 of these bytes per GPU).
     # Config 3 also at B = 128 (B = 64 and 128) and as a batch curve B = 8 / 16 / 32 (the reference forwards

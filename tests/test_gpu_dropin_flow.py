@@ -48,7 +48,7 @@ def build_from_reference_cfg(log_dir, numerics, accumulate):
         model = df.instantiate(cfg).to(DEV)                               # test.py:47  instantiate(cfg.model)
         assert model.accumulate_crops == accumulate
         syn.fill_state_dict(model.ae_net.dinov2_model, 11)                # no network for gigaPose_v1.ckpt: deterministic random weights
-        syn.fill_state_dict(model.ist_net, 12)
+        syn.condition_ist(syn.fill_state_dict(model.ist_net, 12))         # the regime a trained ISTNet works in (synthetic.condition_ist)
         model.set_numerics(numerics)
         _MODELS[numerics] = model
     model = _MODELS[numerics]
@@ -84,7 +84,12 @@ def test_reference_test_py_flow_from_the_reference_model_config(tmp_path, numeri
         p_all = model.predict(cat["tar_img"], cat["tar_mask"], cat["tar_K"], cat["tar_M"], cat["labels"], "syn")
     first = 0
     for (batch, q), n in zip(batches, (5, 9)):
-        p = p_all[list(range(first, first + n))] if accumulate else model.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
+        if accumulate:
+            import types
+
+            p = types.SimpleNamespace(pred_poses=p_all.pred_poses[first:first + n], scores=p_all.scores[first:first + n])
+        else:
+            p = model.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
         first += n
         poses, labels = p.pred_poses[:, 0].cpu().numpy(), q["labels"].numpy()
         sel = []

@@ -272,7 +272,7 @@ def test_ist_backbone_on_a_second_stream_gives_the_same_predictions(monkeypatch,
     model = factory.build_model("dinov2_vits14", k=4, device=dev, seed=6)
     model.template_datasets = {"syn": tset}
     model.set_template_data("syn")
-    assert model.overlap_ist is False
+    assert model.overlap_ist == "auto"   # the product default since round 5
     out = {}
     for B in (5, 40):
         q = tset.crops(71 + B, B, dev)

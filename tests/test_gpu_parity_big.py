@@ -378,4 +378,5 @@ def test_config5_end_to_end_40_objects_fp16_bank(golden_dir):
                 moved += int(d > 1e-3)
     print(f"config 5 end to end, fp16 bank vs f32-class bank: top-5 sets differing {d_set}/64, best template kept {best_kept}/64, "
           f"hypotheses with the same template and inlier count {checked}/320, of which poses moved > 1e-3: {moved}")
-    assert best_kept >= 60 and d_set <= 24 and checked >= 200 and moved <= 0.1 * checked   # regression guard around the measured level
+    # regression guard around the measured level (round 5, MI355X: 4 / 64 sets, 64 / 64 best kept, 311 / 320 comparable, 0 moved)
+    assert best_kept == 64 and d_set <= 8 and checked >= 300 and moved <= 0.02 * checked

@@ -90,7 +90,7 @@ def test_plane_epilogues_with_other_scales(epi, s_in, s_out):
 def test_plane_epilogue_range_guard_follows_the_scale():
     """3e4 in a bias: beyond the x 8 planes (2.4e5 > 65504: flagged), inside the x 1 planes (clean)."""
     torch.manual_seed(4)
-    I, J, K = 1024, 4096, 64
+    I, J, K = 1024, 4096, 128
     A = torch.randn(I, K, device=DEV) * 0.05
     Bm = torch.randn(J, K, device=DEV)
     bias = torch.zeros(I, device=DEV)

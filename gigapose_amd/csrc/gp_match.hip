@@ -757,6 +757,63 @@ __global__ __launch_bounds__(256) void format_points_kernel(const uint8_t* __res
     src_pts[2 * i + 1] = valid ? (js / GP_G) : -1;
 }
 
+// ------------------------------------------------------------------ top-k + gather + format in ONE launch (round 5)
+// What LocalSimilarity.test does after the tiles (matching.py:279-316: topk over templates, gather the winners' records,
+// format_prediction) took four launches here (topk, gather_records, format_points, a torch int32 -> int64 cast of the ids): per step
+// that is ~25 us of queue time for ~20 us of work.  One block per detection: wave 0 selects the k winners with topk_kernel's rule
+// (higher score, then lower template index), then the block copies each winner's record and writes the point lists.  Same values
+// as the three kernels above (tests compare them).
+__global__ __launch_bounds__(256) void select_topk_kernel(const float* __restrict__ sim_avg, const uint8_t* __restrict__ idx_t2s,
+                                                           const float* __restrict__ score_t2s, const float* __restrict__ mask_all, int N, int k,
+                                                           long long* __restrict__ ids64, float* __restrict__ scores,
+                                                           float* __restrict__ rec_score, long long* __restrict__ tar_pts,
+                                                           long long* __restrict__ src_pts)
+{
+    extern __shared__ unsigned char taken[];  // N flags, then (4-byte aligned) k winner ids
+    int* win = reinterpret_cast<int*>(taken + ((N + 3) & ~3));
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    for (int n = t; n < N; n += 256) taken[n] = 0;
+    __syncthreads();
+    const float* v = sim_avg + (size_t)b * N;
+    if (t < 64) {   // wave 0 only: its LDS operations are in program order, no barrier inside the selection loop
+        for (int j = 0; j < k; ++j) {
+            float bv = 0.f;
+            int bi = 0x7fffffff;
+            for (int n = lane; n < N; n += 64) {
+                if (taken[n]) continue;
+                const float x = v[n];
+                if (bi == 0x7fffffff || x > bv) { bv = x; bi = n; }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+            }
+            if (lane == 0) {
+                ids64[(size_t)b * k + j] = bi;
+                scores[(size_t)b * k + j] = bv;
+                taken[bi] = 1;
+                win[j] = bi;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // lane 0's `taken` write is seen by the wave's next scan
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {
+        const size_t src = ((size_t)b * N + win[j]) * GP_P + t;
+        const size_t i = ((size_t)b * k + j) * GP_P + t;
+        const bool valid = mask_all[src] != 0.f;  // torch.nonzero(mask)  (matching.py:42)
+        const int js = idx_t2s[src];
+        rec_score[i] = score_t2s[src];
+        tar_pts[2 * i + 0] = valid ? (t % GP_G) : -1;
+        tar_pts[2 * i + 1] = valid ? (t / GP_G) : -1;
+        src_pts[2 * i + 0] = valid ? (js % GP_G) : -1;
+        src_pts[2 * i + 1] = valid ? (js / GP_G) : -1;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -892,6 +949,18 @@ int gp_topk(const float* sim_avg, int B, int N, int k, int* ids, float* scores, 
     GP_REQUIRE(sim_avg && ids && scores, "gp_topk: null pointer");
     hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(64), (size_t)N, (hipStream_t)stream, sim_avg, N, k, ids, scores);
     GP_CHECK_LAUNCH("gp_topk");
+    return GP_OK;
+}
+
+int gp_select_topk(const float* sim_avg, const uint8_t* idx_t2s, const float* score_t2s, const float* mask_all, int B, int N, int k,
+                   long long* ids, float* scores, float* rec_score, long long* tar_pts, long long* src_pts, void* stream)
+{
+    GP_REQUIRE(k >= 1 && k <= N, "gp_select_topk: selected index k out of range (k=%d, N=%d)", k, N);   // torch.topk raises (matching.py:279)
+    if (B == 0) return GP_OK;
+    GP_REQUIRE(sim_avg && idx_t2s && score_t2s && mask_all && ids && scores && rec_score && tar_pts && src_pts, "gp_select_topk: null pointer");
+    hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(256), (size_t)((N + 3) & ~3) + sizeof(int) * (size_t)k, (hipStream_t)stream, sim_avg,
+                       idx_t2s, score_t2s, mask_all, N, k, ids, scores, rec_score, tar_pts, src_pts);
+    GP_CHECK_LAUNCH("gp_select_topk");
     return GP_OK;
 }
 

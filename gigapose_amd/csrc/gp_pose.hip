@@ -15,10 +15,12 @@ namespace {
 struct RansacSmem {
     float sx[GP_P], sy[GP_P], tx[GP_P], ty[GP_P];  // compacted pixel coordinates
     float sc[GP_P], cs[GP_P], sn[GP_P];            // compacted scale, cos, sin
+    float wt[GP_P];                                // compacted weights (RANSAC.forward's `scores`; ones by default)
     short orig[GP_P];                              // compacted -> patch position
-    int count[GP_P];
+    float count[GP_P];                             // weighted inlier score per candidate (unit weights: an exact integer count)
     int wave_n[4];
-    int best, best_count, n;
+    int best, n;
+    float best_count;
 };
 
 // exclusive prefix of `flag` over the 256-thread block (4 waves): returns position, total in *tot
@@ -70,6 +72,7 @@ __device__ __forceinline__ bool is_inlier(const RansacSmem& s, int j, float m00,
 __global__ __launch_bounds__(256) void ransac_kernel(
     const long long* __restrict__ src_pts, const long long* __restrict__ tar_pts,  // (R,256,2)
     const float* __restrict__ rel_scale, const float* __restrict__ rel_inplane,    // (R,256), (R,256,2)
+    const float* __restrict__ score,                                               // (R,256) weights or null = ones (ransac.py:119-120)
     float patch_size, float thr, float* __restrict__ Mout, unsigned char* __restrict__ failed,
     long long* __restrict__ inl_src, long long* __restrict__ inl_tar, long long* __restrict__ inl_score)
 {
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(256) void ransac_kernel(
         s.sc[pos] = rel_scale[rp];
         s.cs[pos] = rel_inplane[2 * rp];
         s.sn[pos] = rel_inplane[2 * rp + 1];
+        s.wt[pos] = score ? score[rp] : 1.0f;
         s.orig[pos] = (short)p;
     }
     // defaults: identity M, not failed, -1 / 0 padding (ransac.py:125-131)
@@ -102,18 +106,20 @@ __global__ __launch_bounds__(256) void ransac_kernel(
         if (p == 0) failed[r] = 0;
         return;
     }
-    // every correspondence proposes a similarity; score = # other correspondences within thr
-    int cnt = 0;
+    // every correspondence proposes a similarity; score = sum of the weights of the OTHER correspondences within thr (ransac.py:98;
+    // ascending order, f32: with the default unit weights an exact count)
+    float cnt = 0.f;
     if (p < n) {
         float m00, m01, m10, m11, t0, t1;
         candidate(s, p, m00, m01, m10, m11, t0, t1);
         for (int j = 0; j < n; ++j)
-            if (j != p && is_inlier(s, j, m00, m01, m10, m11, t0, t1, thr, n >= 46)) ++cnt;
+            if (j != p && is_inlier(s, j, m00, m01, m10, m11, t0, t1, thr, n >= 46)) cnt = cnt + s.wt[j];
         s.count[p] = cnt;
     }
     __syncthreads();
     if (p == 0) {  // torch.max: first maximal candidate (ransac.py:99)
-        int best = 0, bc = s.count[0];
+        int best = 0;
+        float bc = s.count[0];
         for (int i = 1; i < n; ++i)
             if (s.count[i] > bc) { bc = s.count[i]; best = i; }
         s.best = best;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void ransac_kernel(
         M[0] = m00; M[1] = m01; M[2] = t0;
         M[3] = m10; M[4] = m11; M[5] = t1;
         M[6] = 0.f; M[7] = 0.f; M[8] = 1.f;
-        failed[r] = (s.best_count == 0) ? 1 : 0;  // failed = score == 0 (ransac.py:100)
+        failed[r] = (s.best_count == 0.f) ? 1 : 0;  // failed = score == 0 (ransac.py:100)
     }
     // inliers of the winner, in ascending order, packed at the front (ransac.py:103-104, 160-163)
     const bool inl = (p < n) && (p != best) && is_inlier(s, p, m00, m01, m10, m11, t0, t1, thr, n >= 46);
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256) void ransac_kernel(
         const size_t src = r * GP_P + s.orig[p];
         inl_src[2 * o] = src_pts[2 * src]; inl_src[2 * o + 1] = src_pts[2 * src + 1];
         inl_tar[2 * o] = tar_pts[2 * src]; inl_tar[2 * o + 1] = tar_pts[2 * src + 1];
-        inl_score[o] = 1;  // scores default to ones (ransac.py:119-120)
+        inl_score[o] = (long long)s.wt[p];  // the weight, cast to the points' int64 as the reference's assignment does (ransac.py:163); default 1
     }
 }
 
@@ -304,18 +310,26 @@ __global__ __launch_bounds__(256) void rank_hypotheses_kernel(const long long* _
 
 extern "C" {
 
-int gp_ransac(const long long* src_pts, const long long* tar_pts, const float* rel_scale,
-              const float* rel_inplane, int R, float patch_size, float pixel_threshold, float* M,
-              unsigned char* failed, long long* inl_src, long long* inl_tar, long long* inl_score, void* stream)
+int gp_ransac_scored(const long long* src_pts, const long long* tar_pts, const float* rel_scale,
+                     const float* rel_inplane, const float* score, int R, float patch_size, float pixel_threshold, float* M,
+                     unsigned char* failed, long long* inl_src, long long* inl_tar, long long* inl_score, void* stream)
 {
     GP_REQUIRE(R >= 0, "gp_ransac: bad size");
     if (R == 0) return GP_OK;
     GP_REQUIRE(src_pts && tar_pts && rel_scale && rel_inplane && M && failed && inl_src && inl_tar && inl_score,
                "gp_ransac: null pointer");
     hipLaunchKernelGGL(ransac_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, src_pts, tar_pts, rel_scale,
-                       rel_inplane, patch_size, pixel_threshold, M, failed, inl_src, inl_tar, inl_score);
+                       rel_inplane, score, patch_size, pixel_threshold, M, failed, inl_src, inl_tar, inl_score);
     GP_CHECK_LAUNCH("gp_ransac");
     return GP_OK;
+}
+
+int gp_ransac(const long long* src_pts, const long long* tar_pts, const float* rel_scale,
+              const float* rel_inplane, int R, float patch_size, float pixel_threshold, float* M,
+              unsigned char* failed, long long* inl_src, long long* inl_tar, long long* inl_score, void* stream)
+{
+    return gp_ransac_scored(src_pts, tar_pts, rel_scale, rel_inplane, nullptr, R, patch_size, pixel_threshold, M, failed, inl_src, inl_tar,
+                            inl_score, stream);
 }
 
 int gp_recover_poses(const int* labels, const float* tar_K, const float* tar_M, const long long* id_src,

@@ -308,10 +308,12 @@ class GigaPose(_Base):
         if tar_img.is_cuda:
             _lib.status_word(tar_img.device)  # device labels / hand-offs / split range are checked by the kernels (check_status)
         if not labels.is_cuda and tar_img.is_cuda:
-            # stream-ordered upload from pinned memory: a pageable-memory copy would block the host until the stream drains,
-            # i.e. a host sync per call that exposes the launch latency of everything after it
-            labels = labels.pin_memory().to(tar_img.device, non_blocking=True)
-        labels0 = (labels.to(tar_img.device) - 1).to(torch.int32).contiguous()
+            # host labels: the 0-based int32 form every kernel takes is made on the HOST and uploaded once, stream-ordered from pinned
+            # memory (a pageable-memory copy would block the host until the stream drains, i.e. a host sync per call that exposes the
+            # launch latency of everything after it; converting on the device cost three ATen launches per step)
+            labels0 = (labels.to(torch.int64) - 1).to(torch.int32).contiguous().pin_memory().to(tar_img.device, non_blocking=True)
+        else:
+            labels0 = (labels.to(tar_img.device) - 1).to(torch.int32).contiguous()
         side = None
         if tar_img.is_cuda and (self.overlap_ist is True or (self.overlap_ist == "auto" and tar_img.shape[0] <= 32)):
             # IST backbone on a second HIP stream: both chains are matrix-core bound, the overlap fills
@@ -344,7 +346,7 @@ class GigaPose(_Base):
         pred = self.pose_recovery[dataset_name].forward_ransac(predictions=pred)  # stage 5
         rank_hypotheses(pred, sort_pred_by_inliers)                              # gigaPose.py:588-594, one launch
         poses = self.pose_recovery[dataset_name].forward_recovery(                # stage 6
-            tar_label=labels, tar_K=tar_K, tar_M=tar_M, pred_src_views=pred.id_src, pred_M=pred.M)
+            tar_label=labels, tar_K=tar_K, tar_M=tar_M, pred_src_views=pred.id_src, pred_M=pred.M, labels0=labels0)
         pred.register_tensor("pred_poses", poses)
         return pred
 

@@ -165,16 +165,31 @@ class LocalSimilarity(torch.nn.Module):
                   _lib.ptr(src_pts), _lib.stream_ptr())
         return tar_pts, src_pts
 
+    def select_topk(self, sim_avg, idx, sc, ma, k=None):
+        """topk + gather_records + format_points (reference matching.py:279-316) as ONE launch (gp_select_topk): ids (B,k) int64,
+        score_src (B,k), score_pts (B,k,256), tar_pts / src_pts (B,k,256,2) int64.  Equal to the three stage calls (tests)."""
+        k = self.k if k is None else k
+        B, N = sim_avg.shape
+        if k > N:
+            raise RuntimeError("selected index k out of range")  # torch.topk's error (matching.py:279)
+        dev = sim_avg.device
+        ids = torch.empty(B, k, dtype=torch.int64, device=dev)
+        scores = torch.empty(B, k, dtype=torch.float32, device=dev)
+        rec_score = torch.empty(B, k, P, dtype=torch.float32, device=dev)
+        tar_pts = torch.empty(B, k, P, 2, dtype=torch.int64, device=dev)
+        src_pts = torch.empty(B, k, P, 2, dtype=torch.int64, device=dev)
+        _lib.call("gp_select_topk", _lib.ptr(sim_avg), _lib.ptr(idx), _lib.ptr(sc), _lib.ptr(ma), _lib.i(B), _lib.i(N), _lib.i(k), _lib.ptr(ids),
+                  _lib.ptr(scores), _lib.ptr(rec_score), _lib.ptr(tar_pts), _lib.ptr(src_pts), _lib.stream_ptr())
+        return ids, scores, rec_score, tar_pts, src_pts
+
     # ---- resident-bank entry point (what GigaPose.eval_retrieval uses) --------------------
     def test_bank(self, bank, tar_feat, tar_mask, labels0):
         """tar_feat (B,C,16,16) AENet features, tar_mask (B,224,224), labels0 (B,) 0-based."""
         query = self.normalize(tar_feat)
         qmask = patch_grid_mask(tar_mask)
         idx, sc, ma, avg = self.match_tiles(query, qmask, bank, labels0.to(torch.int32).contiguous())
-        ids, score_src = self.topk(avg)
-        rec_idx, rec_score, rec_mask = self.gather_records(ids, idx, sc, ma)
-        tar_pts, src_pts = self.format_points(rec_idx, rec_mask)
-        return PandasTensorCollection(infos=pd.DataFrame(), id_src=ids.long(), score_src=score_src,
+        ids, score_src, rec_score, tar_pts, src_pts = self.select_topk(avg, idx, sc, ma)
+        return PandasTensorCollection(infos=pd.DataFrame(), id_src=ids, score_src=score_src,
                                       score_pts=rec_score, tar_pts=tar_pts, src_pts=src_pts)
 
     # ---- validation-time matcher (reference matching.py:115-186) ---------------------------

@@ -18,8 +18,9 @@ class RANSAC(torch.nn.Module):
         self.pixel_threshold = pixel_threshold
 
     @torch.no_grad()
-    def run(self, src_pts, tar_pts, rel_scale, rel_inplane):
-        """src_pts/tar_pts (...,256,2) int64, rel_scale (...,256), rel_inplane (...,256,2) ->
+    def run(self, src_pts, tar_pts, rel_scale, rel_inplane, scores=None):
+        """src_pts/tar_pts (...,256,2) int64, rel_scale (...,256), rel_inplane (...,256,2) [, scores (...,256): the weights of
+        RANSAC.forward's `scores` argument, None = ones] ->
         M (...,3,3), failed (...) bool, inlier src/tar pts (...,256,2) int64, inlier scores (...,256) int64."""
         lead = tuple(src_pts.shape[:-2])
         R = 1
@@ -31,17 +32,26 @@ class RANSAC(torch.nn.Module):
         isrc = torch.empty(*lead, P, 2, dtype=torch.int64, device=dev)
         itar = torch.empty(*lead, P, 2, dtype=torch.int64, device=dev)
         isc = torch.empty(*lead, P, dtype=torch.int64, device=dev)
-        _lib.call("gp_ransac", _lib.ptr(src_pts.contiguous()), _lib.ptr(tar_pts.contiguous()),
-                  _lib.ptr(rel_scale.contiguous().float()), _lib.ptr(rel_inplane.contiguous().float()), _lib.i(R),
+        weights = None if scores is None else scores.to(dev).float().contiguous()
+        if weights is not None and tuple(weights.shape) != tuple(src_pts.shape[:-1]):
+            raise ValueError(f"scores must have shape {tuple(src_pts.shape[:-1])}, got {tuple(weights.shape)}")
+        _lib.call("gp_ransac_scored", _lib.ptr(src_pts.contiguous()), _lib.ptr(tar_pts.contiguous()),
+                  _lib.ptr(rel_scale.contiguous().float()), _lib.ptr(rel_inplane.contiguous().float()), _lib.ptr(weights), _lib.i(R),
                   _lib.f(self.patch_size), _lib.f(self.pixel_threshold), _lib.ptr(M), _lib.ptr(failed),
                   _lib.ptr(isrc), _lib.ptr(itar), _lib.ptr(isc), _lib.stream_ptr())
-        return M, failed.bool(), isrc, itar, isc
+        return M, failed.view(torch.bool), isrc, itar, isc   # the kernel writes 0 / 1 bytes: a reinterpretation, not a conversion launch
 
     def forward(self, batch, scores=None, direction="src2tar"):
-        """Reference signature (ransac.py:108): batch has src_pts/tar_pts (B,P,2), relScale, relInplane."""
-        if direction != "src2tar" or scores is not None:
-            raise NotImplementedError("only the src2tar / unit-score path used at inference is built")
-        M, failed, isrc, itar, isc = self.run(batch.src_pts, batch.tar_pts, batch.relScale, batch.relInplane)
+        """Reference signature (ransac.py:108-121): batch has src_pts / tar_pts (B,P,2), relScale, relInplane -- or, for
+        direction="tar2src", the same four with the suffix `_inv`; `scores` (B,P) weights the correspondences (default: ones).
+        Inference (poses.py:143) uses neither; both are built so that the class is a full stand-in (round 5)."""
+        if direction == "src2tar":
+            fields = (batch.src_pts, batch.tar_pts, batch.relScale, batch.relInplane)
+        elif direction == "tar2src":
+            fields = (batch.src_pts_inv, batch.tar_pts_inv, batch.relScale_inv, batch.relInplane_inv)
+        else:
+            raise ValueError(f"direction must be 'src2tar' or 'tar2src', got {direction!r}")   # the reference fails later with an UnboundLocalError
+        M, failed, isrc, itar, isc = self.run(*fields, scores=scores)
         out = PandasTensorCollection(src_pts=isrc, tar_pts=itar, scores=isc, infos=batch.infos)
         return M, failed, out
 
@@ -59,13 +69,15 @@ class ObjectPoseRecovery(torch.nn.Module):
         self.deferred_flag = None
 
     @torch.no_grad()
-    def forward_recovery(self, tar_label, tar_K, tar_M, pred_src_views, pred_M):
+    def forward_recovery(self, tar_label, tar_K, tar_M, pred_src_views, pred_M, labels0=None):
         """tar_label (B) 1-based object labels (reference indexes template tensors with label-1,
-        poses.py:111-113); returns pred_poses (B,k,4,4)."""
+        poses.py:111-113); returns pred_poses (B,k,4,4).  labels0 (optional, not in the reference signature): the same labels already
+        as a 0-based int32 device tensor (GigaPose.predict has it: saves two conversion launches per step)."""
         B, k = pred_src_views.shape
         O, N = self.template_Ms.shape[:2]
         dev = pred_M.device
-        labels0 = (tar_label.to(dev) - 1).to(torch.int32).contiguous()
+        if labels0 is None:
+            labels0 = (tar_label.to(dev) - 1).to(torch.int32).contiguous()
         poses = torch.empty(B, k, 4, 4, dtype=torch.float32, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         _lib.call("gp_recover_poses", _lib.ptr(labels0), _lib.ptr(tar_K.contiguous().float()),

@@ -134,6 +134,11 @@ int gp_gather_records(const int* ids, const uint8_t* idx_t2s, const float* score
  * tar_pts, src_pts int64 (rows,256,2) as (x,y), -1 where rec_mask == 0.  rows = B*k. */
 int gp_format_points(const uint8_t* rec_idx, const float* rec_mask, int rows, long long* tar_pts,
                      long long* src_pts, void* stream);
+/* gp_topk + gp_gather_records + gp_format_points in ONE launch (what GigaPose's hot loop calls; the three above stay as stage entries
+ * and for the template-sharded path, which exchanges records between the top-k and the formatting): ids (B,k) int64 as the reference
+ * returns them (matching.py:279-316), scores (B,k), rec_score (B,k,256), tar_pts / src_pts (B,k,256,2) int64 (-1 = invalid). */
+int gp_select_topk(const float* sim_avg, const uint8_t* idx_t2s, const float* score_t2s, const float* mask_all, int B, int N, int k,
+                   long long* ids, float* scores, float* rec_score, long long* tar_pts, long long* src_pts, void* stream);
 
 /* ---- dense layers: k-major f32 MFMA GEMM ---------------------------------------------------- */
 
@@ -408,6 +413,12 @@ int gp_ist_regress(const float* tar_feat, const float* src_bank, const int* labe
 int gp_ransac(const long long* src_pts, const long long* tar_pts, const float* rel_scale,
               const float* rel_inplane, int R, float patch_size, float pixel_threshold, float* M,
               unsigned char* failed, long long* inl_src, long long* inl_tar, long long* inl_score, void* stream);
+/* RANSAC.forward(batch, scores=...) (ransac.py:108-121, 98): `score` (R,256) f32 weights every correspondence (NULL = ones =
+ * gp_ransac): a candidate's score is the f32 sum, in ascending order, of the weights of the other correspondences within the
+ * threshold; failed = (best score == 0); inl_score = the winners' weights cast to int64 as the reference's assignment does. */
+int gp_ransac_scored(const long long* src_pts, const long long* tar_pts, const float* rel_scale,
+                     const float* rel_inplane, const float* score, int R, float patch_size, float pixel_threshold, float* M,
+                     unsigned char* failed, long long* inl_src, long long* inl_tar, long long* inl_score, void* stream);
 
 /* ---- pose recovery: ObjectPoseRecovery.forward_recovery (src/models/poses.py:26-122) --------- */
 

@@ -197,8 +197,8 @@ def ist_inference(tar_feat, src_feat_sel, tar_pts, src_pts, weights, use_tanh=Tr
     return outs[0].reshape(B, k, P), outs[1].reshape(B, k, P, 2)
 
 
-def ransac(src_pts, tar_pts, rel_scale, rel_inplane, patch_size=14.0, thr=14.0):
-    """RANSAC.forward (ransac.py:108-172) over leading dims (...,256,2)."""
+def ransac(src_pts, tar_pts, rel_scale, rel_inplane, patch_size=14.0, thr=14.0, scores=None):
+    """RANSAC.forward (ransac.py:108-172) over leading dims (...,256,2); scores (...,256) = its `scores` argument (None: ones)."""
     src_pts = np.ascontiguousarray(src_pts, np.int64)
     tar_pts = np.ascontiguousarray(tar_pts, np.int64)
     lead = src_pts.shape[:-2]
@@ -209,8 +209,9 @@ def ransac(src_pts, tar_pts, rel_scale, rel_inplane, patch_size=14.0, thr=14.0):
     isrc = np.empty((R, P, 2), np.int64)
     itar = np.empty((R, P, 2), np.int64)
     isc = np.empty((R, P), np.int64)
-    lib().oracle_ransac(_p(src_pts), _p(tar_pts), _p(rs), _p(ri), ctypes.c_int(R), ctypes.c_float(patch_size),
-                        ctypes.c_float(thr), _p(M), _p(failed), _p(isrc), _p(itar), _p(isc))
+    sc = _f32(scores) if scores is not None else None
+    lib().oracle_ransac_scored(_p(src_pts), _p(tar_pts), _p(rs), _p(ri), _p(sc) if sc is not None else None, ctypes.c_int(R),
+                               ctypes.c_float(patch_size), ctypes.c_float(thr), _p(M), _p(failed), _p(isrc), _p(itar), _p(isc))
     return (M.reshape(*lead, 3, 3), failed.reshape(lead).astype(bool), isrc.reshape(*lead, P, 2),
             itar.reshape(*lead, P, 2), isc.reshape(*lead, P))
 

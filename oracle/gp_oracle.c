@@ -301,13 +301,27 @@ static int cand_inlier(const cand_t* c, float sx, float sy, float tx, float ty, 
     return sqrtf(d0 * d0 + d1 * d1) <= thr;
 }
 
+/* `score` (R x P f32, or NULL = ones): the per-correspondence weights of RANSAC.forward(batch, scores=...) (ransac.py:119-120, 98:
+ * score_inliers = sum(inliers * val_score)); summed in ascending correspondence order in f32 (torch.sum's order is unspecified:
+ * exact for the integer-valued weights the goldens use); the emitted inlier scores are the weights cast to the points' int64
+ * (ransac.py:163 assigns into an int64 tensor: truncation). */
+void oracle_ransac_scored(const int64_t* src_pts, const int64_t* tar_pts, const float* rel_scale,
+                          const float* rel_inplane, const float* score, int R, float patch_size, float thr,
+                          float* M, uint8_t* failed, int64_t* inl_src, int64_t* inl_tar, int64_t* inl_score);
 void oracle_ransac(const int64_t* src_pts, const int64_t* tar_pts, const float* rel_scale,
                    const float* rel_inplane, int R, float patch_size, float thr,
                    float* M, uint8_t* failed, int64_t* inl_src, int64_t* inl_tar, int64_t* inl_score)
 {
+    oracle_ransac_scored(src_pts, tar_pts, rel_scale, rel_inplane, NULL, R, patch_size, thr, M, failed, inl_src, inl_tar, inl_score);
+}
+
+void oracle_ransac_scored(const int64_t* src_pts, const int64_t* tar_pts, const float* rel_scale,
+                          const float* rel_inplane, const float* score, int R, float patch_size, float thr,
+                          float* M, uint8_t* failed, int64_t* inl_src, int64_t* inl_tar, int64_t* inl_score)
+{
 #pragma omp parallel for schedule(dynamic)
     for (int r = 0; r < R; ++r) {
-        float sx[P], sy[P], tx[P], ty[P], sc[P], cs[P], sn[P]; int orig[P];
+        float sx[P], sy[P], tx[P], ty[P], sc[P], cs[P], sn[P], wt[P]; int orig[P];
         int n = 0;
         for (int p = 0; p < P; ++p) {
             size_t rp = (size_t)r * P + p;
@@ -320,6 +334,7 @@ void oracle_ransac(const int64_t* src_pts, const int64_t* tar_pts, const float* 
             tx[n] = (float)tar_pts[2 * rp] * patch_size;
             ty[n] = (float)tar_pts[2 * rp + 1] * patch_size;
             sc[n] = rel_scale[rp]; cs[n] = rel_inplane[2 * rp]; sn[n] = rel_inplane[2 * rp + 1];
+            wt[n] = score ? score[rp] : 1.0f;
             orig[n] = p; ++n;
         }
         float* Mr = M + (size_t)r * 9;
@@ -327,24 +342,24 @@ void oracle_ransac(const int64_t* src_pts, const int64_t* tar_pts, const float* 
             for (int i = 0; i < 9; ++i) Mr[i] = (i % 4 == 0) ? 1.f : 0.f;
             failed[r] = 0; continue;
         }
-        int best = 0, bc = -1;
+        int best = 0; float bc = 0.f;
         for (int i = 0; i < n; ++i) {
             cand_t c = make_cand(sx, sy, tx, ty, sc, cs, sn, i);
-            int cnt = 0;
-            for (int j = 0; j < n; ++j) if (j != i && cand_inlier(&c, sx[j], sy[j], tx[j], ty[j], thr, n >= 46)) ++cnt;
-            if (cnt > bc) { bc = cnt; best = i; }                   /* first max (:99) */
+            float cnt = 0.f;                                         /* unit weights: an exact integer count */
+            for (int j = 0; j < n; ++j) if (j != i && cand_inlier(&c, sx[j], sy[j], tx[j], ty[j], thr, n >= 46)) cnt = cnt + wt[j];
+            if (i == 0 || cnt > bc) { bc = cnt; best = i; }         /* first max (:99) */
         }
         cand_t c = make_cand(sx, sy, tx, ty, sc, cs, sn, best);
         Mr[0] = c.m00; Mr[1] = c.m01; Mr[2] = c.t0; Mr[3] = c.m10; Mr[4] = c.m11; Mr[5] = c.t1;
         Mr[6] = 0.f; Mr[7] = 0.f; Mr[8] = 1.f;
-        failed[r] = (bc == 0);                                      /* :100 */
+        failed[r] = (bc == 0.f);                                    /* :100 */
         int q = 0;
         for (int j = 0; j < n; ++j) {
             if (j == best || !cand_inlier(&c, sx[j], sy[j], tx[j], ty[j], thr, n >= 46)) continue;
             size_t o = (size_t)r * P + q, s = (size_t)r * P + orig[j];
             inl_src[2 * o] = src_pts[2 * s]; inl_src[2 * o + 1] = src_pts[2 * s + 1];
             inl_tar[2 * o] = tar_pts[2 * s]; inl_tar[2 * o + 1] = tar_pts[2 * s + 1];
-            inl_score[o] = 1; ++q;                                   /* :160-163 */
+            inl_score[o] = (int64_t)wt[j]; ++q;                      /* :160-163 (float -> int64 assignment truncates) */
         }
     }
 }

@@ -337,6 +337,36 @@ def run_ref_e2e(which, double=False, dets_per_forward=4, model=None):
     return model, arrays
 
 
+def gen_pose_scored():
+    """RANSAC.forward with its two optional arguments (ransac.py:108-121): `scores` (per-correspondence weights) and
+    direction="tar2src" (the `*_inv` fields).  Unused at inference, present on the class: the unmodified reference's outputs on the
+    many-to-one boundary case (exact 14 px ties) with integer-valued weights 0..3 (f32 sums of those are exact in any order,
+    so torch.sum's unspecified order cannot matter) -> tests/golden/pose_scored.npz."""
+    ref_shim.install()
+    import pandas as pd
+    from src.megapose.utils.tensor_collection import PandasTensorCollection
+    from src.models.ransac import RANSAC
+
+    case = syn.many_to_one_case(221, 14)
+    inv = syn.many_to_one_case(222, 14)
+    rs = np.random.RandomState(223)
+    weights = rs.randint(0, 4, case["rel_scale"].shape).astype(np.float32)
+    weights[3] = 0.0                                         # a problem whose every weight is zero: failed = True with inliers present
+    batch = PandasTensorCollection(infos=pd.DataFrame(), src_pts=torch.from_numpy(case["src_pts"]), tar_pts=torch.from_numpy(case["tar_pts"]),
+                                   relScale=torch.from_numpy(case["rel_scale"]), relInplane=torch.from_numpy(case["rel_inplane"]),
+                                   src_pts_inv=torch.from_numpy(inv["src_pts"]), tar_pts_inv=torch.from_numpy(inv["tar_pts"]),
+                                   relScale_inv=torch.from_numpy(inv["rel_scale"]), relInplane_inv=torch.from_numpy(inv["rel_inplane"]))
+    out = {"weights": weights}
+    ransac = RANSAC(pixel_threshold=14)
+    for tag, kw in (("s2t_w", dict(scores=torch.from_numpy(weights))), ("t2s", dict(direction="tar2src")),
+                    ("t2s_w", dict(scores=torch.from_numpy(weights), direction="tar2src"))):
+        Ms, failed, o = ransac(batch, **kw)
+        out.update({f"{tag}_M": Ms.numpy(), f"{tag}_failed": failed.numpy(), f"{tag}_scores": o.scores.numpy().astype(np.int8),
+                    f"{tag}_src_pts": o.src_pts.numpy().astype(np.int16), f"{tag}_tar_pts": o.tar_pts.numpy().astype(np.int16)})
+        print("pose_scored", tag, "failed", failed.tolist(), "weighted inliers", o.scores.sum(-1).tolist())
+    np.savez_compressed(os.path.join(GOLD, "pose_scored.npz"), **out)
+
+
 def gen_e2e(which="e2e"):
     _, arrays = run_ref_e2e(which)
     np.savez_compressed(os.path.join(GOLD, which + ".npz"), **arrays)
@@ -417,7 +447,7 @@ def gen_bop_csv():
     print("bop_csv:", [k for k in gold if k != "seed"])
 
 
-STAGES = {"bop_csv": gen_bop_csv, "val": gen_val, "matcher": gen_matcher, "matcher_variants": gen_matcher_variants, "ist": gen_ist, "pose": gen_pose, "e2e": gen_e2e, "crop": gen_crop,
+STAGES = {"bop_csv": gen_bop_csv, "val": gen_val, "matcher": gen_matcher, "matcher_variants": gen_matcher_variants, "ist": gen_ist, "pose": gen_pose, "pose_scored": gen_pose_scored, "e2e": gen_e2e, "crop": gen_crop,
           "matcher_big": lambda: gen_matcher_big(["match_cfg2", "match_cfg3"]), "matcher_cfg5": lambda: gen_matcher_big(["match_cfg5"]), "e2e_cfg2": lambda: gen_e2e("e2e_cfg2"), "e2e_cfg3": lambda: gen_e2e("e2e_cfg3"),
           "e2e_cfg2_f64": lambda: gen_e2e_f64("e2e_cfg2"), "e2e_cfg3_f64": lambda: gen_e2e_f64("e2e_cfg3"), "e2e_f64": lambda: gen_e2e_f64("e2e")}
 

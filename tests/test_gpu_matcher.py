@@ -304,3 +304,28 @@ def test_split_matcher_live_patch_compaction_is_bit_identical(C):
         assert torch.equal(a, b), f"{name} differs between the compacted and the full tile"
     assert (full[2].sum() > 50) and (full[2].sum(-1) > 0).any(), "the case exercises no valid correspondence"
     print(f"compaction C={C}: {int(full[2].sum())} valid correspondences over {B * N} tiles, all outputs bit-identical")
+
+
+def test_select_topk_equals_topk_gather_format():
+    """gp_select_topk (one launch: what the hot loop calls since round 5) == gp_topk + gp_gather_records + gp_format_points +
+    the int64 cast, on random tile records with EXACT ties in sim_avg (tie rule: higher score, then lower template index), k = N,
+    k = 1, N not a multiple of 4 (the shared-memory layout pads the flags)."""
+    from gigapose_amd.matching import LocalSimilarity
+
+    rs = np.random.RandomState(12)
+    for B, N, k in [(7, 162, 5), (3, 13, 13), (5, 6, 1), (64, 162, 5)]:
+        metric = LocalSimilarity(k=k, sim_threshold=0.5, patch_threshold=3)
+        avg = rs.randint(0, 12, (B, N)).astype(np.float32) / 16.0          # many exact ties
+        idx = rs.randint(0, 256, (B, N, 256)).astype(np.uint8)
+        sc = rs.rand(B, N, 256).astype(np.float32)
+        ma = (rs.rand(B, N, 256) > 0.6).astype(np.float32)
+        t = lambda a: torch.from_numpy(a).to(DEV)
+        avg_d, idx_d, sc_d, ma_d = t(avg), t(idx), t(sc), t(ma)
+        ids, score = metric.topk(avg_d)
+        rec_idx, rec_score, rec_mask = metric.gather_records(ids, idx_d, sc_d, ma_d)
+        tar, src = metric.format_points(rec_idx, rec_mask)
+        ids2, score2, rec_score2, tar2, src2 = metric.select_topk(avg_d, idx_d, sc_d, ma_d)
+        assert ids2.dtype == torch.int64 and torch.equal(ids2, ids.long()) and torch.equal(score2, score)
+        assert torch.equal(rec_score2, rec_score) and torch.equal(tar2, tar) and torch.equal(src2, src)
+    with pytest.raises(RuntimeError):
+        LocalSimilarity(k=7, sim_threshold=0.5, patch_threshold=3).select_topk(avg_d[:, :6].contiguous(), idx_d, sc_d, ma_d)

@@ -104,3 +104,25 @@ def test_ransac_boundary_and_e2e_votes_reproduce_reference_bit_exactly(golden_di
                                                e["relScale"], e["relInplane"])
     np.testing.assert_array_equal(isc.sum(-1) / 256, e["all_scores"])
     np.testing.assert_array_equal(M.view(np.uint32), e["M"].view(np.uint32))
+
+
+def _scored_cases():
+    case, inv = syn.many_to_one_case(221, 14), syn.many_to_one_case(222, 14)
+    return {"s2t_w": (case, True), "t2s": (inv, False), "t2s_w": (inv, True)}
+
+
+def test_ransac_scores_and_tar2src_reproduce_the_reference(golden_dir):
+    """RANSAC.forward's optional arguments (ransac.py:108-121) -- per-correspondence `scores` and direction="tar2src" (the `*_inv`
+    fields) -- on the exact-14-px boundary case, against the unmodified reference (oracle/make_goldens.py: gen_pose_scored):
+    weighted winners, failed flags (a problem whose weights are all zero fails), inlier lists, the weights cast
+    to int64, and M bit for bit."""
+    g = np.load(os.path.join(golden_dir, "pose_scored.npz"))
+    for tag, (case, weighted) in _scored_cases().items():
+        M, failed, isrc, itar, isc = oracle.ransac(case["src_pts"], case["tar_pts"], case["rel_scale"], case["rel_inplane"],
+                                                   scores=g["weights"] if weighted else None)
+        np.testing.assert_array_equal(isc, g[tag + "_scores"].astype(np.int64), err_msg=tag)
+        np.testing.assert_array_equal(isrc, g[tag + "_src_pts"].astype(np.int64), err_msg=tag)
+        np.testing.assert_array_equal(itar, g[tag + "_tar_pts"].astype(np.int64), err_msg=tag)
+        np.testing.assert_array_equal(failed, g[tag + "_failed"], err_msg=tag)
+        np.testing.assert_array_equal(M.view(np.uint32), g[tag + "_M"].view(np.uint32), err_msg=tag)
+    assert g["s2t_w_failed"][3], "the all-zero-weights problem must fail (best weighted score 0), whatever its inliers"

@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 
 from . import cpu as oracle
+from . import ist_torch
 
 
 def vit_features(hf_model, images, chunk=64):
@@ -109,7 +110,7 @@ def eval_retrieval(hf_vit, ist_net, bank_ae, bank_ist, bank_masks, tmpl_geom, cr
     rel_scale, rel_inplane = [], []
     for j in range(k):                                                        # HOT LOOP 2 (gigaPose.py:545-575)
         src_ist = bank_ist[labels - 1, pred["id_src"][:, j]]
-        tar_ist = ist_net.backbone.reference_forward(tar_img)                 # recomputed k times, as the reference does
+        tar_ist = ist_torch.resnet_forward(ist_net.backbone, tar_img)                 # recomputed k times, as the reference does
         sc, cs = ist_inference(ist_net, src_ist, tar_ist, pred["src_pts"][:, j], pred["tar_pts"][:, j])
         rel_scale.append(sc)
         rel_inplane.append(cs)

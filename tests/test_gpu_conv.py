@@ -6,6 +6,7 @@ import torch
 
 from gigapose_amd import synthetic as syn
 from oracle import cpu as oracle
+from oracle import ist_torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -95,7 +96,7 @@ def test_resnet_hip_vs_torch_reference_and_golden(golden_dir):
     tmpl, _ = syn.template_images(102, 2)
     x = torch.from_numpy(np.concatenate([tmpl, tmpl[:1] * 0.5]))  # B=3 (odd batch)
     with torch.no_grad():
-        ref = net.backbone.reference_forward(x).numpy()
+        ref = ist_torch.resnet_forward(net.backbone, x).numpy()
     got = net.to(DEV).forward_by_chunk(x.to(DEV)).cpu().numpy()
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() / scale < 2e-5, np.abs(got - ref).max() / scale

@@ -13,6 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from gigapose_amd import synthetic as syn
+from oracle import ist_torch
 from test_oracle_pose_ist import build_ist
 
 pytestmark = pytest.mark.gpu
@@ -187,8 +188,8 @@ def test_ist_outputs_as_close_to_f64_truth_as_the_reference(golden_dir):
     p = model.last_predictions
     ist64 = build_ist(303, conditioned=True).double()
     with torch.no_grad():
-        tar64 = ist64.backbone.reference_forward(torch.from_numpy(q["tar_img"]).double()).reshape(E2E["B"], 256, 256)
-        tmpl64 = [ist64.backbone.reference_forward(it.rgb.double()).reshape(-1, 256, 256) for it in items]
+        tar64 = ist_torch.resnet_forward(ist64.backbone, torch.from_numpy(q["tar_img"]).double()).reshape(E2E["B"], 256, 256)
+        tmpl64 = [ist_torch.resnet_forward(ist64.backbone, it.rgb.double()).reshape(-1, 256, 256) for it in items]
     # evaluate the scale head in f64 for the golden's hypothesis order
     errs_mine, errs_ref, mags = [], [], []
     mine_ids = p.id_src.cpu().numpy()

@@ -12,6 +12,7 @@ import torch
 
 from gigapose_amd import _lib
 from gigapose_amd import synthetic as syn
+from oracle import ist_torch
 from test_gpu_vit import hip_gemm, run_vit
 
 pytestmark = pytest.mark.gpu
@@ -302,7 +303,7 @@ def test_ist_backbone_split_vs_chain_and_torch():
     tmpl, _ = syn.template_images(102, 2)
     x = torch.from_numpy(np.concatenate([tmpl, tmpl[:1] * 0.5]))      # B=3
     with torch.no_grad():
-        ref = net.backbone.double().reference_forward(x.double()).numpy()
+        ref = ist_torch.resnet_forward(net.backbone.double(), x.double()).numpy()
     net = net.float().to(DEV)
     chain = net.backbone.set_numerics("chain")(x.to(DEV)).cpu().numpy()
     split = net.backbone.set_numerics("split")(x.to(DEV)).cpu().numpy()

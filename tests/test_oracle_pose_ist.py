@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from gigapose_amd import synthetic as syn
+from oracle import ist_torch
 from oracle import cpu as oracle
 
 IST_CFG = dict(n_heads=0, input_dim=3, input_size=256, initial_dim=128, block_dims=[128, 192, 256, 512],
@@ -41,7 +42,7 @@ def test_resnet_and_mlp_oracle_vs_reference_golden(golden_dir):
     net = build_ist(101)
     tmpl, _ = syn.template_images(102, 2)
     with torch.no_grad():
-        feat = net.backbone.reference_forward(torch.from_numpy(tmpl)).numpy()  # torch fp32 statement of the HIP path
+        feat = ist_torch.resnet_forward(net.backbone, torch.from_numpy(tmpl)).numpy()  # torch fp32 statement of the HIP path
     np.testing.assert_allclose(feat, g["resnet_feat"], rtol=1e-4, atol=1e-3)  # |feat| ~ 20
     rs = np.random.RandomState(103)
     src_feat = rs.standard_normal((3, 256, 16, 16)).astype(np.float32)

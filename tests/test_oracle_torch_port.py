@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import torch_port
+from oracle import ist_torch, torch_port
 from test_oracle_matcher import CASES, load_case
 
 
@@ -41,7 +41,7 @@ def test_torch_eval_retrieval_port_vs_reference_golden(golden_dir):
     items, q = e2e_inputs(E2E["seed"], E2E["O"], E2E["N"], E2E["B"])
     with torch.no_grad():
         bank_ae = torch.stack([torch_port.vit_features(hf, it.rgb) for it in items])
-        bank_ist = torch.stack([ist.backbone.reference_forward(it.rgb) for it in items])
+        bank_ist = torch.stack([ist_torch.resnet_forward(ist.backbone, it.rgb) for it in items])
     geom = tuple(np.stack([getattr(it, n).numpy() for it in items]) for n in ["K", "M", "poses"])
     crops = {n: torch.from_numpy(q[n]) for n in ["tar_img", "tar_mask", "tar_K", "tar_M", "labels"]}
     poses, pred = torch_port.eval_retrieval(hf, ist, bank_ae, bank_ist, torch.stack([it.mask for it in items]), geom, crops, E2E["k"])

@@ -48,6 +48,7 @@ struct GpLnFold {
 struct GpPlaneOut {
     float scale;   // power of two
     float* amax;   // device float or null
+    int park;      // epilogue 3 only: > 1 = run a whole tile's K as `park` parts, each folded into the f32 residual (gp_split256.hip: PARK)
 };
 __device__ __forceinline__ void gp_record_amax(float* amax, float mx_scaled, float inv_scale)
 {

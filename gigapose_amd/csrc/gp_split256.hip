@@ -386,6 +386,7 @@ struct ArgsP {
     float* st_main; float* st_strip;               // producer (10): statistics of the rows it writes
     int st_ld; float ln_eps;
     int j_valid;                                   // rows of B that carry data (the last strip fragment may reach beyond them)
+    int park;                                      // PARK builds (epilogue 3): K of a whole tile runs as `park` parts, each folded into the f32 residual (see the kernel)
     float plane_scale;                             // plane epilogues 6 / 7: the output tensor's power-of-two scale (default kActScale = 8)
     float* amax;                                   // calibration launches: max |x| of the planes written (null otherwise)
 };
@@ -403,8 +404,9 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)  // value held by
 // in two rounds, so that every global access is 16 bytes per lane over full 128-byte lines (64 instead of 512
 // instructions per lane for the residual epilogue).  Wave-private: no workgroup barrier between the rounds (LDS
 // operations of one wave execute in order).  Same arithmetic per element as before: results are bit-identical.
-template <int EPI, int NJ = 4>
-__device__ __forceinline__ void epilogue_f32_lds(const ArgsP& a, f32x16 (&acc)[2][NJ], float* __restrict__ wl, int i_base, int j_base, int ln)
+template <int EPI, int NJ = 4, bool BIAS_MUL = false>
+__device__ __forceinline__ void epilogue_f32_lds(const ArgsP& a, f32x16 (&acc)[2][NJ], float* __restrict__ wl, int i_base, int j_base, int ln,
+                                                 float bias_mul = 1.0f)  // BIAS_MUL (PARK builds): 1 for a tile's first K part, 0 for the later ones
 {
     const int l31 = ln & 31, half = ln >> 5;
     constexpr bool kBiasI = EPI == XEPI_BIAS_I || EPI == XEPI_BIAS_I_GELU || EPI == XEPI_BIAS_I_SCALE_RES || EPI == XEPI_BIAS_I_RELU;
@@ -455,6 +457,7 @@ __device__ __forceinline__ void epilogue_f32_lds(const ArgsP& a, f32x16 (&acc)[2
     } else {
         float bias_l = 0.f, scale_l = 0.f;  // lane l holds the value of row i_base + l
         if (kBiasI) bias_l = a.bias[i_base + ln];
+        if (BIAS_MUL) bias_l = bias_l * bias_mul;
         if (EPI == XEPI_BIAS_I_SCALE_RES) scale_l = a.scale[i_base + ln];
         f32x4 bias_j = {0.f, 0.f, 0.f, 0.f};
         if (EPI == XEPI_BIAS_J) bias_j = *reinterpret_cast<const f32x4*>(a.bias + j_base + 4 * l31);
@@ -1123,10 +1126,17 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
 // NJ: 32-row matrix tiles of B per wave -- 4: the 256 x 256 tile; 2: a 256 x 128 tile (wave tile 64 x 64, half the rows of the B
 // planes staged and half the matrix instructions per k-step) for launches whose 256 x 256 tiles fill at most half the slots: twice
 // the tiles, so half the slots per tile and half-size partial accumulators, or no split at all (round 4; B <= 16 crops at ViT-L).
-template <int EPI, bool TIMING = false, bool PAR = false, int NJ = 4>
+// PARK (round 5; epilogue 3 = x += scale (acc + bias) in place, whole tiles only): the K range of a tile runs as a.park PARTS, each from
+// a zero accumulator and each folded into the f32 residual by the tile's own epilogue (the first part carries the bias).  The one f32
+// accumulator then sees K / park instead of K products' roundings -- fc2's K = 4096 is 768 roundings of ONE accumulator (64 k16 blocks x
+// 3 products x 4), the only stage of the plane path measurably worse than a blocked CPU GEMM (profiles/r04_stage_errors.txt: 7.2e-7
+// vs 3.5e-7 of the output's rms).  Cost: one more epilogue + pipeline restart per part and tile.  Its own instantiation: the default
+// kernel's code and registers (251 VGPRs, no scratch) are untouched.
+template <int EPI, bool TIMING = false, bool PAR = false, int NJ = 4, bool PARK = false>
 __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
 {
     static_assert(NJ == 4 || (NJ == 2 && !kEpiLnf<EPI> && EPI != PEPI_RES_PLANES_STATS), "half-width tiles: epilogues 0-7 only");
+    static_assert(!PARK || (EPI == XEPI_BIAS_I_SCALE_RES && !PAR && NJ == 4 && !TIMING), "PARK: the in-place residual epilogue on whole 256 x 256 tiles");
     constexpr int TJ = 64 * NJ;  // rows of B (columns j) per tile
     unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     const unsigned long long k_c0 = TIMING ? __builtin_readcyclecounter() : 0, k_w0 = TIMING ? wall_clock64() : 0;
@@ -1197,7 +1207,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
         const bool is_head = !is_dp && seg - rounds_dp < n_head;
         const bool is_rest = !is_dp && n_rest && seg == n_seg - 1;
         const int t = is_dp ? seg * slots_x + n : n_dp + (is_head ? tb : (is_rest ? ta : first_whole + seg - rounds_dp - n_head));
-        const int s0 = is_rest ? sa : 0, s1 = is_head ? sb : nstep;
+        const int seg_s0 = is_rest ? sa : 0, seg_s1 = is_head ? sb : nstep;
         const int q = t_lo + t;
         const int per_band = a.group * a.tiles_j;
         const int band = q / per_band, rr = q - band * per_band;
@@ -1205,6 +1215,11 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
         const int gsz = min(a.group, a.tiles_i - first_i);
         const int i0 = (first_i + rr % gsz) * TB, j0 = (rr / gsz) * TJ;
 
+        // PARK: a whole tile's k range in n_parts parts (split tiles -- head / rest segments -- keep their single range)
+        const int n_parts = (PARK && !is_head && !is_rest) ? max(1, min(a.park, (seg_s1 - seg_s0) / 4)) : 1;
+        for (int part = 0; part < n_parts; ++part) {
+        const int s0 = PARK ? seg_s0 + (seg_s1 - seg_s0) * part / n_parts : seg_s0;
+        const int s1 = PARK ? seg_s0 + (seg_s1 - seg_s0) * (part + 1) / n_parts : seg_s1;
         f32x16 acc[2][NJ];
         if (!PAR && is_rest) {
             if (tid == 0) {
@@ -1435,6 +1450,8 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
                 epilogue_res_planes(a, acc, reinterpret_cast<float*>(wl), ln_lds + 2 * (TB * wr + 128 * wc), i0 + 64 * wr, j0 + 128 * wc, tid_ & 63);
             else if constexpr (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES)
                 epilogue_planes_thin<EPI, NJ>(a, acc, wl, i0 + 64 * wr, j0 + 32 * NJ * wc, tid_ & 63);
+            else if constexpr (PARK)
+                epilogue_f32_lds<EPI, NJ, true>(a, acc, reinterpret_cast<float*>(wl), i0 + 64 * wr, j0 + 32 * NJ * wc, tid_ & 63, part == 0 ? 1.0f : 0.0f);
             else
                 epilogue_f32_lds<EPI, NJ>(a, acc, reinterpret_cast<float*>(wl), i0 + 64 * wr, j0 + 32 * NJ * wc, tid_ & 63);
             __syncthreads();  // LDS buffer 0 is re-staged by the next segment's prologue
@@ -1452,6 +1469,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
                 }
             }
         }
+        }  // part
         if (TIMING && a.trace && tid == 0 && seg < 7) a.trace[(size_t)p * 32 + 5 + 4 * seg] = wall_clock64();
     }
     if (a.strip_fj > 0) strip_phase<EPI>(a, reinterpret_cast<float*>(lds), &strip_next, threadIdx.x);
@@ -1609,11 +1627,13 @@ int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bh
     a.j_valid = (J_valid > 0 && J_valid < J) ? J_valid : J;
     a.plane_scale = kActScale;
     a.amax = nullptr;
+    a.park = 0;
     if (po) {   // per-tensor output scale of the plane epilogues 6 / 7 (the folded-LayerNorm epilogues keep the default)
         GP_REQUIRE(po->scale > 0.f && (epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES || (po->scale == kActScale && !po->amax)),
                    "gp_gemm_planes256: a plane scale other than 8 needs epilogue 6 or 7 (got %d)", epilogue);
         a.plane_scale = po->scale;
         a.amax = po->amax;
+        a.park = po->park;
     }
     if (ln) {
         a.ln_main = ln->ln_main; a.ln_strip = ln->ln_strip; a.st_main = ln->st_main; a.st_strip = ln->st_strip;
@@ -1676,6 +1696,11 @@ int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bh
             default: GP_REQUIRE(false, "gp_gemm_planes256: unknown epilogue %d", epilogue);
         }
         GP_CHECK_LAUNCH("gp_gemm_planes256/par");
+        return GP_OK;
+    }
+    if (a.park > 1 && epilogue == XEPI_BIAS_I_SCALE_RES && D == res && ldd == ldr) {   // in place: a later part reads what an earlier part wrote
+        hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES, false, false, 4, true>), dim3(kSlots), dim3(TNT), 0, st, a);
+        GP_CHECK_LAUNCH("gp_gemm_planes256/park");
         return GP_OK;
     }
     switch (epilogue) {
@@ -1777,8 +1802,22 @@ int gp_gemm_planes256_scaled(const void* a_hi, const void* a_lo, const void* b_h
 {
     GP_REQUIRE(scratch && scratch_bytes >= gp_gemm_split256_scratch_bytes(), "gp_gemm_planes256_scaled: scratch too small");
     if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
-    const GpPlaneOut po{plane_scale, amax};
+    const GpPlaneOut po{plane_scale, amax, 0};
     return gp_gemm_planes256_launch(a_hi, a_lo, b_hi, b_lo, D, ldd, out_hi, out_lo, ldo, I, J, J_valid, K, epilogue, bias, scale, residual, ldr,
+                                    out_scale, scratch, (hipStream_t)stream, nullptr, &po);
+}
+
+/* gp_gemm_planes256_ragged, epilogue 3 in place (D == residual): D[i][j] += scale_i (out_scale sum_k A B + bias_i) with the K range of
+ * every whole tile run as `park` parts, each from a zero accumulator and each folded into D by the tile's own epilogue -- a long K
+ * (fc2: 4096) then costs an f32 accumulator K / park products' roundings instead of K's.  park <= 1: gp_gemm_planes256_ragged. */
+int gp_gemm_planes256_park(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, int I, int J, int J_valid,
+                           int K, const float* bias, const float* scale, float out_scale, int park, float* scratch, size_t scratch_bytes,
+                           void* stream)
+{
+    GP_REQUIRE(scratch && scratch_bytes >= gp_gemm_split256_scratch_bytes(), "gp_gemm_planes256_park: scratch too small");
+    if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
+    const GpPlaneOut po{kActScale, nullptr, park};
+    return gp_gemm_planes256_launch(a_hi, a_lo, b_hi, b_lo, D, ldd, nullptr, nullptr, 0, I, J, J_valid, K, XEPI_BIAS_I_SCALE_RES, bias, scale, D, ldd,
                                     out_scale, scratch, (hipStream_t)stream, nullptr, &po);
 }
 

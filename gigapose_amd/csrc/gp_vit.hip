@@ -1147,7 +1147,7 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
 int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                           const float* const* weights, int n_weights, const void* const* split, int n_split,
                           float* workspace, size_t workspace_bytes, float* out_features, int normalize,
-                          int stop_after_layers, const float* plane_scales, float* plane_amax, void* stream);
+                          int stop_after_layers, const float* plane_scales, float* plane_amax, int fc2_park, void* stream);
 
 int gp_attention_split_scaled(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
                               float qkv_scale, void* stream);
@@ -1213,7 +1213,7 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
                          int stop_after_layers, void* stream)
 {
     return gp_vit_forward_split2(images, B, dim, depth, heads, mlp_dim, ln_eps, weights, n_weights, split, n_split, workspace, workspace_bytes,
-                                 out_features, normalize, stop_after_layers, nullptr, nullptr, stream);
+                                 out_features, normalize, stop_after_layers, nullptr, nullptr, 0, stream);
 }
 
 /* gp_vit_forward_split with PER-TENSOR plane scales (round 5).  The plane path keeps four activation tensors per layer as f16 hi / lo
@@ -1226,13 +1226,16 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
  *                 (atomic max on the f32 bits; zero it first), from which the host picks the scales (vit.py: calibrate_plane_scales).
  * A smaller scale only moves the f16 subnormal floor of the lo plane up (absolute error 2^-25 / s per element instead of 2^-28); the
  * consumers undo it exactly (out_scale = 1 / (64 s)), so with all scales 8 nothing changes.  Shapes that do not take the plane path
- * (f32 activations, 128 x 128 kernels: range 65504) ignore both arrays. */
+ * (f32 activations, 128 x 128 kernels: range 65504) ignore both arrays.
+ *   fc2_park      > 1: fc2's K = mlp_dim runs as that many parts, each folded into the f32 residual stream by the tile's own epilogue
+ *                 (gp_split256.hip: PARK) -- 768 roundings of ONE f32 accumulator become 768 / fc2_park; 0 / 1 = one part. */
 int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                           const float* const* weights, int n_weights, const void* const* split, int n_split,
                           float* workspace, size_t workspace_bytes, float* out_features, int normalize,
-                          int stop_after_layers, const float* plane_scales, float* plane_amax, void* stream)
+                          int stop_after_layers, const float* plane_scales, float* plane_amax, int fc2_park, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
+    GP_REQUIRE(fc2_park >= 0 && fc2_park <= 16, "gp_vit_forward_split2: fc2_park must be in 0..16");
     enum { PS_LN1 = 0, PS_QKV, PS_LN2, PS_GELU, PS_PER_LAYER = 4 };
     bool default_scales = true;
     if (plane_scales)
@@ -1378,7 +1381,8 @@ int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int he
             const float os = 1.0f / (kPlaneScale * 64.0f);  // g_vit_planes == 1 (probe path): activations x 8, weights x 64
             const float os_ln1 = 1.0f / (ps[PS_LN1] * 64.0f), os_qkv = 1.0f / (ps[PS_QKV] * 64.0f), os_ln2 = 1.0f / (ps[PS_LN2] * 64.0f),
                         os_gelu = 1.0f / (ps[PS_GELU] * 64.0f);   // a consumer undoes its B operand's scale and the weights' x 64, exactly
-            const GpPlaneOut po_qkv{ps[PS_QKV], am ? am + PS_QKV : nullptr}, po_gelu{ps[PS_GELU], am ? am + PS_GELU : nullptr};
+            const GpPlaneOut po_qkv{ps[PS_QKV], am ? am + PS_QKV : nullptr, 0}, po_gelu{ps[PS_GELU], am ? am + PS_GELU : nullptr, 0};
+            const GpPlaneOut po_fc2{kPlaneScale, nullptr, fc2_park};   // fc2 (K = mlp_dim): K in fc2_park parts (gp_split256.hip: PARK; 0 / 1 = off)
             launch_layernorm_planes(X, Hhi, Hlo, w[L_LN1_G], w[L_LN1_B], C, Mpad, ln_eps, st, ps[PS_LN1], am ? am + PS_LN1 : nullptr);
             GP_CHECK_LAUNCH("gp_vit_forward/layernorm_planes");
             if (g_vit_planes == 2) {
@@ -1436,7 +1440,7 @@ int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int he
                 return rc;
             // x = x + ls2 * fc2(.)
             if ((rc = gp_gemm_planes256_launch(sq[S_FC2_HI], sq[S_FC2_LO], Fhi, Flo, X, Mpad, nullptr, nullptr, 0, C, Mpad, Mtok, mlp_dim,
-                                               3 /*BIAS_I_SCALE_RES*/, w[L_FC2_B], w[L_LS2], X, Mpad, os_gelu, SK, st)))
+                                               3 /*BIAS_I_SCALE_RES*/, w[L_FC2_B], w[L_LS2], X, Mpad, os_gelu, SK, st, nullptr, &po_fc2)))
                 return rc;
         }
     }

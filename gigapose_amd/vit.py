@@ -99,6 +99,10 @@ class Dinov2ViT(nn.Module):
         self.plane_scales = None      # list of depth * 4 floats, or None
         self.plane_amax = None        # running max |x| per (layer, tensor) over every calibration pass: numpy (depth, 4)
         self.plane_headroom = float(os.environ.get("GIGAPOSE_PLANE_HEADROOM", "4"))
+        # fc2 (K = 4 dim) accumulated in parts, each folded into the f32 residual stream (gp_split256.hip: PARK): the single f32
+        # accumulator of the plane GEMM sees K / fc2_park products' roundings instead of K's (the one stage of
+        # the plane path measurably worse than a blocked CPU GEMM).  0 / 1 = off.  GIGAPOSE_FC2_PARK.
+        self.fc2_park = int(os.environ.get("GIGAPOSE_FC2_PARK", "0"))
 
     def set_split_gemm(self, mode):
         if mode not in ("256", "128"):
@@ -366,7 +370,8 @@ class Dinov2ViT(nn.Module):
         _lib.call("gp_vit_forward_split2", _lib.ptr(x), _lib.i(B), _lib.i(self.dim), _lib.i(self.depth),
                   _lib.i(self.heads), _lib.i(self.mlp_dim), _lib.f(1e-6), table, _lib.i(len(tensors)),
                   split_table, _lib.i(len(split)), _lib.ptr(ws), ctypes.c_size_t(need), _lib.ptr(out),
-                  _lib.i(1 if normalize else 0), _lib.i(stop_after_layers), scales, _lib.ptr(plane_amax), _lib.stream_ptr())
+                  _lib.i(1 if normalize else 0), _lib.i(stop_after_layers), scales, _lib.ptr(plane_amax), _lib.i(self.fc2_park),
+                  _lib.stream_ptr())
         return out
 
     @torch.no_grad()

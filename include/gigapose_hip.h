@@ -313,7 +313,7 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
 int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                           const float* const* weights, int n_weights, const void* const* split, int n_split,
                           float* workspace, size_t workspace_bytes, float* out_features, int normalize,
-                          int stop_after_layers, const float* plane_scales, float* plane_amax, void* stream);
+                          int stop_after_layers, const float* plane_scales, float* plane_amax, int fc2_park, void* stream);
 /* stage entries of the same (tests): gp_gemm_planes256_ragged whose plane epilogue (6 / 7) writes s x with s = plane_scale (the
  * consumer GEMM then takes out_scale = 1 / (64 s)), optionally recording max |x| into the device float `amax`; gp_attention_split on
  * q | k | v planes that carry qkv_scale instead of 8 (its output planes carry the same scale). */
@@ -323,6 +323,14 @@ int gp_gemm_planes256_scaled(const void* a_hi, const void* a_lo, const void* b_h
                              size_t scratch_bytes, void* stream);
 int gp_attention_split_scaled(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
                               float qkv_scale, void* stream);
+/* Long-K accumulation in parts (round 5; fc2 of the ViT MLP, HF modeling_dinov2.py:272-299: K = 4 dim).  The single-accumulator plane GEMM
+ * rounds its f32 accumulator once per matrix-instruction pass: K = 4096 is 768 roundings (64 k16 blocks x 3 products x 4), where a
+ * blocked CPU GEMM sees a few dozen.  gp_gemm_planes256_park runs the K range of every whole tile of an in-place residual GEMM
+ * (epilogue 3, D == residual) as `park` parts, each from a zero accumulator, each folded into D by the tile's own epilogue (the bias
+ * goes with the first part).  gp_vit_forward_split2's `fc2_park` applies it to fc2 (0 / 1 = off). */
+int gp_gemm_planes256_park(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, int I, int J, int J_valid,
+                           int K, const float* bias, const float* scale, float out_scale, int park, float* scratch, size_t scratch_bytes,
+                           void* stream);
 
 /* ---- IST backbone: ResNet.forward (src/models/network/resnet.py:364-381, BasicBlock :26-50) -- */
 

@@ -141,6 +141,15 @@ def main():
     alt = X1.t() + f32(ls2) * torch.nn.functional.linear(f.float(), f32(W2), f32(b2))
     report("fc2 + residual (x2)", X2.t().double(), ref, alt)
     report("  fc2 branch alone", (X2 - X1).t().double(), ref - x1_64, alt - X1.t())
+    # ---- the same fc2 with its K = 4096 run in parts, each folded into the f32 residual (round 5: gp_gemm_planes256_park)
+    w2hi, w2lo = split_planes_x64(f32(W2))
+    for parts in (2, 4, 8):
+        Xp = X1.clone()
+        _lib.call("gp_gemm_planes256_park", _lib.ptr(w2hi), _lib.ptr(w2lo), _lib.ptr(fhi), _lib.ptr(flo), _lib.ptr(Xp), _lib.i(Mpad), _lib.i(C),
+                  _lib.i(Mpad), _lib.i(Mtok), _lib.i(vit.mlp_dim), _lib.ptr(f32(b2)), _lib.ptr(f32(ls2)), _lib.f(os_), _lib.i(parts), _lib.ptr(ws),
+                  ctypes.c_size_t(nb), st())
+        torch.cuda.synchronize()
+        report(f"  fc2 branch, K in {parts} parts", (Xp - X1).t().double(), ref - x1_64, alt - X1.t())
     _lib.check_status()
 
     print(f"ViT-L layer {L}, {B} crops ({Mtok} tokens): per-stage error vs float64 on the same inputs, rms relative to the stage output's rms")

@@ -1132,7 +1132,12 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
 // 3 products x 4), the only stage of the plane path measurably worse than a blocked CPU GEMM (profiles/r04_stage_errors.txt: 7.2e-7
 // vs 3.5e-7 of the output's rms).  Cost: one more epilogue + pipeline restart per part and tile.  Its own instantiation: the default
 // kernel's code and registers (251 VGPRs, no scratch) are untouched.
-template <int EPI, bool TIMING = false, bool PAR = false, int NJ = 4, bool PARK = false>
+// PSPLIT (PAR builds): false = the parallel-split reduction is compiled OUT (every tile whole on its own slot, S = 1).  With the 256 x 128
+// tiles taking every launch of at most 128 tiles, the 256 x 256 PAR build only ever runs 129-255 WHOLE tiles (ViT-L: q|k|v at 11-21
+// crops, proj / fc2 at 33-63) -- yet it carried the reduction's registers: 256 VGPRs + 150-200 bytes of scratch, and in round 5 an
+// unrelated edit moved those spills into the k loop (q|k|v at 16 crops 100 -> 214 us per launch, the 16-crop step 14.1 -> 16.5 ms;
+// profiles/r05_b16_regression.txt).  The no-split instantiation has nothing to spill.
+template <int EPI, bool TIMING = false, bool PAR = false, int NJ = 4, bool PARK = false, bool PSPLIT = true>
 __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
 {
     static_assert(NJ == 4 || (NJ == 2 && !kEpiLnf<EPI> && EPI != PEPI_RES_PLANES_STATS), "half-width tiles: epilogues 0-7 only");
@@ -1167,7 +1172,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
     // part n % S of tile n / S, slots beyond S * tiles have no tile (they take strip fragments).  S = 1: whole tiles, no exchange.
     // (the GELU build keeps whole tiles, S = 1: with the partial-sum loop next to its epilogue hipcc spills 273 registers, and a
     // launch of T < 256 whole tiles on T slots is within 10 % of the split one at the sizes where it occurs -- fc1 below 16 crops)
-    constexpr bool kParSplit = PAR && EPI != PEPI_GELU_PLANES && EPI != PEPI_LNF_GELU_PLANES;
+    constexpr bool kParSplit = PAR && PSPLIT && EPI != PEPI_GELU_PLANES && EPI != PEPI_LNF_GELU_PLANES;
     const int par_S = kParSplit ? max(1, min(a.par, slots_x / max(n_t, 1))) : 1;  // a.par: the host's cap (k-steps per slot, see the launch)
     if (PAR) {
         const int tile = n / par_S, part = n - tile * par_S;
@@ -1678,6 +1683,16 @@ int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bh
             default: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES, false, true, 2>), dim3(kSlots), dim3(TNT), 0, st, a); break;
         }
         GP_CHECK_LAUNCH("gp_gemm_planes256/par128");
+        return GP_OK;
+    }
+    if (a.par && 2 * T256 > kSlots && (epilogue == XEPI_BIAS_I_SCALE_RES || epilogue == PEPI_BIAS_I_PLANES)) {
+        // 129-255 whole tiles, one per slot (S = floor(256 / tiles) = 1): the PAR build WITHOUT the split-K reduction (see PSPLIT)
+        a.par = 1;
+        if (epilogue == XEPI_BIAS_I_SCALE_RES)
+            hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES, false, true, 4, false, false>), dim3(kSlots), dim3(TNT), 0, st, a);
+        else
+            hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES, false, true, 4, false, false>), dim3(kSlots), dim3(TNT), 0, st, a);
+        GP_CHECK_LAUNCH("gp_gemm_planes256/par-whole");
         return GP_OK;
     }
     if (a.par) {  // fewer tiles than slots: the parallel split-K build (its own instantiation: the serial hand-over kernel keeps its registers)

@@ -225,7 +225,10 @@ def vit_large_layer_plans(crops, half_tiles=True):
             continue
         half = half_tiles and 2 * t256 <= 256
         T, width = (2 * t256, 128) if half else (t256, 256)
-        plan, S_of = par_plan(T, K // 32, 16 if can_split else 10 ** 9)      # the GELU build keeps whole tiles (S = 1)
+        # the GELU build keeps whole tiles (S = 1); so does (round 5) every 256-wide launch of 129-255 tiles: the launcher takes the
+        # PSPLIT = false instantiation for them (an XCD holding exactly 16 of 132 tiles would otherwise have split them two ways)
+        whole = (not can_split) or (width == 256 and T > 128)
+        plan, S_of = par_plan(T, K // 32, 10 ** 9 if whole else 16)
         S = max(S_of.values())
         partial_mb = sum(1 for (_, _, _, part, s) in plan.values() if part < s - 1) * 256 * width * 4 / 1e6
         out[name] = (width, T, S, len(plan), partial_mb)
@@ -257,3 +260,17 @@ def test_half_width_tile_plans_cover_every_unit(crops):
         nstep = 128 if name == "fc2" else 32
         plan, _ = par_plan(T, nstep, 16 if name != "fc1" else 10 ** 9)
         assert sum(s1 - s0 for (_, s0, s1, _, _) in plan.values()) == T * nstep and busy == len(plan) <= 256
+
+
+def test_full_width_parallel_builds_only_ever_run_whole_tiles():
+    """Round 5 (profiles/r05_b16_regression.txt): with the 256 x 128 tiles taking every launch of at most 128 tiles, a 256 x 256 tile launch
+    below 256 tiles holds 129-255 tiles, and the launcher runs them as ONE whole tile per slot (S = 1, no partial accumulators) on the
+    PSPLIT = false instantiations (no split-K reduction compiled in: 235 / 251 VGPRs, no scratch) -- q|k|v at 11-21 crops, proj / fc2 at
+    33-63.  (Only an XCD holding exactly 16 tiles -- 132 tiles: 11 / 33 crops -- would have split two ways under the old rule.)"""
+    seen = set()
+    for crops in range(4, 64):
+        for name, (width, T, S, busy, partial_mb) in vit_large_layer_plans(crops).items():
+            if width == 256 and T < 256:
+                assert 128 < T < 256 and S == 1 and busy == T and partial_mb == 0.0, (crops, name, T, S)
+                seen.add(name)
+    assert {"qkv", "proj", "fc2"} <= seen

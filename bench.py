@@ -594,16 +594,20 @@ def main():
                     for b in images[:8]:          # warm-up: one flush / eight images
                         model.test_step(b, 9999)
                     model.flush_pending()
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for im, b in enumerate(images):
-                        model.test_step(b, im)
-                    model.flush_pending()
-                    torch.cuda.synchronize()
-                    dtf = time.perf_counter() - t0
+                    passes = []
+                    for _ in range(3):   # three passes, the median counts: one np.savez in a few hundred stalls for ~50 ms on these hosts' /tmp
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for im, b in enumerate(images):
+                            model.test_step(b, im)
+                        model.flush_pending()
+                        torch.cuda.synchronize()
+                        passes.append(time.perf_counter() - t0)
+                    dtf = sorted(passes)[1]
                     n_files = len([f for f in os.listdir(os.path.join(tmp, "predictions")) if f.endswith(".npz")])
                     dropin_flow[name] = {"value": round(n_img * n_det / dtf, 2), "unit": "query-crops/sec", "accumulate_crops": acc,
-                                         "ms_per_image": round(1e3 * dtf / n_img, 3), "npz_files_written": n_files - 1}
+                                         "ms_per_image": round(1e3 * dtf / n_img, 3), "npz_files_written": n_files - 1,
+                                         "passes_crops_per_s": [round(n_img * n_det / t, 1) for t in passes]}
                 finally:
                     shutil.rmtree(tmp, ignore_errors=True)
             model.log_dir, model.accumulate_crops = keep_dir, keep_acc

@@ -586,7 +586,9 @@ def main():
             dropin_flow = {"workload": f"{n_img} images x {n_det} detections through GigaPose.test_step (one image per call, as the reference's "
                                        f"test.py feeds it) + the final flush; headline bank ({args.objects} object(s) x {args.templates} templates), "
                                        "per-image npz files written", "numerics": args.numerics}
-            for name, acc in (("accumulated", 64), ("per_image", 0)):
+            # per_image_pipelined: accumulate_crops = 1 -- every image is its own predict() (the reference's batches), but queued like a
+            # flush: its files are written while the next image runs on the GPU
+            for name, acc in (("accumulated", 64), ("per_image", 0), ("per_image_pipelined", 1)):
                 tmp = tempfile.mkdtemp(prefix="gigapose_flow_")
                 try:
                     model.log_dir, model.accumulate_crops = tmp, acc

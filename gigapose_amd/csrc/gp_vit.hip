@@ -416,8 +416,12 @@ __global__ __launch_bounds__(256) void transpose_tm_to_cm_kernel(const float* __
 // longer than the plain residual epilogue -- a wash -- and the consumers (q|k|v, fc1) are 4.6 / 9.5 us longer: 32.4 ms against
 // 32.0 ms per forward.  The LayerNorm kernel moves its 134 MB at 3.9 TB/s on the whole chip; the same bytes in a GEMM's tail are
 // moved while 256 workgroups have nothing else to do.  0 = LayerNorm as its own launches (layernorm_planes_reg_kernel).
-static int g_ln_fold = 0;
-extern "C" void gp_vit_set_ln_fold(int on) { g_ln_fold = (on >= 0 && on <= 2) ? on : 1; }
+// Whether a forward folds is decided PER CALL by what its caller packed (n_split = 28 * depth: the folded operands are there); this
+// process-wide value is only an A/B override on top of that: -1 (default) = follow the packing, 0 = never fold, 1 = fold in place,
+// 2 = fold with a ping-pong residual stream.  (Until round 5 it was the decision itself, set at pack time: with two models in one
+// process the last one packed decided for both -- ADVICE r4.)
+static int g_ln_fold = -1;
+extern "C" void gp_vit_set_ln_fold(int on) { g_ln_fold = (on >= -1 && on <= 2) ? on : -1; }
 
 static int g_attn_probe = 0;     // timing probe (gp_vit_set_attn_probe): 1 = return after staging, 2 = after query 256
 extern "C" void gp_vit_set_attn_probe(int mode) { g_attn_probe = mode; }
@@ -1303,7 +1307,7 @@ int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int he
     // fc1, fc2 -- five launches, no LayerNorm kernel.  The residual stream is token-major f32 and ping-pongs between X2 and X (a
     // producer epilogue reads one and writes the other: no load waits for a store); its raw planes (what the next GEMM multiplies)
     // are written by proj into the (dead) q|k|v region and by fc2 into the (dead) attention-output region.
-    const bool fold = planes && have_fold && g_ln_fold && g_vit_planes == 2 && nl > 0 && C % 256 == 0 && (C == 1024 || C == 768) &&
+    const bool fold = planes && have_fold && g_ln_fold != 0 && g_vit_planes == 2 && nl > 0 && C % 256 == 0 && (C == 1024 || C == 768) &&
                       gp_gemm_planes256_usable(3 * C, Mpad, Mtok, C) && default_scales && !plane_amax;   // the folded epilogues keep the x 8
     GP_REQUIRE(g_vit_planes == 2 || !planes || (default_scales && !plane_amax), "gp_vit_forward_split2: plane scales need the full plane path (gp_vit_set_planes(2))");
     if (fold) {

@@ -272,7 +272,8 @@ class Dinov2ViT(nn.Module):
                 _lib.lib().gp_gemm_planes256_set_half_tiles(int(os.environ["GIGAPOSE_PLANES_HALF"]))
             if "GIGAPOSE_PLANES_DP" in os.environ:   # A/B probe: 0 = every plane-GEMM tile cut stream-K style
                 _lib.lib().gp_gemm_planes256_set_dp(int(os.environ["GIGAPOSE_PLANES_DP"]))
-            _lib.lib().gp_vit_set_ln_fold(self.ln_fold)   # needs the operands packed above (n_split = 28 per layer)
+            if self.ln_fold == 2:   # A/B probe of the ping-pong residual stream; folding itself follows the packing (n_split = 28 per
+                _lib.lib().gp_vit_set_ln_fold(2)   # layer), per call: two models in one process no longer decide for each other
         self._packed = (device, tensors, table, split, split_table)
 
     def _workspace(self, B, device):

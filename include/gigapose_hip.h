@@ -285,7 +285,7 @@ int gp_gemm_planes256_ln(const void* a_hi, const void* a_lo, const void* b_hi, c
                          float ln_eps, float* scratch, size_t scratch_bytes, void* stream);
 int gp_raw_planes_stats(const float* X, float* Xt, void* out_hi, void* out_lo, float* st_main, float* st_strip, int C, int Mpad, int strip_j0,
                         void* stream);
-void gp_vit_set_ln_fold(int on);
+void gp_vit_set_ln_fold(int on); /* A/B override: -1 (default) a forward folds iff its n_split carries the folded operands, 0 never, 1 in place, 2 ping-pong */
 /* stage entry of the plane path (tests, tools/probe_stage_errors.py): LayerNorm over C of X [C][Mpad] f32 (channel-major, as the
  * residual stream is kept) -> token-major activation planes hi / lo [Mpad][C] (x 8); HF modeling_dinov2.py:342-380 norm1 / norm2. */
 int gp_layernorm_planes(const float* X, void* out_hi, void* out_lo, const float* gamma, const float* beta, int C, int Mpad, float eps,

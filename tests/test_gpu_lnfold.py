@@ -231,7 +231,7 @@ def test_vit_large_folded_equals_unfolded_features(B):
     q = factory.TemplateSet(1, 8, seed=100).crops(9, B, DEV)
     lib = _lib.lib()
     try:
-        vit.patch_features(q["tar_img"][:1])   # packs, and sets the library switch from vit.ln_fold
+        vit.patch_features(q["tar_img"][:1])   # packs the folded operands: from here on this model's forwards fold
         lib.gp_vit_set_ln_fold(1)
         f1 = vit.patch_features(q["tar_img"]).clone()
         f1b = vit.patch_features(q["tar_img"]).clone()
@@ -240,7 +240,7 @@ def test_vit_large_folded_equals_unfolded_features(B):
         f0 = vit.patch_features(q["tar_img"]).clone()
         xp0 = vit.forward_features(q["tar_img"])["x_prenorm"].clone()
     finally:
-        lib.gp_vit_set_ln_fold(0)
+        lib.gp_vit_set_ln_fold(-1)   # back to the default: a forward folds iff its caller packed the folded operands
     torch.cuda.synchronize()
     _lib.check_status()
     assert torch.equal(f1, f1b), "the folded path is not deterministic"

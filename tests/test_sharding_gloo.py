@@ -144,6 +144,9 @@ class _Bank:
 def _class_worker(rank, world, port, case, k, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if isinstance(case, str):   # a path: large cases travel as one .npz instead of being pickled to every rank
+        with np.load(case) as z:
+            case = {n: z[n] for n in z.files}
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         N = case["src_feats"].shape[1]
@@ -225,9 +228,14 @@ def test_sharded_matcher_class_world8_x_162_templates_the_north_star_partition()
     ret = mgr.dict()
     keep = {v: os.environ.get(v) for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS")}
     os.environ.update(OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")   # eight ranks on the build container's eight cores: one thread each
+    import tempfile
+
+    path = os.path.join(tempfile.mkdtemp(prefix="shard8_"), "case.npz")
+    np.savez(path, **case)
     try:
-        mp.spawn(_class_worker, args=(world, _free_port(), case, k, ret), nprocs=world, join=True)
+        mp.spawn(_class_worker, args=(world, _free_port(), path, k, ret), nprocs=world, join=True)
     finally:
+        os.remove(path)
         for v, old in keep.items():
             os.environ.pop(v, None) if old is None else os.environ.__setitem__(v, old)
     full = oracle.local_similarity_test(case["src_feats"], case["tar_feat"], case["src_masks"], case["tar_mask"], case["labels"], k)

@@ -389,3 +389,39 @@ def test_config5_end_to_end_40_objects_fp16_bank(golden_dir):
           f"hypotheses with the same template and inlier count {checked}/320, of which poses moved > 1e-3: {moved}")
     # regression guard around the measured level (round 5, MI355X: 4 / 64 sets, 64 / 64 best kept, 311 / 320 comparable, 0 moved)
     assert best_kept == 64 and d_set <= 8 and checked >= 300 and moved <= 0.02 * checked
+
+
+@pytest.mark.parametrize("scale", [1.0])
+def test_eval_retrieval_config3_with_every_plane_scale_lowered(golden_dir, scale):
+    """The worst case of the per-tensor plane scales (round 5): a checkpoint whose calibration lowers EVERY tensor of EVERY layer from
+    x 8 to x 1 (outliers of ~16 k everywhere).  The lo planes' subnormal floor rises eightfold (absolute error 2^-25 per element);
+    end to end at config 3 the run must still be equal to the float64 reference or an explained float64 tie, with as many hypotheses
+    on the float64 path as the bar asks of the default scales."""
+    import parity_explain as px
+
+    mar_path = os.path.join(golden_dir, "e2e_cfg3_margins.npz")
+    if not os.path.exists(mar_path):
+        pytest.skip("e2e_cfg3_margins.npz not generated")
+    m = dict(np.load(mar_path))
+    cfg = E2E_CONFIGS["e2e_cfg3"]
+    model, batch, q = build_e2e_model(cfg, "split")
+    vit = model.ae_net.dinov2_model
+    vit.plane_amax = np.full((vit.depth, 4), 65504.0 / (scale * vit.plane_headroom))     # "calibrated": nothing left to learn from the templates
+    vit.plane_scales = [scale] * (4 * vit.depth)
+    cap = {}
+    match_tiles = model.testing_metric.match_tiles
+
+    def spy(*a, **kw):
+        cap["tiles"] = match_tiles(*a, **kw)
+        return cap["tiles"]
+
+    model.testing_metric.match_tiles = spy
+    assert model.test_step(batch, 0) == 0
+    model.flush_pending()
+    assert vit.plane_scales == [scale] * (4 * vit.depth), "the planted calibration must have been kept"
+    p = {n: v.cpu().numpy() for n, v in model.last_predictions.tensors.items()}
+    geom = px.geometry(cfg["seed"], cfg["O"], cfg["N"], cfg["B"])
+    rep = px.explain(m, ours_for_checker(model, p, cap["tiles"], m), eps_sim=EPS_SIM, eps_px=EPS_PX, geom=geom)
+    print(f"config 3 [split, every plane scale {scale:g}] vs the reference in float64: {px.summary(rep)}")
+    assert not rep["unexplained"] and rep["hyp_checked"] == rep["hyp"]
+    assert rep["hyp_same_all"] >= SAME_ALL_FLOOR[("e2e_cfg3", "split")]

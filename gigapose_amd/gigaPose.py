@@ -200,7 +200,7 @@ class GigaPose(_Base):
         the inputs that tripped the guard -- the scales of the offending tensors drop by powers of two, every GEMM stays on the fast
         kernels, banks are kept (a feature computed under another scale differs by f32 round-off, as it does between two batch
         shapes).  If no scale changed (already covered: not a range problem of the ViT planes) fall back to the wide kernels
-        (_widen_split_range).  Returns True if the caller should run again."""
+        (_widen_split_range).  Returns "recalibrated" / "widened" (the caller runs again; after "widened" every bank has been rebuilt) or False."""
         import warnings
 
         if bits & 4 and images is not None:
@@ -208,8 +208,8 @@ class GigaPose(_Base):
             if getattr(vit, "numerics", None) == "split" and getattr(vit, "split_gemm", "128") != "128" and self._calibrate_planes(images):
                 warnings.warn("split numerics: a ViT activation left the range of its f16 planes; plane scales re-calibrated on the offending "
                               f"inputs: {vit.plane_scale_report()} (tensor: (max |x|, scale)); all GEMMs stay on the 256 x 256 kernels.", RuntimeWarning)
-                return True
-        return self._widen_split_range(bits)
+                return "recalibrated"
+        return "widened" if self._widen_split_range(bits) else False
 
     def _collect_status(self):
         """Read + clear the guard-rail bits at a point where the host synchronises anyway.  With a sharded template bank the
@@ -283,13 +283,12 @@ class GigaPose(_Base):
         torch.cuda.synchronize()
         bits = self._collect_status()
         if bits & _lib.SPLIT_RANGE_BITS:
-            vit_was = getattr(getattr(self.ae_net, "dinov2_model", None), "split_gemm", None)
-            if self._recover_range(bits, (template_dataset[idx].rgb for idx in range(len(template_dataset)))):
-                widened = getattr(getattr(self.ae_net, "dinov2_model", None), "split_gemm", None) != vit_was or bool(bits & 16)
-                if widened and dataset_name in self.template_datas:   # _widen_split_range rebuilt every bank, this one included
-                    return
+            how = self._recover_range(bits, (template_dataset[idx].rgb for idx in range(len(template_dataset))))
+            if how == "widened" and dataset_name in self.template_datas:   # _widen_split_range rebuilt every bank, this one included
+                return
+            if how:
                 self.template_datas.pop(dataset_name, None)
-                return self.set_template_data(dataset_name)      # once more (re-calibrated planes, or the wide-range kernels); then any bit raises
+                return self.set_template_data(dataset_name)      # once more (re-calibrated planes, or the wide-range kernels); a further trip of the same kind raises
         _lib.raise_status(bits)
         self.onboarding_time = (time.time() - t0) / max(1, len(template_dataset))
 

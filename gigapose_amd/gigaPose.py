@@ -183,10 +183,11 @@ class GigaPose(_Base):
         vit = getattr(self.ae_net, "dinov2_model", None)
         if vit is None or not hasattr(vit, "calibrate_plane_scales"):
             return False
-        group = self.template_shard[2] if self.template_shard is not None else None
+        sharded = self.template_shard is not None
+        group = self.template_shard[2] if sharded else None            # None under sharding = the default process group
         changed = False
         for x in ([images] if torch.is_tensor(images) else images):
-            changed = vit.calibrate_plane_scales(x.to(self.device), group=group) or changed
+            changed = vit.calibrate_plane_scales(x.to(self.device), group=group, sync_ranks=sharded) or changed
         _lib.raise_status(_lib.take_status() & ~_lib.SPLIT_RANGE_BITS)   # hand-over bits of the pass raise; its range bits are what it measures
         return changed
 

@@ -299,11 +299,11 @@ class Dinov2ViT(nn.Module):
         return float(min(8.0, max(2.0 ** -10, 2.0 ** math.floor(math.log2(65504.0 / (amax * headroom))))))
 
     @torch.no_grad()
-    def calibrate_plane_scales(self, images, group=None, chunk=64):
+    def calibrate_plane_scales(self, images, group=None, chunk=64, sync_ranks=False):
         """One forward over `images` (chunks of <= `chunk`) in calibration mode: every plane producer records max |x| of the tensor it
         writes (gp_vit_forward_split2: plane_amax); the running maximum over all calibration passes of this model picks the scales.
-        Returns True if a scale changed.  `group`: a torch.distributed group whose ranks calibrate together (sharded template bank:
-        every rank must end up with the same scales) -- the maxima are all-reduced.  A non-finite activation raises."""
+        Returns True if a scale changed.  `sync_ranks`: the ranks of `group` (None = the default group) calibrate together (sharded
+        template bank: every rank must end up with the same scales) -- the maxima are all-reduced.  A non-finite activation raises."""
         if self.numerics != "split" or self.split_gemm == "128" or images.shape[0] == 0:
             return False
         device = images.device
@@ -315,10 +315,10 @@ class Dinov2ViT(nn.Module):
                 self.patch_features(images[s0:s0 + chunk], plane_amax=amax)
         finally:
             self.plane_scales = keep
-        if group is not None:
+        if sync_ranks:
             import torch.distributed as dist
 
-            if dist.get_world_size(group) > 1:
+            if dist.is_initialized() and dist.get_world_size(group) > 1:
                 if dist.get_backend(group) == "gloo":
                     host = amax.cpu()
                     dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)

@@ -290,6 +290,15 @@ def _sync_worker(rank, world, port, ret):
         model.enable_template_sharding()
         _lib.take_status = lambda: (4 if rank == 1 else 0) | (8 if rank == 0 else 0)
         ret[f"bits{rank}"] = model._collect_status()
+        # (4) plane-scale calibration under a sharded bank: every rank sees its own crops, the maxima are all-reduced, all ranks end up
+        #     with the same scales (the device pass is replaced: rank r "measures" a GELU outlier of 3000 (r + 1) in layer r)
+        vit = model.ae_net.dinov2_model.set_numerics("split")
+        _lib.take_status = lambda: 0
+
+        def fake_forward(images, plane_amax=None, **kw):
+            plane_amax[4 * rank + 3] = 3000.0 * (rank + 1)
+        vit.patch_features = fake_forward
+        ret[f"cal{rank}"] = (model._calibrate_planes(torch.zeros(2, 3, 224, 224)), list(vit.plane_scales or []), vit.plane_scale_report())
         # (3) an uneven row count is refused locally, before the collective
         try:
             sharding.all_to_all_rows(torch.zeros(2 * world + 1, 4, dtype=torch.uint8))
@@ -311,3 +320,6 @@ def test_ranks_decide_together_world2():
         assert "different batch sizes (5..6" in ret[f"batch{rank}"], ret[f"batch{rank}"]
         assert ret[f"bits{rank}"] == 12, "every rank must see the OR of all ranks' status bits"
         assert ret[f"rows{rank}"] == "refused"
+        changed, scales, report = ret[f"cal{rank}"]
+        assert changed and scales == ret["cal0"][1], "ranks hold different plane scales"
+        assert report == {"L0.gelu": (3000.0, 4.0), "L1.gelu": (6000.0, 2.0)}

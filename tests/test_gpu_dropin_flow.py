@@ -167,3 +167,34 @@ def test_accumulated_test_steps_in_split_numerics(tmp_path):
         close = np.abs(pa - pb).reshape(len(pa), -1).max(1) <= 1e-4 * (1 + np.abs(pa).reshape(len(pa), -1).max(1))
         assert close.mean() >= 0.9, f"image {i}: {int((~close).sum())} of {len(close)} equal-score hypotheses moved (a RANSAC tie at 14.000 px moves a few)"
     assert same >= 0.9 * total, f"{same} / {total} hypothesis scores equal"
+
+
+def test_accumulated_flow_edge_cases_empty_image_and_oversized_image(tmp_path):
+    """An image without detections (its npz is written, empty), an image with more crops than the threshold (one flush of its own, chunked
+    by AENet's max_batch_size inside predict), a flush that ends exactly on the threshold, and flush_pending() called twice."""
+    model = build_from_reference_cfg(tmp_path, "chain", 16)
+    tset = factory.TemplateSet(2, 12, seed=90)
+    model.template_datasets = {"syn": tset}
+    model.test_dataset_name = "syn"
+    model.run_id = "r0"
+    sizes = [5, 0, 11, 70, 16, 3]
+    batches = []
+    for i, n in enumerate(sizes):
+        b, _ = image_batch(tset, 400 + i, max(n, 1), view_id=30 + i)
+        if n == 0:   # no detection in this image: empty tensors, empty infos, empty test list
+            b = b[[]]
+            b.test_list = b.test_list[[]] if hasattr(b, "test_list") else None
+            from gigapose_amd.tensor_collection import PandasTensorCollection
+
+            b.test_list = PandasTensorCollection(infos=pd.DataFrame(dict(im_id=[], scene_id=[], obj_id=[], inst_count=[], detection_time=[])))
+        batches.append(b)
+    for i, b in enumerate(batches):
+        assert model.test_step(b, i) == 0
+    model.flush_pending()
+    model.flush_pending()
+    assert model._pending == [] and model._in_flight is None and model._pending_crops == 0
+    pred_dir = os.path.join(str(tmp_path), "predictions")
+    for i, n in enumerate(sizes):
+        with np.load(os.path.join(pred_dir, f"{i}.npz")) as z:
+            assert z["poses"].shape == (n, 5, 4, 4) and z["scores"].shape == (n, 5) and len(z["object_id"]) == n
+            assert np.isfinite(z["poses"]).all()

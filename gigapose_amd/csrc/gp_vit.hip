@@ -232,28 +232,36 @@ __global__ __launch_bounds__(1024) void layernorm_planes_kernel(const float* __r
 // layernorm_wide_kernel's contiguous slices: y agrees with it to f32 round-off, not bit for bit).  Conversion: each thread
 // packs (hi, lo) of its 8 channels of chunk k into one 32-byte LDS row piece; after the barrier 16 consecutive lanes read
 // the 16 pieces of one token and store 256 contiguous bytes per plane.
-template <int NK>
+// TOK (round 5): tokens per block.  32 by default; 16 when 32-token blocks would cover at most half the CUs (ViT-L up to 15 crops): 16
+// tokens x 32 channel slices -- twice the blocks, half the values per thread (a chunk is then 256 channels, a token's store 512
+// contiguous bytes per plane).  Measured (tools/gpu_r05_ln16.sh, two alternating rounds on one box): 8 crops 12.1 -> 10.6 us per launch
+// (the 8-crop step 8.93 -> 8.82 ms); at 16 / 24 crops (129 / 193 blocks) the 16-token form is SLOWER (13.0 -> 15.6, 15.1 -> 17.3 us: twice
+// the blocks with 64-byte token segments) -- hence the threshold at 128 blocks.  The per-thread summation order of the statistics differs
+// between the two forms: they agree to f32 round-off, not bit for bit -- like two batch shapes.
+template <int NK, int TOK = 32>
 __global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* __restrict__ X, _Float16* __restrict__ Yhi,
                                                                     _Float16* __restrict__ Ylo, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, int Mpad, float eps,
                                                                     int* __restrict__ status, float plane_scale, float* __restrict__ amax)
 {
-    constexpr int C = 128 * NK, TP = 132;  // LDS row pitch in words: 16-byte aligned pieces, tokens 33 sixteen-byte slots apart
-    __shared__ float red[16][32];
-    __shared__ __attribute__((aligned(16))) unsigned int tile[2][32 * TP];
+    constexpr int C = 128 * NK, SL = 512 / TOK, CH = 8 * SL, NC = C / CH;  // slices, channels per chunk, chunks
+    constexpr int TP = CH + 4;  // LDS row pitch in words: 16-byte aligned pieces, consecutive tokens one 16-byte slot off the bank period
+    static_assert(C % CH == 0 && (TOK == 32 || TOK == 16), "layernorm_planes_reg_kernel: C must be a multiple of the chunk width");
+    __shared__ float red[SL][TOK];
+    __shared__ __attribute__((aligned(16))) unsigned int tile[2][TOK * TP];
     // gamma | beta once per block through LDS (requested with the activations, visible after the first barrier): read from global
     // memory inside the chunk loop they were eight dependent L2 round trips per block -- hidden by the other blocks of a CU at 64
     // crops, 4 of the 13 us of a launch at 8 (65 blocks on 256 CUs)
     __shared__ __attribute__((aligned(16))) float gb[2][C];
-    const int tok = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const size_t tok0 = (size_t)blockIdx.x * 32;
-    float xv[NK][8];
+    const int tok = threadIdx.x & (TOK - 1), sl = threadIdx.x / TOK;
+    const size_t tok0 = (size_t)blockIdx.x * TOK;
+    float xv[NC][8];
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < NK; ++k)
+    for (int k = 0; k < NC; ++k)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            xv[k][e] = X[(size_t)(128 * k + 8 * sl + e) * Mpad + tok0 + tok];
+            xv[k][e] = X[(size_t)(CH * k + 8 * sl + e) * Mpad + tok0 + tok];
             s += xv[k][e];
         }
     for (int c = threadIdx.x; c < C; c += 512) {
@@ -264,12 +272,12 @@ __global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* 
     __syncthreads();
     float tot = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) tot += red[j][tok];
+    for (int j = 0; j < SL; ++j) tot += red[j][tok];
     const float mean = tot / (float)C;
     __syncthreads();
     float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < NK; ++k)
+    for (int k = 0; k < NC; ++k)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float d = xv[k][e] - mean;
@@ -279,16 +287,16 @@ __global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* 
     __syncthreads();
     tot = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) tot += red[j][tok];
+    for (int j = 0; j < SL; ++j) tot += red[j][tok];
     const float rstd = 1.0f / __builtin_sqrtf(tot / (float)C + eps);
-    const int g2 = threadIdx.x & 15, t2 = threadIdx.x >> 4;  // store phase: 16 lanes = the 16 eight-channel pieces of token t2
+    const int g2 = threadIdx.x & (SL - 1), t2 = threadIdx.x / SL;  // store phase: SL lanes = the SL eight-channel pieces of token t2
     const size_t row = (tok0 + t2) * C + 8 * g2;
     int bad = 0;
     float vmax = 0.f;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
+    for (int k = 0; k < NC; ++k) {
         unsigned int* T = tile[k & 1];
-        const int c = 128 * k + 8 * sl;
+        const int c = CH * k + 8 * sl;
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(gb[0] + c), g1 = *reinterpret_cast<const f32x4*>(gb[0] + c + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(gb[1] + c), b1 = *reinterpret_cast<const f32x4*>(gb[1] + c + 4);
         unsigned int w[8];
@@ -316,8 +324,8 @@ __global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* 
             h[4 + e] = __builtin_bit_cast(_Float16, (unsigned short)(r1[e] & 0xffffu));
             l[4 + e] = __builtin_bit_cast(_Float16, (unsigned short)(r1[e] >> 16));
         }
-        *reinterpret_cast<v16x8*>(Yhi + row + 128 * k) = h;
-        *reinterpret_cast<v16x8*>(Ylo + row + 128 * k) = l;
+        *reinterpret_cast<v16x8*>(Yhi + row + CH * k) = h;
+        *reinterpret_cast<v16x8*>(Ylo + row + CH * k) = l;
     }
     if (bad) gp_raise(status, GP_ST_SPLIT_RANGE);
     if (amax) gp_record_amax(amax, vmax, 1.0f / plane_scale);
@@ -425,14 +433,16 @@ extern "C" void gp_vit_set_ln_fold(int on) { g_ln_fold = (on >= -1 && on <= 2) ?
 
 static int g_attn_probe = 0;     // timing probe (gp_vit_set_attn_probe): 1 = return after staging, 2 = after query 256
 extern "C" void gp_vit_set_attn_probe(int mode) { g_attn_probe = mode; }
-static int g_ln_planes_reg = 1;  // A/B hook (gp_vit_set_ln_reg): 0 = the three-pass kernel
-extern "C" void gp_vit_set_ln_reg(int on) { g_ln_planes_reg = on ? 1 : 0; }
+static int g_ln_planes_reg = 1;  // A/B hook (gp_vit_set_ln_reg): 0 = the three-pass kernel, 2 = always the 32-token blocks
+extern "C" void gp_vit_set_ln_reg(int on) { g_ln_planes_reg = (on >= 0 && on <= 2) ? on : 1; }
 
 int launch_layernorm_planes(const float* X, _Float16* hi, _Float16* lo, const float* g, const float* b, int C, int Mpad, float eps,
                             hipStream_t st, float plane_scale = kPlaneScale, float* amax = nullptr)
 {
     GpProfScope prof(GP_PROF_LN, 8.0 * C * Mpad, st);
-    if (g_ln_planes_reg && C == 1024 && Mpad % 32 == 0)
+    if (g_ln_planes_reg && C == 1024 && Mpad % 32 == 0 && Mpad / 32 <= 128 && g_ln_planes_reg != 2)   // at most half a block per CU: 16-token blocks
+        hipLaunchKernelGGL((layernorm_planes_reg_kernel<8, 16>), dim3(Mpad / 16), dim3(512), 0, st, X, hi, lo, g, b, Mpad, eps, gp_status_buffer(), plane_scale, amax);
+    else if (g_ln_planes_reg && C == 1024 && Mpad % 32 == 0)
         hipLaunchKernelGGL(layernorm_planes_reg_kernel<8>, dim3(Mpad / 32), dim3(512), 0, st, X, hi, lo, g, b, Mpad, eps, gp_status_buffer(), plane_scale, amax);
     else if (g_ln_planes_reg && C == 768 && Mpad % 32 == 0)
         hipLaunchKernelGGL(layernorm_planes_reg_kernel<6>, dim3(Mpad / 32), dim3(512), 0, st, X, hi, lo, g, b, Mpad, eps, gp_status_buffer(), plane_scale, amax);

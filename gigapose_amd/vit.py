@@ -270,6 +270,8 @@ class Dinov2ViT(nn.Module):
                 _lib.lib().gp_gemm_planes256_set_par(int(os.environ["GIGAPOSE_PLANES_PAR"]))
             if "GIGAPOSE_PLANES_HALF" in os.environ:  # A/B probe: 0 = no 256 x 128 tiles below half a tile per slot
                 _lib.lib().gp_gemm_planes256_set_half_tiles(int(os.environ["GIGAPOSE_PLANES_HALF"]))
+            if "GIGAPOSE_LN_REG" in os.environ:      # A/B probe: 2 = LayerNorm always in 32-token blocks (default: 16-token blocks up to 128 blocks), 0 = the three-pass kernel
+                _lib.lib().gp_vit_set_ln_reg(int(os.environ["GIGAPOSE_LN_REG"]))
             if "GIGAPOSE_PLANES_DP" in os.environ:   # A/B probe: 0 = every plane-GEMM tile cut stream-K style
                 _lib.lib().gp_gemm_planes256_set_dp(int(os.environ["GIGAPOSE_PLANES_DP"]))
             if self.ln_fold == 2:   # A/B probe of the ping-pong residual stream; folding itself follows the packing (n_split = 28 per

@@ -290,6 +290,8 @@ void gp_vit_set_ln_fold(int on); /* A/B override: -1 (default) a forward folds i
  * residual stream is kept) -> token-major activation planes hi / lo [Mpad][C] (x 8); HF modeling_dinov2.py:342-380 norm1 / norm2. */
 int gp_layernorm_planes(const float* X, void* out_hi, void* out_lo, const float* gamma, const float* beta, int C, int Mpad, float eps,
                         void* stream);
+void gp_vit_set_ln_reg(int mode); /* A/B hook of the plane path's LayerNorm: 1 (default) 32-token blocks, 16-token blocks when the launch has at most
+                                    128 of them (ViT-L up to 15 crops: +1.3 % at 8 crops; slower above); 2 always 32-token blocks; 0 the first-generation three-pass kernel */
 void gp_vit_set_planes(int mode); /* 2 (default) = planes + attention in split numerics, 1 = planes + f32 attention, 0 = off */
 
 /* softmax(q k^T / 8) v per (image, head) in split numerics (attention_split_kernel): qkv_hi/lo = f16 planes [Mpad][3 dim]

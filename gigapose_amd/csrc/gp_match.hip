@@ -647,11 +647,17 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
 // per 32 channels (the first version) 64 query rows re-read their 1 MB 32 times each -- 0.5-0.66 ms per step for a 67 MB
 // conversion (rocprofv3, profiles/r02_kernel_stats.txt); 4 chunks keep 256 CUs busy at an eighth of the traffic.
 __global__ __launch_bounds__(256) void l2norm_split_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
-                                                            _Float16* __restrict__ lo, int C, int Cp)
+                                                            _Float16* __restrict__ lo, int C, int Cp,
+                                                            const float* __restrict__ mask_img = nullptr, int mh = 0, int mw = 0,
+                                                            float* __restrict__ patch_mask = nullptr)
 {
     __shared__ float t[32][GP_P + 1];
     __shared__ float dn[GP_P];
     const int row = blockIdx.x, p = threadIdx.x;
+    // (round 5) the row's 16 x 16 patch mask = F.interpolate(mask, (16, 16)) nearest (matching.py:222, 227) = pixel (i H / 16, j W / 16) of
+    // its H x W mask, written by the row's first block: the strided copy was the one ATen launch left between the ViT and the matcher
+    if (patch_mask && blockIdx.y == 0)
+        patch_mask[(size_t)row * GP_P + p] = mask_img[(size_t)row * mh * mw + (size_t)((p >> 4) * (mh / GP_G)) * mw + (p & 15) * (mw / GP_G)];
     const float* xr = x + (size_t)row * C * GP_P;
     float ss = 0.f;
     int c = 0;
@@ -856,16 +862,24 @@ int gp_match_tiles(const float* query, const float* bank, const float* qmask, co
                               mask_all, sim_avg, stream);
 }
 
-int gp_l2norm_split(const float* x, void* hi, void* lo, int rows, int C, void* stream)
+int gp_l2norm_split_mask(const float* x, void* hi, void* lo, int rows, int C, const float* mask_img, int mask_h, int mask_w,
+                         float* patch_mask, void* stream)
 {
     GP_REQUIRE(rows >= 0 && C > 0, "gp_l2norm_split: bad arguments (rows=%d C=%d)", rows, C);
     if (rows == 0) return GP_OK;
     GP_REQUIRE(x && hi && lo, "gp_l2norm_split: null pointer");
+    GP_REQUIRE(!patch_mask || (mask_img && mask_h > 0 && mask_w > 0 && mask_h % GP_G == 0 && mask_w % GP_G == 0),
+               "gp_l2norm_split_mask: the mask image must be (rows, H, W) f32 with H, W multiples of 16 (got %d x %d)", mask_h, mask_w);
     const int ngrp = (C + 31) / 32;
     hipLaunchKernelGGL(l2norm_split_kernel, dim3(rows, ngrp < 4 ? ngrp : 4), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)hi,
-                       (_Float16*)lo, C, ngrp * 32);
+                       (_Float16*)lo, C, ngrp * 32, mask_img, mask_h, mask_w, patch_mask);
     GP_CHECK_LAUNCH("gp_l2norm_split");
     return GP_OK;
+}
+
+int gp_l2norm_split(const float* x, void* hi, void* lo, int rows, int C, void* stream)
+{
+    return gp_l2norm_split_mask(x, hi, lo, rows, C, nullptr, 0, 0, nullptr, stream);
 }
 
 static int g_match_compact = 1;  // 0: every patch treated as live = the full 256 x 256 tile (A/B hook: gp_match_split_set_compact)

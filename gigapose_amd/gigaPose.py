@@ -501,7 +501,11 @@ class GigaPose(_Base):
                 self._in_flight = self._run_flush(nxt["images"], nxt["dataset_name"])
         else:
             _lib.raise_status(bits)
-        assert int(job["host"]["bad_crop_M"][0]) == 0, "tar_M must be an isotropic scale + translation"   # reference lib3d/torch.py:54-55
+        if int(job["host"]["bad_crop_M"][0]) != 0:   # reference lib3d/torch.py:54-55 (the device flag is persistent: clear it before raising)
+            flag = self.pose_recovery[job["dataset_name"]]._flag
+            if flag is not None:
+                flag.zero_()
+            raise AssertionError("tar_M must be an isotropic scale + translation")
         total_ms = 1e3 * job["wall_s"] if "wall_s" in job else job["ev"][0].elapsed_time(job["ev"][1])
         scores, poses = job["host"]["scores"].numpy(), job["host"]["pred_poses"].numpy()
         n_all, a = len(job["labels"]), 0

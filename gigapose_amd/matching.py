@@ -33,15 +33,26 @@ def patch_grid_mask(mask224):
 default_numerics = _lib.default_numerics   # "split" unless GIGAPOSE_NUMERICS=chain (the verification mode)
 
 
-def normalize_split(feats):
+def normalize_split(feats, mask224=None):
     """(rows, C, 256) f32 -> matcher-normalised, x32, split into f16 planes (hi, lo), each (rows, 256, Cp) with
-    Cp = round_up(C, 32) (zero padded: the split matcher consumes 32 channels per step)."""
+    Cp = round_up(C, 32) (zero padded: the split matcher consumes 32 channels per step).  With mask224 (rows, H, W) f32 the same
+    launch also writes the rows' patch masks (rows, 256) = patch_grid_mask(mask224), returned third."""
     rows, C = feats.shape[:2]
     x = feats.reshape(rows, C, P).contiguous().float()
     hi = torch.empty(rows, P, (C + 31) // 32 * 32, dtype=torch.float16, device=x.device)
     lo = torch.empty_like(hi)
-    _lib.call("gp_l2norm_split", _lib.ptr(x), _lib.ptr(hi), _lib.ptr(lo), _lib.i(rows), _lib.i(C), _lib.stream_ptr())
-    return hi, lo
+    if mask224 is None:
+        _lib.call("gp_l2norm_split", _lib.ptr(x), _lib.ptr(hi), _lib.ptr(lo), _lib.i(rows), _lib.i(C), _lib.stream_ptr())
+        return hi, lo
+    fused = (mask224.dtype == torch.float32 and mask224.is_contiguous() and mask224.dim() == 3 and mask224.shape[0] == rows
+             and mask224.shape[1] % 16 == 0 and mask224.shape[2] % 16 == 0)
+    if not fused:   # another dtype / layout: the strided copy
+        _lib.call("gp_l2norm_split", _lib.ptr(x), _lib.ptr(hi), _lib.ptr(lo), _lib.i(rows), _lib.i(C), _lib.stream_ptr())
+        return hi, lo, patch_grid_mask(mask224)
+    qmask = torch.empty(rows, P, dtype=torch.float32, device=x.device)
+    _lib.call("gp_l2norm_split_mask", _lib.ptr(x), _lib.ptr(hi), _lib.ptr(lo), _lib.i(rows), _lib.i(C), _lib.ptr(mask224),
+              _lib.i(mask224.shape[1]), _lib.i(mask224.shape[2]), _lib.ptr(qmask), _lib.stream_ptr())
+    return hi, lo, qmask
 
 
 class MatchBank:
@@ -185,8 +196,12 @@ class LocalSimilarity(torch.nn.Module):
     # ---- resident-bank entry point (what GigaPose.eval_retrieval uses) --------------------
     def test_bank(self, bank, tar_feat, tar_mask, labels0):
         """tar_feat (B,C,16,16) AENet features, tar_mask (B,224,224), labels0 (B,) 0-based."""
-        query = self.normalize(tar_feat)
-        qmask = patch_grid_mask(tar_mask)
+        if self.numerics == "split":   # normalise + split + the patch masks in ONE launch
+            hi, lo, qmask = normalize_split(tar_feat.reshape(tar_feat.shape[0], tar_feat.shape[1], P), tar_mask)
+            query = (hi, lo)
+        else:
+            query = self.normalize(tar_feat)
+            qmask = patch_grid_mask(tar_mask)
         idx, sc, ma, avg = self.match_tiles(query, qmask, bank, labels0.to(torch.int32).contiguous())
         ids, score_src, rec_score, tar_pts, src_pts = self.select_topk(avg, idx, sc, ma)
         return PandasTensorCollection(infos=pd.DataFrame(), id_src=ids, score_src=score_src,

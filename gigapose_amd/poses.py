@@ -67,6 +67,7 @@ class ObjectPoseRecovery(torch.nn.Module):
         # "deferred": leave the device flag in self.deferred_flag for a caller that synchronises later (GigaPose's flush pipeline)
         self.check_asserts = True
         self.deferred_flag = None
+        self._flag = None   # the kernel only ORs into it; it stays zero unless an assert is about to fire: no per-call fill launch
 
     @torch.no_grad()
     def forward_recovery(self, tar_label, tar_K, tar_M, pred_src_views, pred_M, labels0=None):
@@ -79,7 +80,9 @@ class ObjectPoseRecovery(torch.nn.Module):
         if labels0 is None:
             labels0 = (tar_label.to(dev) - 1).to(torch.int32).contiguous()
         poses = torch.empty(B, k, 4, 4, dtype=torch.float32, device=dev)
-        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        if self._flag is None or self._flag.device != dev:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        flag = self._flag
         _lib.call("gp_recover_poses", _lib.ptr(labels0), _lib.ptr(tar_K.contiguous().float()),
                   _lib.ptr(tar_M.contiguous().float()), _lib.ptr(pred_src_views.contiguous().long()),
                   _lib.ptr(pred_M.contiguous().float()), _lib.ptr(self.template_K), _lib.ptr(self.template_Ms),
@@ -89,7 +92,10 @@ class ObjectPoseRecovery(torch.nn.Module):
             self.deferred_flag = flag
         elif self.check_asserts and B > 0:
             # reference lib3d/torch.py:54-55 asserts the crop transform is isotropic scale + translation
-            assert int(flag.item()) == 0, "tar_M must be an isotropic scale + translation"
+            bad = int(flag.item())
+            if bad:
+                flag.zero_()
+            assert bad == 0, "tar_M must be an isotropic scale + translation"
         return poses
 
     @torch.no_grad()

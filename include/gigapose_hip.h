@@ -103,6 +103,10 @@ int gp_match_tiles_dir(const float* query, const float* bank, const float* qmask
  * gp_match_tiles_split: query planes (B,256,Cp), bank planes (O,N,256,Cp); C here = Cp; everything else as
  * gp_match_tiles. */
 int gp_l2norm_split(const float* x, void* hi, void* lo, int rows, int C, void* stream);
+/* + in the same launch the rows' 16 x 16 patch masks: patch_mask (rows, 256) f32 = mask_img (rows, mask_h, mask_w) f32 sampled at pixel
+ * (i mask_h / 16, j mask_w / 16) = F.interpolate(mask, (16, 16)) nearest (matching.py:222, 227); patch_mask NULL = gp_l2norm_split. */
+int gp_l2norm_split_mask(const float* x, void* hi, void* lo, int rows, int C, const float* mask_img, int mask_h, int mask_w,
+                         float* patch_mask, void* stream);
 int gp_match_tiles_split(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
                          const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
                          float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,

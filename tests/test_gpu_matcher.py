@@ -329,3 +329,22 @@ def test_select_topk_equals_topk_gather_format():
         assert torch.equal(rec_score2, rec_score) and torch.equal(tar2, tar) and torch.equal(src2, src)
     with pytest.raises(RuntimeError):
         LocalSimilarity(k=7, sim_threshold=0.5, patch_threshold=3).select_topk(avg_d[:, :6].contiguous(), idx_d, sc_d, ma_d)
+
+
+def test_patch_masks_written_by_the_normalise_launch_equal_the_strided_copy():
+    """gp_l2norm_split_mask (round 5): the query's 16 x 16 patch masks come out of the normalise + split launch; they must equal
+    patch_grid_mask (= F.interpolate(mask, (16, 16)) nearest, matching.py:222, 227) for 224 x 224 and other 16-divisible sizes, and the
+    planes must be the ones gp_l2norm_split writes.  Other dtypes / layouts take the strided copy."""
+    from gigapose_amd.matching import normalize_split, patch_grid_mask
+
+    rs = np.random.RandomState(3)
+    for B, C, H, W in [(5, 64, 224, 224), (3, 384, 64, 96), (64, 1024, 224, 224)]:
+        feats = torch.from_numpy(rs.standard_normal((B, C, 256)).astype(np.float32)).to(DEV)
+        mask = torch.from_numpy((rs.rand(B, H, W) > 0.4).astype(np.float32) * rs.rand(B, H, W).astype(np.float32)).to(DEV)
+        hi0, lo0 = normalize_split(feats)
+        hi, lo, qm = normalize_split(feats, mask)
+        assert torch.equal(hi, hi0) and torch.equal(lo, lo0) and torch.equal(qm, patch_grid_mask(mask))
+        hi, lo, qm = normalize_split(feats, mask.double())                       # not f32: the fallback path, same values
+        assert torch.equal(qm, patch_grid_mask(mask)) and torch.equal(hi, hi0)
+        hi, lo, qm = normalize_split(feats, mask.transpose(1, 2).contiguous().transpose(1, 2))   # not contiguous
+        assert torch.equal(qm, patch_grid_mask(mask))

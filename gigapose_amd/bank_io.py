@@ -29,7 +29,7 @@ from .tensor_collection import PandasTensorCollection
 
 MAGIC = b"GPBANK01"
 ALIGN = 4096
-_NP = {"float32": np.float32, "float16": np.float16, "int64": np.int64, "uint8": np.uint8}
+_NP = {"float32": np.float32, "float64": np.float64, "float16": np.float16, "int64": np.int64, "uint8": np.uint8}
 
 
 def write_sections(path, meta, arrays):
@@ -81,6 +81,11 @@ def save_bank(model, dataset_name, path):
             arrays["match_lo"] = bank.lo.cpu().numpy()
     else:
         arrays["match_f32"] = bank.features.cpu().numpy()
+    # the ViT's plane-scale calibration (max |x| per (layer, tensor), vit.py) travels with the bank: a model started from the file
+    # has never seen the templates, and would otherwise find its outlier tensors by tripping the range guard on the first query
+    vit = getattr(getattr(model, "ae_net", None), "dinov2_model", None)
+    if bank.numerics == "split" and getattr(vit, "plane_amax", None) is not None:
+        arrays["vit_plane_amax"] = np.asarray(vit.plane_amax, dtype=np.float64)
     return write_sections(path, dict(numerics=bank.numerics, bank_dtype=getattr(bank, "bank_dtype", "f32"), O=bank.O, N=bank.N, C=bank.C), arrays)
 
 
@@ -120,4 +125,7 @@ def load_bank(model, dataset_name, path, shard=None, group=None):
         model.match_banks[dataset_name] = ShardedMatcher(model.testing_metric, bank, lo, group)
     model.pose_recovery[dataset_name] = ObjectPoseRecovery(template_K=data["K"], template_Ms=data["M"],
                                                            template_poses=data["poses"])
+    vit = getattr(getattr(model, "ae_net", None), "dinov2_model", None)
+    if "vit_plane_amax" in h["sections"] and hasattr(vit, "adopt_plane_amax"):
+        vit.adopt_plane_amax(np.array(map_section(path, h, "vit_plane_amax")))   # running maximum with what the model already knows
     return h

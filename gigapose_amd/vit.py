@@ -337,6 +337,20 @@ class Dinov2ViT(nn.Module):
         self.plane_scales = None if all(v == 8.0 for v in new) else new
         return changed
 
+    def adopt_plane_amax(self, amax):
+        """Take over a calibration made elsewhere (bank_io: the onboarding process saved it with the bank): running maximum with what
+        this model has seen itself, scales re-picked.  Returns True if a scale changed."""
+        import numpy as np
+
+        amax = np.asarray(amax, dtype=np.float64).reshape(self.depth, 4)
+        if not np.isfinite(amax).all() or (amax < 0).any():
+            raise ValueError("plane-scale calibration: the adopted maxima must be finite and non-negative")
+        self.plane_amax = amax.copy() if self.plane_amax is None else np.maximum(self.plane_amax, amax)
+        new = [self.scale_for(float(a), self.plane_headroom) for a in self.plane_amax.reshape(-1)]
+        old = self.plane_scales or [8.0] * (self.depth * 4)
+        self.plane_scales = None if all(v == 8.0 for v in new) else new
+        return new != old
+
     def plane_scale_report(self):
         """{(layer, tensor): (amax, scale)} for every tensor whose scale is not the default 8 (diagnostics, bench.py)."""
         if self.plane_scales is None or self.plane_amax is None:

@@ -80,3 +80,46 @@ def test_fp16_bank_file_round_trip_and_8_way_shards(tmp_path):
         assert torch.equal(sm.bank.hi, full.hi[:, lo:hi]) and torch.equal(sm.bank.masks, full.masks[:, lo:hi])
         sizes.append(hi - lo)
     assert sum(sizes) == 162 and sorted(sizes, reverse=True) == [21, 21, 20, 20, 20, 20, 20, 20]
+
+
+def test_bank_file_carries_the_plane_scale_calibration(tmp_path):
+    """A model started from a bank file has never seen the templates: the ViT's plane-scale calibration (round 5) travels in the file.
+    Weights with planted outliers (synthetic.plant_dinov2_outliers, ViT-L width, 2 blocks): the onboarding model calibrates, saves;
+    the loading model adopts the calibration, predicts WITHOUT tripping the range guard (no warning), and equals the onboarding
+    model's predictions bit for bit."""
+    import warnings
+
+    from gigapose_amd import _lib
+    from gigapose_amd import synthetic as syn
+    from gigapose_amd.vit import Dinov2ViT
+    from test_gpu_guards import _gigapose_with_vit
+
+    dev = torch.device("cuda", 0)
+
+    def make():
+        return _gigapose_with_vit(syn.plant_dinov2_outliers(syn.fill_state_dict(Dinov2ViT(1024, 2, 16), 11).eval()).to(dev))
+
+    tset = factory.TemplateSet(1, 64, seed=80)
+    q = tset.crops(81, 64, dev)
+    a = make()
+    a.template_datasets = {"syn": tset}
+    a.set_template_data("syn")
+    report = a.ae_net.dinov2_model.plane_scale_report()
+    assert report, "the planted outliers must have lowered some plane scales"
+    path = str(tmp_path / "outliers.gpbank")
+    hdr = bank_io.save_bank(a, "syn", path)
+    assert "vit_plane_amax" in hdr["sections"]
+    ref = a.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
+    torch.cuda.synchronize()
+    _lib.check_status()
+    b = make()
+    assert b.ae_net.dinov2_model.plane_scales is None
+    bank_io.load_bank(b, "syn", path)
+    assert b.ae_net.dinov2_model.plane_scale_report() == report
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = b.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
+        torch.cuda.synchronize()
+        _lib.check_status()                                       # clean: no range trip on the first query
+    for n, v in ref.tensors.items():
+        assert torch.equal(v, got.tensors[n]), n

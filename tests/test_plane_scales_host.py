@@ -34,3 +34,15 @@ def test_calibration_state_and_report():
     vit.plane_scales = [8.0] * 8
     vit.load_state_dict(vit.state_dict())                              # so do newly loaded weights
     assert vit.plane_scales is None
+
+
+def test_a_calibration_can_be_adopted_from_a_bank_file():
+    vit = Dinov2ViT(384, 2, 6)
+    assert vit.adopt_plane_amax(np.array([[1.0, 2.0, 3.0, 4.0], [5.0, 6.0, 7.0, 8.0]])) is False and vit.plane_scales is None
+    assert vit.plane_amax is not None                                  # "calibrated": set_template_data will not calibrate again
+    assert vit.adopt_plane_amax(np.array([[0.0, 0.0, 0.0, 1.2e4], [0.0, 0.0, 0.0, 0.0]])) is True
+    assert vit.plane_scale_report() == {"L0.gelu": (1.2e4, 1.0)} and vit.plane_amax[1, 3] == 8.0     # running maximum
+    import pytest
+
+    with pytest.raises(ValueError):
+        vit.adopt_plane_amax(np.full((2, 4), np.nan))

@@ -90,3 +90,29 @@ def test_fused_multiply_convert_pitfall():
     mixed = hi_two_step.astype(np.float64) + lo.astype(np.float64)   # ... storing the other hi with that lo is not
     bad = np.abs(mixed - v32) > 2.0 ** -12
     assert bad.any() and bad.mean() < 1e-3                  # rare (ties only), but an f16 ulp of hi when it happens
+
+
+def test_a_lower_plane_scale_only_raises_the_subnormal_floor():
+    """The error model behind the per-tensor plane scales (round 5): with scale s, an element keeps 22 bits while
+    |s x| >= 2^-3 (lo a normal f16); below that lo is quantised to f16's subnormal spacing, an ABSOLUTE error of 2^-25 / s.  Going from
+    s = 8 to s = 1 (a tensor holding an outlier of ~1e4) therefore leaves a GEMM over activation-like values f32-class: the dot product's
+    error grows by the floor term only, far below the f32 chain's 3.9e-7 of sum |a||b|."""
+    rng = np.random.RandomState(2)
+    x = rng.randn(200000) * np.exp(rng.uniform(-4, 2, 200000))
+    for s in (8.0, 1.0, 0.125):
+        hi, lo = split(x, s)
+        err = np.abs((hi + lo) / s - x.astype(np.float32))
+        big = np.abs(s * x) >= 2.0 ** -3
+        assert (err[big] / np.abs(x[big])).max() < 2.0 ** -21
+        assert err[~big].max() <= 2.0 ** -25 / s * 1.0001
+    K = 4096
+    w = rng.randn(32, K) * 0.03
+    act = np.maximum(rng.randn(48, K), 0.0) * 0.8      # GELU-like: half zeros, a right tail
+    act[:, 7] = 1.2e4                                   # the massive unit that forces s = 1
+    ref = w.astype(np.float32).astype(np.float64) @ act.astype(np.float32).astype(np.float64).T
+    mag = np.abs(w) @ np.abs(act).T
+    e1 = (np.abs(split_matmul(w, act, 64.0, 1.0) - ref) / mag).max()
+    assert e1 < 2e-7, e1
+    # with the default s = 8 the same tensor does not fit f16 at all: the outlier's hi plane is inf
+    with np.errstate(over="ignore"):
+        assert not np.isfinite(split(act, 8.0)[0]).all()

@@ -84,3 +84,16 @@ def test_bench_without_a_launcher_spawns_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["config"]["parallelism"] == "sharded2"
     assert "spawning" in r.stderr
+
+
+def test_bench_main_world8_prints_one_line_with_both_modes():
+    """The shape of the driver's scaling run at N = 8 (one rank per GPU of a node): eight gloo ranks through bench.py's own main() with the
+    stub model -- the both-modes block with the two exchanges of gigapose_amd/sharding.py among eight ranks, the max-over-ranks time, the
+    per-rank gather of eight entries, one JSON line."""
+    out = launch(8, ["--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "4"], timeout=400)
+    cfg = out["config"]
+    assert out["n_gpus"] == 8 and cfg["rccl_ranks"] == 8 and cfg["global_batch"] == 32 and cfg["parallelism"] == "sharded8"
+    assert len(cfg["per_rank_ms_per_step"]) == 8 and out["scaling"] == "weak"
+    other = out["other_modes"]["replicas"]
+    assert "error" not in other and other["parallelism"] == "replicas8" and len(other["per_rank_ms_per_step"]) == 8
+    assert abs(out["value"] - 8 * 4 * 2 / (out["ms_per_step"] * 2 / 1e3)) / out["value"] < 1e-3

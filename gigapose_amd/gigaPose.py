@@ -90,6 +90,7 @@ class GigaPose(_Base):
         super().__init__()
         numerics = kwargs.pop("numerics", None)
         accumulate = kwargs.pop("accumulate_crops", None)
+        ownership = kwargs.pop("image_ownership", None)
         self.model_name = model_name
         self.ae_net = ae_net
         self.ist_net = ist_net
@@ -126,9 +127,20 @@ class GigaPose(_Base):
         # written then.  0 = the reference's flow (one predict per image, file written before test_step returns).  `accumulate_crops:`
         # in the model YAML (read from **kwargs like `numerics`) or GIGAPOSE_ACCUMULATE_CROPS.
         self.accumulate_crops = int(os.environ.get("GIGAPOSE_ACCUMULATE_CROPS", "64")) if accumulate is None else int(accumulate)
-        self._pending = []        # queued images: (batch, idx_batch)
+        self._pending = []        # queued images: (batch, idx_batch, (dataset_name, log_dir, test_setting) when queued)
         self._pending_crops = 0
         self._in_flight = None    # the flush whose kernels are queued on the GPU while the host writes the previous flush's files
+        self._sharded_flow = None  # sharded_flow.ShardedFlow: test_step's fixed-size flushes when the template bank is sharded
+        # Who computes which image when several ranks run the reference's test loop?  The reference's webdataset pipeline has no
+        # split_by_node (reference src/custom_megapose/web_scene_dataset.py:207-215): under a multi-process launch EVERY rank
+        # replays EVERY image and overwrites predictions/<idx>.npz (reference gigaPose.py:611), i.e. N GPUs give 1 x throughput.
+        # `image_ownership: round_robin` (model YAML, next to `numerics`; env GIGAPOSE_IMAGE_OWNERSHIP=round_robin): test_step
+        # skips images with idx_batch % world != rank (ranks of the default process group, or of the shard group when the bank is
+        # sharded); rank 0 merges all ranks' files in on_test_epoch_end after a barrier.  Off (None) by default: a single process,
+        # or a loader that already splits the images, needs nothing.
+        self.image_ownership = (os.environ.get("GIGAPOSE_IMAGE_OWNERSHIP") or None) if ownership is None else (ownership or None)
+        if self.image_ownership not in (None, "round_robin"):
+            raise ValueError("image_ownership must be None or 'round_robin'")
         if numerics is not None:
             self.set_numerics(numerics)
 
@@ -295,11 +307,12 @@ class GigaPose(_Base):
 
     # ------------------------------------------------------------------ the hot loop
     @torch.no_grad()
-    def predict(self, tar_img, tar_mask, tar_K, tar_M, labels, dataset_name, sort_pred_by_inliers=True):
+    def predict(self, tar_img, tar_mask, tar_K, tar_M, labels, dataset_name, sort_pred_by_inliers=True, exchange_aux=None):
         """Device-only part of eval_retrieval (gigaPose.py:511-604): crops -> sorted pose hypotheses.
         labels: (B) int tensor of 1-based object labels.  Returns a PandasTensorCollection with
         id_src, score_src, score_pts, tar_pts, src_pts, relScale, relInplane, idx_failed, M,
-        ransac_*, scores (B,k), pred_poses (B,k,4,4)."""
+        ransac_*, scores (B,k), pred_poses (B,k,4,4).  `exchange_aux` (sharded bank only): a (B,) int32 word per crop that
+        travels with exchange #1; all ranks' words are in `self.match_banks[dataset_name].last_aux` afterwards."""
         bank = self.match_banks[dataset_name]
         template_data = self.template_datas[dataset_name]
         n_obj = template_data.ist_features.shape[0]
@@ -332,7 +345,7 @@ class GigaPose(_Base):
                 tar_ist = self.ist_net.forward_by_chunk(tar_img)                 # stage 4a: IST backbone (once)
         else:
             # sharded bank: exchange #1 (query features to every rank) travels while the IST backbone runs
-            pending = bank.start_exchange(tar_ae, tar_mask, labels0)
+            pending = bank.start_exchange(tar_ae, tar_mask, labels0, exchange_aux)
             if side is None:
                 tar_ist = self.ist_net.forward_by_chunk(tar_img)
             pred = bank.finish(pending)                                          # match the shard + exchange #2 + merge
@@ -407,41 +420,74 @@ class GigaPose(_Base):
     def test_step(self, batch, idx_batch):
         """Reference signature and return value (gigaPose.py:635-642).  With accumulate_crops > 0 the image is queued and the work
         happens at the next flush (see __init__); eval_retrieval itself is unchanged and immediate."""
+        if self.image_ownership == "round_robin":
+            rank, world = self._image_ranks()
+            if idx_batch % world != rank:
+                return 0                       # another rank's image (see __init__)
+        if self.template_shard is not None and self._flushable(batch):
+            # sharded bank: ranks see different images with different detection counts, the exchanges are fixed-size collectives --
+            # crop-granular queue, flushes of exactly accumulate_crops rows, collectively agreed end (sharded_flow.py)
+            self._flow().push(batch, idx_batch)
+            return 0
         if not self._accumulating(batch):
-            self.flush_pending()   # keep file order if the mode is switched mid-run
-            if self.accumulate_crops == 0 and self._flushable(batch):
+            if self.template_shard is None:
+                self.flush_pending()   # keep file order if the mode is switched mid-run
+            if self.accumulate_crops == 0 and self.template_shard is None and self._flushable(batch):
                 # the reference's flow -- one predict() per image, its file on disk when test_step returns -- through the lean host
                 # writer of the flushes (scores / poses downloaded once, selection in numpy) instead of filter_and_save's ~20 device
                 # gathers for a `predictions[selected]` nobody reads here: 1.4 ms per image (bench.py: dropin_flow.per_image)
                 if self.test_dataset_name not in self.template_datas:
                     self.set_template_data(self.test_dataset_name)
                 t0 = time.time()
-                job = self._run_flush([(batch, idx_batch)], self.test_dataset_name)
+                job = self._run_flush([(batch, idx_batch, self._bind())], self.test_dataset_name)
                 job["ev"][1].synchronize()
                 job["wall_s"] = time.time() - t0       # `time` of the npz = this call's wall clock, as the reference measures it
                 self._finish_flush(job)
                 return 0
             self.eval_retrieval(batch, idx_batch=idx_batch, dataset_name=self.test_dataset_name)
             return 0
-        self._pending.append((batch, idx_batch))
+        bound = self._bind()
+        if self._pending and self._pending[-1][2] != bound:
+            self.flush_pending()               # the driver re-pointed the model (dataset / log_dir / setting): what is queued belongs to the old one
+        self._pending.append((batch, idx_batch, bound))
         self._pending_crops += len(batch.infos)
         if self._pending_crops >= self.accumulate_crops:
             self._launch_flush()
         return 0
 
     def _flushable(self, batch):
-        # sharded bank: every rank must enter the fixed-size exchanges with the same batch size -- ranks see different images, so the
-        # flush sizes would differ: the sharded drop-in keeps eval_retrieval's per-image flow (which agrees on the batch size first)
-        return self.template_shard is None and getattr(batch, "test_list", None) is not None and batch.tar_img.is_cuda
+        return getattr(batch, "test_list", None) is not None and batch.tar_img.is_cuda
 
     def _accumulating(self, batch):
-        return self.accumulate_crops > 0 and self._flushable(batch)
+        return self.accumulate_crops > 0 and self.template_shard is None and self._flushable(batch)
+
+    def _bind(self):
+        """What a queued image belongs to, taken when it is queued (a driver may re-point the model between test_steps)."""
+        return (self.test_dataset_name, self.log_dir, self.test_setting)
+
+    def _flow(self):
+        if self._sharded_flow is None:
+            from .sharded_flow import ShardedFlow
+
+            self._sharded_flow = ShardedFlow(self)
+        return self._sharded_flow
+
+    def _image_ranks(self):
+        """(rank, world) for image ownership and for the end-of-epoch barrier: the shard group if the bank is sharded, else the
+        default process group, else a single process."""
+        import torch.distributed as dist
+
+        if self.template_shard is not None:
+            return self.template_shard[0], self.template_shard[1]
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
 
     @torch.no_grad()
     def _launch_flush(self):
         """Queue ONE predict() over the pending images (whole images, at least one, up to accumulate_crops crops) on the GPU without
         waiting for it, then write the files of the PREVIOUS flush while this one runs."""
-        dataset_name = self.test_dataset_name
+        dataset_name = self._pending[0][2][0] if self._pending else self.test_dataset_name
         if dataset_name not in self.template_datas:
             self.set_template_data(dataset_name)
         take, n = [], 0
@@ -455,16 +501,30 @@ class GigaPose(_Base):
             self._finish_flush(prev)
 
     def _run_flush(self, images, dataset_name):
-        batches = [b for b, _ in images]
+        batches = [im[0] for im in images]
         cat = (lambda name: batches[0].tensors[name]) if len(batches) == 1 else (lambda name: torch.cat([b.tensors[name] for b in batches], dim=0))
         labels_np = np.concatenate([np.asarray(b.infos.label).astype(np.int32) for b in batches])
-        dev = batches[0].tar_img.device
+        job = self._run_rows({n: cat(n) for n in ("tar_img", "tar_mask", "tar_K", "tar_M")}, labels_np, dataset_name)
+        job["images"] = images
+        return job
+
+    def _run_rows(self, inputs, labels_np, dataset_name, aux=None):
+        """The device half of a flush: ONE predict() over the rows of `inputs`, queued without a host wait, and what the host needs
+        afterwards copied to pinned memory BEHIND the kernels.  `aux` (sharded flow only): an int the ranks exchange with this
+        flush (sharded_flow.py)."""
+        dev = inputs["tar_img"].device
+        n = len(labels_np)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         recovery = self.pose_recovery[dataset_name]
         keep_asserts, recovery.check_asserts = recovery.check_asserts, ("deferred" if recovery.check_asserts else False)
+        sharded = self.template_shard is not None
+        aux_t = None
+        if sharded:
+            aux_t = torch.full((n,), int(aux or 0), dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
         try:
-            pred = self.predict(cat("tar_img"), cat("tar_mask"), cat("tar_K"), cat("tar_M"), torch.from_numpy(labels_np), dataset_name)
+            pred = self.predict(inputs["tar_img"], inputs["tar_mask"], inputs["tar_K"], inputs["tar_M"], torch.from_numpy(labels_np), dataset_name,
+                                exchange_aux=aux_t)
         finally:
             recovery.check_asserts = keep_asserts
         # what the files and the guard rails need, to pinned host memory BEHIND the kernels (stream order; no host wait here): scores,
@@ -474,49 +534,71 @@ class GigaPose(_Base):
         flag = recovery.deferred_flag if keep_asserts else None
         host = {"scores": torch.empty(pred.scores.shape, dtype=pred.scores.dtype, pin_memory=True),
                 "pred_poses": torch.empty(pred.pred_poses.shape, dtype=pred.pred_poses.dtype, pin_memory=True),
-                "status": torch.zeros(1, dtype=torch.int32, pin_memory=True), "bad_crop_M": torch.zeros(1, dtype=torch.int32, pin_memory=True)}
+                "bad_crop_M": torch.zeros(1, dtype=torch.int32, pin_memory=True)}
         host["scores"].copy_(pred.scores, non_blocking=True)
         host["pred_poses"].copy_(pred.pred_poses, non_blocking=True)
-        host["status"].copy_(word, non_blocking=True)
+        if sharded:
+            # every rank's status word of THIS flush (one 4-byte-per-rank all-gather), so that all ranks take the same recovery
+            # decision in the same place; and all ranks' exchange words (they arrived with exchange #1)
+            from .sharding import all_gather_rows
+
+            words, _ = all_gather_rows(word.view(1, 1), self.template_shard[2])
+            host["status"] = torch.zeros(words.shape[0], dtype=torch.int32, pin_memory=True)
+            host["status"].copy_(words.reshape(-1), non_blocking=True)
+            aux_all = self.match_banks[dataset_name].last_aux
+            host["aux_all"] = torch.zeros(aux_all.shape[0], dtype=torch.int32, pin_memory=True)
+            host["aux_all"].copy_(aux_all, non_blocking=True)
+        else:
+            host["status"] = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+            host["status"].copy_(word, non_blocking=True)
         word.zero_()
         if flag is not None:
             host["bad_crop_M"].copy_(flag, non_blocking=True)
         ev1.record()
-        return dict(images=images, labels=labels_np, pred=pred, host=host, ev=(ev0, ev1), dataset_name=dataset_name, device=dev)
+        return dict(inputs=inputs, labels=labels_np, pred=pred, host=host, ev=(ev0, ev1), dataset_name=dataset_name, device=dev)
+
+    def _clear_crop_flag(self, dataset_name):
+        flag = self.pose_recovery[dataset_name]._flag   # the device flag is persistent: clear it before raising
+        if flag is not None:
+            flag.zero_()
 
     def _finish_flush(self, job):
         """Wait for a flush, check the guard rails, write one <idx>.npz per image (contents = filter_and_save's, reference
         gigaPose.py:400-449) with `time` = the flush's device time apportioned by crop count."""
         job["ev"][1].synchronize()
-        bits = int(job["host"]["status"][0])           # this flush's own bits (snapshot + clear in stream order, _run_flush)
-        if bits & _lib.SPLIT_RANGE_BITS and self._recover_range(bits, [b.tar_img for b, _ in job["images"]]):
-            # the kernels of the NEXT flush (already queued) ran with the narrow planes too: redo both, in order
-            nxt, self._in_flight = self._in_flight, None
-            self._drain_device()
-            redo = self._run_flush(job["images"], job["dataset_name"])
-            redo["ev"][1].synchronize()
-            _lib.raise_status(int(redo["host"]["status"][0]))   # a second trip raises
-            job = redo
-            if nxt is not None and nxt is not job:
-                self._in_flight = self._run_flush(nxt["images"], nxt["dataset_name"])
-        else:
-            _lib.raise_status(bits)
-        if int(job["host"]["bad_crop_M"][0]) != 0:   # reference lib3d/torch.py:54-55 (the device flag is persistent: clear it before raising)
-            flag = self.pose_recovery[job["dataset_name"]]._flag
-            if flag is not None:
-                flag.zero_()
+        bits = int(job["host"]["status"][0])           # this flush's own bits (snapshot + clear in stream order, _run_rows)
+        redone = False
+        while bits & _lib.SPLIT_RANGE_BITS and self._recover_range(bits, [im[0].tar_img for im in job["images"]]):
+            # a remedy applied (plane scales re-calibrated, or a network moved to its wide kernels): run the flush again.  The loop ends
+            # when the flush is clean or no remedy is left (a trip with both the ViT and the IST bit may need both, one per pass)
+            if not redone:   # the kernels of the NEXT flush (already queued) ran with the old planes too: redo both, in order
+                nxt, self._in_flight = self._in_flight, None
+                self._drain_device()
+                redone = True
+            wall = "wall_s" in job
+            t0 = time.time()
+            job = self._run_flush(job["images"], job["dataset_name"])
+            job["ev"][1].synchronize()
+            if wall:
+                job["wall_s"] = time.time() - t0       # the per-image flow reports wall clock: the redo's own
+            bits = int(job["host"]["status"][0])
+        _lib.raise_status(bits)
+        if redone and nxt is not None:
+            self._in_flight = self._run_flush(nxt["images"], nxt["dataset_name"])
+        if int(job["host"]["bad_crop_M"][0]) != 0:   # reference lib3d/torch.py:54-55
+            self._clear_crop_flag(job["dataset_name"])
             raise AssertionError("tar_M must be an isotropic scale + translation")
         total_ms = 1e3 * job["wall_s"] if "wall_s" in job else job["ev"][0].elapsed_time(job["ev"][1])
         scores, poses = job["host"]["scores"].numpy(), job["host"]["pred_poses"].numpy()
         n_all, a = len(job["labels"]), 0
-        keep = self.test_setting == "localization"
-        for batch, idx_batch in job["images"]:
+        for batch, idx_batch, (_, log_dir, test_setting) in job["images"]:
             n = len(batch.infos)
-            save_path = osp.join(self.log_dir, "predictions", f"{idx_batch}.npz")
-            self._save_image(batch.infos, batch.test_list, scores[a:a + n], poses[a:a + n], 1e-3 * total_ms * n / max(n_all, 1), save_path, keep)
+            save_path = osp.join(log_dir, "predictions", f"{idx_batch}.npz")
+            self._save_image(batch.infos, batch.test_list, scores[a:a + n], poses[a:a + n], 1e-3 * total_ms * n / max(n_all, 1), save_path,
+                             test_setting == "localization")
             a += n
         pred = job["pred"]
-        pred.infos = pd.concat([b.infos for b, _ in job["images"]], axis=0, sort=False).reset_index(drop=True)
+        pred.infos = pd.concat([im[0].infos for im in job["images"]], axis=0, sort=False).reset_index(drop=True)
         self.last_predictions = pred
 
     @staticmethod
@@ -549,7 +631,12 @@ class GigaPose(_Base):
 
     def flush_pending(self):
         """Run what is queued and write every outstanding file (on_test_epoch_end calls it; a caller that reads the npz files between
-        test_steps calls it too)."""
+        test_steps calls it too).  With a sharded bank this is a COLLECTIVE: every rank of the shard group must call it (the ranks
+        agree inside the flushes on when all queues are empty, sharded_flow.py)."""
+        if self.template_shard is not None:
+            if self._sharded_flow is not None or self.test_dataset_name is not None:
+                self._flow().drain()
+            return
         while self._pending:
             self._launch_flush()
         if self._in_flight is not None:
@@ -563,6 +650,14 @@ class GigaPose(_Base):
         """Merge the per-batch npz files into the BOP csv files (reference gigaPose.py:644-653 ->
         src/utils/inout.py:278-367; here gigapose_amd/inout.py, byte-identical output)."""
         self.flush_pending()
+        # The reference wrote every file inside test_step; here each rank's last flushes are written by flush_pending() just above:
+        # rank 0 must not start merging before every rank's files are on disk (ADVICE r5) -- one barrier when several ranks run.
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            group = self.template_shard[2] if self.template_shard is not None else None
+            if dist.get_world_size(group) > 1:
+                dist.barrier(group=group)
         if self.global_rank != 0:
             return
         from .inout import save_predictions_from_batched_predictions

@@ -123,21 +123,25 @@ def _align16(n):
     return (n + 15) // 16 * 16
 
 
-def pack_query(q, qmask, labels0):
+def pack_query(q, qmask, labels0, aux=None):
     """Exchange #1 payload, one byte row per crop: matcher-normalised features (f32 (B,C,256), or the f16 hi / lo planes
-    (B,256,Cp) of the split numerics) | patch mask f32[256] | label i32, every field at a 16-byte aligned offset of a
-    preallocated row (one copy per field, no concatenation temporaries): 1 MB per crop at C = 1024.
+    (B,256,Cp) of the split numerics) | patch mask f32[256] | label i32 [| aux i32], every field at a 16-byte aligned offset
+    of a preallocated row (one copy per field, no concatenation temporaries): 1 MB per crop at C = 1024.  `aux` (B,) int32 is
+    an optional per-crop word the caller wants every rank to see (the accumulated drop-in flow sends its "this rank has nothing
+    left" flag with it, gigapose_amd/sharded_flow.py); it is the LAST field and unpack_query skips it (unpack_aux reads it).
     Returns (rows (B, L) u8, layout)."""
     B = qmask.shape[0]
     feats = list(q) if isinstance(q, (tuple, list)) else [q]
     fields = [f.contiguous() for f in feats] + [qmask.contiguous().float(), labels0.to(torch.int32).contiguous()]
+    if aux is not None:
+        fields.append(aux.to(device=qmask.device, dtype=torch.int32).contiguous())
     layout, off = [], 0
-    for f in fields:
+    for j, f in enumerate(fields):
         nbytes = f[0].numel() * f.element_size() if B else 0
-        layout.append((tuple(f.shape[1:]), f.dtype, off, nbytes))
+        layout.append((tuple(f.shape[1:]), f.dtype, off, nbytes) + (("aux",) if aux is not None and j == len(fields) - 1 else ()))
         off = _align16(off + nbytes)
     rows = torch.empty(B, off, dtype=torch.uint8, device=qmask.device)
-    for f, (_, _, o, nbytes) in zip(fields, layout):
+    for f, (_, _, o, nbytes, *_tag) in zip(fields, layout):
         rows[:, o:o + nbytes] = f.view(torch.uint8).reshape(B, nbytes)
     return rows, layout
 
@@ -146,10 +150,19 @@ def unpack_query(rows, layout):
     """Inverse of pack_query for (n, L) u8 rows: (features or (hi, lo)), qmask (n,256) f32, labels (n,) i32 (contiguous
     copies: the kernels take dense arrays)."""
     n, out = rows.shape[0], []
-    for shape, dtype, o, nbytes in layout:
-        out.append(rows[:, o:o + nbytes].contiguous().view(dtype).reshape(n, *shape))
+    for shape, dtype, o, nbytes, *tag in layout:
+        if not tag:
+            out.append(rows[:, o:o + nbytes].contiguous().view(dtype).reshape(n, *shape))
     feats, qmask, labels = out[:-2], out[-2], out[-1]
     return (feats[0] if len(feats) == 1 else tuple(feats)), qmask, labels
+
+
+def unpack_aux(rows, layout):
+    """The optional per-crop int32 word of pack_query(aux=...) for (n, L) rows: (n,) int32, or None if the rows carry none."""
+    for shape, dtype, o, nbytes, *tag in layout:
+        if tag:
+            return rows[:, o:o + nbytes].contiguous().view(dtype).reshape(rows.shape[0])
+    return None
 
 
 def pack_candidates(ids_global, scores, rec_idx, rec_score, rec_mask):
@@ -207,17 +220,19 @@ class ShardedMatcher:
         self.metric, self.bank, self.lo, self.group = metric, bank_shard, template_lo, group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.last_aux = None
         if bank_shard.N < metric.k:
             raise ValueError(f"shard of {bank_shard.N} templates is smaller than k={metric.k}")
 
     @torch.no_grad()
-    def start_exchange(self, tar_feat, tar_mask, labels0):
+    def start_exchange(self, tar_feat, tar_mask, labels0, aux=None):
         """Exchange #1, asynchronous: pack this rank's matcher-normalised query features, patch masks and labels into one byte
         row per crop and all-gather them in ONE collective.  RCCL runs it on its own stream; the caller keeps launching
-        independent work (the IST backbone, gigaPose.py) and calls finish() when it needs the matches."""
+        independent work (the IST backbone, gigaPose.py) and calls finish() when it needs the matches.  `aux` (B,) int32:
+        an optional word per crop that travels with the row; after finish() `self.last_aux` holds all ranks' words (W * B,)."""
         from .matching import patch_grid_mask
 
-        rows, layout = pack_query(self.metric.normalize(tar_feat), patch_grid_mask(tar_mask), labels0)
+        rows, layout = pack_query(self.metric.normalize(tar_feat), patch_grid_mask(tar_mask), labels0, aux)
         allrows, work = all_gather_rows(rows, self.group, async_op=True)
         return dict(rows=allrows, work=work, layout=layout, n_own=tar_feat.shape[0])
 
@@ -234,6 +249,7 @@ class ShardedMatcher:
         if h["rows"].shape[0] != n_ranks * h["n_own"]:
             raise ValueError(f"exchange #1 returned {h['rows'].shape[0]} rows for {n_ranks} ranks x {h['n_own']} crops: every rank must pass the same batch size")
         q, qmask, labels_all = unpack_query(h["rows"], h["layout"])
+        self.last_aux = unpack_aux(h["rows"], h["layout"])
         idx, sc, ma, avg = m.match_tiles(q, qmask, self.bank, labels_all)
         ids, score = m.topk(avg)
         rec_idx, rec_score, rec_mask = m.gather_records(ids, idx, sc, ma)
@@ -243,5 +259,5 @@ class ShardedMatcher:
         return PandasTensorCollection(infos=pd.DataFrame(), id_src=gid, score_src=gsc, score_pts=rsc.contiguous(),
                                       tar_pts=tar_pts, src_pts=src_pts)
 
-    def test_bank(self, tar_feat, tar_mask, labels0):
-        return self.finish(self.start_exchange(tar_feat, tar_mask, labels0))
+    def test_bank(self, tar_feat, tar_mask, labels0, aux=None):
+        return self.finish(self.start_exchange(tar_feat, tar_mask, labels0, aux))

@@ -306,14 +306,17 @@ class Dinov2ViT(nn.Module):
         writes (gp_vit_forward_split2: plane_amax); the running maximum over all calibration passes of this model picks the scales.
         Returns True if a scale changed.  `sync_ranks`: the ranks of `group` (None = the default group) calibrate together (sharded
         template bank: every rank must end up with the same scales) -- the maxima are all-reduced.  A non-finite activation raises."""
-        if self.numerics != "split" or self.split_gemm == "128" or images.shape[0] == 0:
+        active = self.numerics == "split" and self.split_gemm != "128"
+        if not sync_ranks and (not active or images.shape[0] == 0):
             return False
+        # with sync_ranks a rank that has nothing to measure (no image, or not on the plane path) still takes part in the
+        # all-reduce below with zeros: its peers are inside that collective (ADVICE r5)
         device = images.device
         amax = torch.zeros(self.depth * 4, dtype=torch.float32, device=device)
         keep = self.plane_scales
         self.plane_scales = [self.CALIBRATION_SCALE] * (self.depth * 4)
         try:
-            for s0 in range(0, images.shape[0], chunk):
+            for s0 in range(0, images.shape[0] if active else 0, chunk):
                 self.patch_features(images[s0:s0 + chunk], plane_amax=amax)
         finally:
             self.plane_scales = keep
@@ -327,6 +330,8 @@ class Dinov2ViT(nn.Module):
                     amax = host
                 else:
                     dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=group)
+        if not active:
+            return False
         seen = amax.double().cpu().numpy().reshape(self.depth, 4)      # a host synchronisation: calibration is outside every timed region
         if not bool((seen == seen).all()) or not bool((seen < float("inf")).all()):
             raise _lib.GigaPoseHipError("plane-scale calibration: a ViT activation is not finite (NaN / inf input or weights)")

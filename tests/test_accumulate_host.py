@@ -48,6 +48,7 @@ class _Model(GigaPose):
         os.makedirs(os.path.join(log_dir, "predictions"), exist_ok=True)
         self.template_datas, self.template_shard = {"syn": object()}, None
         self.accumulate_crops, self._pending, self._pending_crops, self._in_flight = accumulate, [], 0, None
+        self.image_ownership, self._sharded_flow = None, None
         self.flushes, self.trip_on_flush, self.widened, self.clock = [], None, 0, 0.0
         self.model_name, self.run_id = "large", "r0"
 
@@ -63,15 +64,15 @@ class _Model(GigaPose):
         return self.widened == 1
 
     def _run_flush(self, images, dataset_name):
-        imgs = torch.cat([b.tar_img for b, _ in images])
+        imgs = torch.cat([im[0].tar_img for im in images])
         res = [crop_result(i) for i in imgs]
         status = 0
         if self.trip_on_flush is not None and len(self.flushes) == self.trip_on_flush and not self.widened:
             status = 4                                           # the range bit of the split planes
-        self.flushes.append([idx for _, idx in images])
+        self.flushes.append([im[1] for im in images])
         t0 = self.clock
         self.clock += 10.0
-        labels = np.concatenate([np.asarray(b.infos.label).astype(np.int32) for b, _ in images])
+        labels = np.concatenate([np.asarray(im[0].infos.label).astype(np.int32) for im in images])
         pred = PandasTensorCollection(infos=pd.DataFrame(), scores=torch.from_numpy(np.stack([r[0] for r in res])),
                                       pred_poses=torch.from_numpy(np.stack([r[1] for r in res])))
         host = dict(scores=pred.scores, pred_poses=pred.pred_poses, status=torch.tensor([status], dtype=torch.int32),

@@ -36,7 +36,24 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense f32-input MFMA peak (MI355X_MICROARCH.md)
 FLOP_PER_CROP = {"dinov2_vitl14": 162.0e9, "dinov2_vits14": 12.25e9, "dinov2_vitb14": 0.0}
-REFERENCE_OVER_PORT = round(0.953 / 1.021, 3)  # unmodified reference / oracle.torch_port, same crops + threads + process (profiles/r03_cpu_reference_vs_port.txt)
+ANCHOR_FILE = os.path.join(ROOT, "profiles", "r06_cpu_reference_vs_port.txt")
+
+
+def reference_over_port(threads):
+    """unmodified reference / oracle.torch_port wall-clock ratio, same crops + threads + process, measured in the build container by
+    oracle/time_reference.py at the thread count it is applied to: read from the committed measurement file."""
+    vals = {}
+    try:
+        for ln in open(ANCHOR_FILE):
+            if ln.startswith("reference_over_port_") and "=" in ln:
+                k, v = ln.split("=")
+                vals[int(k.strip().split("_")[3])] = float(v)
+    except OSError:
+        pass
+    if not vals:
+        return None, None
+    t = min(vals, key=lambda n: abs(n - threads))
+    return vals[t], t
 
 
 _REAL_STDOUT = None   # a dup of the process's original fd 1 once main() has pointed fd 1 at stderr
@@ -64,6 +81,69 @@ def spawn_ranks(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stderr.write("bench.py: no launcher environment (RANK / WORLD_SIZE unset) -- spawning " + " ".join(cmd) + "\n")
     return subprocess.call(cmd, env=dict(os.environ, GIGAPOSE_BENCH_SPAWNED="1"))
+
+
+def traffic_commit():
+    """Provenance of the STATIC traffic figure: the commit profiles/pmc_traffic.json was last written at (build
+    container: git is there), when tools/pmc_summary.py recorded it, and whether the kernel sources it was recorded on are the ones in
+    this tree (sha1 over gigapose_amd/csrc/*.hip + *.h, stamped into the file by pmc_summary.py)."""
+    import glob
+    import hashlib
+    import subprocess
+
+    out = {}
+    try:
+        r = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h %cs", "--", "profiles/pmc_traffic.json"], capture_output=True, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            out["commit"] = r.stdout.strip()
+    except Exception:
+        pass
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        out["recorded_at"] = pmc.get("_recorded_at")
+        if pmc.get("_kernel_sources_sha1"):
+            h = hashlib.sha1()
+            csrc = os.path.join(ROOT, "gigapose_amd", "csrc")
+            for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+                h.update(open(f, "rb").read())
+            out["recorded_on_these_kernel_sources"] = h.hexdigest() == pmc["_kernel_sources_sha1"]
+    except Exception:
+        pass
+    return out or None
+
+
+def matrix_ceiling_on_this_socket():
+    """What v_mfma_f32_32x32x16_f16 sustains on THIS socket right now (tools/ubench/mfma_ceiling.hip `brief`: 0.4 s per line, after the
+    timed region): MFMA-only loops with all-zero and with random-normal operands, and the 3-product split pattern fed from LDS with its
+    reads one step ahead (the structure of gemm_planes256_kernel's k loop, nothing else in the kernel).  The guide's 2495 TFLOP/s is the
+    ZERO-data number; real data runs into the socket's 1400 W cap at ~0.65 of it (profiles/r06_ubench_mfma_ceiling.txt).  None if the
+    binary is not built (python -c 'import __graft_entry__ as g; g.build()')."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "tools", "ubench", "_mfma_ceiling")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "brief", "0.4"], capture_output=True, text=True, timeout=60)
+    except Exception:
+        return None
+    out = {}
+    for ln in r.stdout.splitlines():
+        if "TFLOP/s" not in ln:
+            continue
+        tf = float(ln.split("TFLOP/s")[0].split()[-1])
+        mhz = float(ln.split("clk")[1].split()[0])
+        watts = float(ln.split("smi:")[1].split()[0]) if "smi:" in ln else 0.0
+        rec = {"tflops": round(tf, 1), "in_kernel_clock_mhz": round(mhz), "socket_watts": round(watts)}
+        if ln.startswith("R  same") and " zeros " in ln:
+            out["mfma_only_zero_operands"] = rec
+        elif ln.startswith("R  same") and " normal " in ln:
+            out["mfma_only_random_operands_same_registers"] = rec
+        elif ln.startswith("R  8 + 8") and " normal " in ln:
+            out["mfma_only_random_operands"] = rec
+        elif ln.startswith("LPP 2x4") and " normal " in ln:
+            out["split_pattern_from_lds_random_operands"] = rec
+    return out or None
 
 
 def sustained_matrix_clock_mhz(lib, dev):
@@ -139,14 +219,15 @@ def cpu_baseline(variant, n_templates, k, sample_crops=32, threads=None):
     t0 = time.time()
     torch_port.eval_retrieval(hf, ist, bank_ae, bank_ist, masks, geom, q, k, dets_per_forward=4)
     dt = time.time() - t0
+    ratio, ratio_threads = reference_over_port(threads)
     return {"value": round(sample_crops / dt, 4), "unit": "query-crops/sec", "cores": threads, "kind": "port",
             "host_logical_cpus": os.cpu_count(), "cpus_in_affinity_mask": avail,
             # the anchor to the UNMODIFIED reference (which cannot travel to the GPU box): both timed in one process on the same
             # 32 crops / threads in the build container by oracle/time_reference.py -> profiles/r03_cpu_reference_vs_port.txt
-            "reference_over_port": REFERENCE_OVER_PORT,
-            "reference_equivalent_value": round(REFERENCE_OVER_PORT * sample_crops / dt, 4),
-            "reference_over_port_source": "profiles/r03_cpu_reference_vs_port.txt: unmodified reference 0.953 crops/s vs this port 1.021 crops/s "
-                                          "(8 threads, 32 crops x 162 templates, ViT-L/14 stand-in, same process, build container)",
+            "reference_over_port": ratio,
+            "reference_equivalent_value": None if ratio is None else round(ratio * sample_crops / dt, 4),
+            "reference_over_port_source": f"profiles/r06_cpu_reference_vs_port.txt: the unmodified reference and this port timed in one process on the same "
+                                          f"32 crops x 162 templates at {ratio_threads} torch threads in the build container (idle), oracle/time_reference.py",
             "sample": f"{sample_crops} crops x {n_templates} templates, {variant}, oracle/torch_port.py (torch-CPU restatement of the "
                       f"reference's eval_retrieval, f32, sub-batches of 4, IST backbone x k as the reference recomputes it), "
                       f"torch threads = {threads} (the host reports {os.cpu_count()} logical CPUs, {avail} in this process's affinity mask; "
@@ -565,7 +646,9 @@ def main():
                 other_configs["config5"] = {"workload": "HANDAL/HOPE scale: 40 objects x 162 templates, fp16 feature bank resident in HBM, 1 GPU "
                                                         f"(unsharded replica), batch={args.batch}",
                                             **time_batch("config5", tset5, 40, args.batch, n_half), "numerics": args.numerics, "bank_dtype": "f16",
-                                            "matcher_bank_GB": round(nbytes / 1e9, 3), "onboarding_s_per_object": round(t_on / 40, 3)}
+                                            "matcher_bank_GB": round(nbytes / 1e9, 3), "onboarding_s_per_object": round(t_on / 40, 3),
+                                            "parity": "bounded, not exact: the f16-rounded template features flip ~10 of 2.65 M patch ids and 4 of 64 "
+                                                      "top-5 sets end to end (tests/test_gpu_parity_big.py); the f32-class bank (6.8 GB) is the parity mode"}
                 drop("config5")
                 del tset5
             except Exception as e:
@@ -711,6 +794,7 @@ def main():
         alg = g.get("TFLOP/s", 0.0)            # algorithmic 2 I J K flops of the launches / their event-timed duration
         executed = round(3.0 * alg, 2)         # what the matrix core executes: 3 f16 MFMAs per f32-equivalent product block
         clk = None if stub else sustained_matrix_clock_mhz(lib, dev)
+        ceil = None if stub else matrix_ceiling_on_this_socket()
         roofline = {"kernel": "gemm_planes256_kernel (ViT linear layers; 3 x v_mfma_f32_32x32x16_f16 per k-block on f16-split f32 "
                               "operands held as hi / lo planes, f32 accumulate)", "bound": "mfma",
                     # achieved / frac: USEFUL work against the roofline, as SURVEY 8(d) defines it (162 GFLOP / crop figure -> 2 I J K per
@@ -720,14 +804,23 @@ def main():
                     "executed_tflops": executed,
                     "mfma_util_executed": round(executed / F16_MFMA_PEAK_TFLOPS, 4),
                     "sustained_matrix_clock_mhz": clk,
-                    "mfma_util_at_sustained_clock": (round(executed / (F16_MFMA_PEAK_TFLOPS * clk / PEAK_CLOCK_MHZ), 4) if clk else None),
+                    # round 6: the ceiling is MEASURED on this socket, after the timed region, by an MFMA-only loop on random data (the
+                    # guide's 2495 TFLOP/s reproduces with all-zero operands only; random data hits the 1400 W cap at ~0.65 of it)
+                    "sustained_mfma_only_tflops": (ceil or {}).get("mfma_only_random_operands", {}).get("tflops"),
+                    "sustained_split_pattern_tflops": (ceil or {}).get("split_pattern_from_lds_random_operands", {}).get("tflops"),
+                    "executed_over_sustained_mfma_only": (round(executed / ceil["mfma_only_random_operands"]["tflops"], 4)
+                                                          if ceil and "mfma_only_random_operands" in ceil else None),
+                    "matrix_ceiling_ubench": ceil,
                     "frac_vs_f32_input_mfma_peak": round(alg / F32_MFMA_PEAK_TFLOPS, 3),
                     "note": "frac = useful (algorithmic) flops / f16 dense peak.  mfma_util_executed = 3 x that: the three f16 products per "
                             "f32-equivalent product all execute on the matrix core (north_star's MFMA-utilisation reading).  "
-                            "mfma_util_at_sustained_clock = executed / (peak x sustained_matrix_clock_mhz / 2400): the kernel runs at the "
-                            "socket's power limit; the clock is measured by the kernel's own cycle counter right after the timed region "
-                            "(bench.py: sustained_matrix_clock_mhz).  frac_vs_f32_input_mfma_peak: the same useful flops against the 157.3 "
-                            "TFLOP/s f32-input MFMA peak the reference's dtype would otherwise be bound by",
+                            "sustained_mfma_only_tflops: v_mfma_f32_32x32x16_f16 alone on random-normal operands, whole chip, 0.4 s, measured by "
+                            "tools/ubench/mfma_ceiling.hip right after the timed region -- the socket's power cap, not the 2.4 GHz clock, sets "
+                            "it (all-zero operands reach the guide's 2495); sustained_split_pattern_tflops: the same for the 3-product pattern "
+                            "with its 12 LDS fragment reads per 24 MFMAs.  executed_over_sustained_mfma_only = executed_tflops / the former: "
+                            "how much of what this socket can do on real data the whole kernel (epilogues, strip, prologue included) delivers.  "
+                            "frac_vs_f32_input_mfma_peak: the same useful flops against the 157.3 TFLOP/s f32-input MFMA peak the reference's "
+                            "dtype would otherwise be bound by",
                     "traffic": traffic}
     else:
         g = kern_timed.get("gemm_kmajor", {})
@@ -758,6 +851,7 @@ def main():
         "traffic_source": "STATIC: read from profiles/pmc_traffic.json, the rocprofv3 --pmc passes of this same command recorded by "
                           "tools/pmc_bench.sh (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction) -- PMC counters cannot be "
                           "collected inside the timed run",
+        "traffic_commit": traffic_commit(),
         "share_of_step": round(kern.get("gemm_split" if args.numerics == "split" else "gemm_kmajor", {}).get("ms_per_step", 0.0)
                                / (1e3 * dt_serial / args.steps), 3),
         "measured": f"live in THE timed region: HIP events on the launch stream around one in {SAMPLE_STRIDE} launches of this kernel family "

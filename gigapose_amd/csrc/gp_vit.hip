@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void transpose_tm_to_cm_kernel(const float* __
 static int g_ln_fold = -1;
 extern "C" void gp_vit_set_ln_fold(int on) { g_ln_fold = (on >= -1 && on <= 2) ? on : -1; }
 
-static int g_attn_probe = 0;     // timing probe (gp_vit_set_attn_probe): 1 = return after staging, 2 = after query 256
+static int g_attn_probe = 0;     // A/B hook (gp_vit_set_attn_probe): 1 = key chunk c + 1 staged under the matrix pass over chunk c (measured slower; default 0 = all chunks up front)
 extern "C" void gp_vit_set_attn_probe(int mode) { g_attn_probe = mode; }
 static int g_ln_planes_reg = 1;  // A/B hook (gp_vit_set_ln_reg): 0 = the three-pass kernel, 2 = always the 32-token blocks
 extern "C" void gp_vit_set_ln_reg(int on) { g_ln_planes_reg = (on >= 0 && on <= 2) ? on : 1; }
@@ -677,6 +677,34 @@ __device__ __forceinline__ unsigned lds_addr(const _Float16* p)  // byte address
 
 constexpr int ATH = 512;  // threads: eight waves = the eight full 32-query tiles (two waves per SIMD)
 
+// Pair conversions of the plane producers (as the GEMM epilogues, gp_split256.hip): two f32 values -> their packed f16 hi pair in one
+// v_cvt_pk_f16_f32, and the packed lo pair f16(v - hi) in one v_fma_mixlo_f16 + one v_fma_mixhi_f16 that read the f16 hi straight
+// from the packed register (v - hi is exact in f32, so the mixed fma's single rounding equals subtraction + conversion).
+typedef _Float16 av16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned attn_hi_pair(float v0, float v1)
+{
+    av16x2 h;
+    h[0] = (_Float16)v0;
+    h[1] = (_Float16)v1;
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ unsigned attn_lo_pair(float v0, float v1, unsigned hi)
+{
+    unsigned lo;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"   // the pair may be the next instruction's MFMA operand / store data: hipcc does not pad hazards behind an asm producer
+        : "=&v"(lo)
+        : "v"(v0), "v"(v1), "v"(hi));
+    return lo;
+}
+__device__ __forceinline__ float attn_max3(float a, float b, float c)
+{   // v_maximum3_f32 through the builtin, NOT inline asm: the operands are accumulator registers fresh from the matrix core, and
+    // hipcc pads MFMA -> VALU read hazards for its own instructions only (an asm v_max3_f32 here read stale registers: run-to-run
+    // differences in round 6's first build)
+    return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
+}
+
 __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __restrict__ QKVhi, const _Float16* __restrict__ QKVlo,
                                                                _Float16* __restrict__ Ohi, _Float16* __restrict__ Olo, int B, int H,
                                                                int C, int Mpad, int probe, float inv_s2)
@@ -693,47 +721,56 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const size_t ld = 3 * (size_t)C, tok0 = (size_t)b * T_TOK;
 
-    // ---- stage K (rows = keys) and V^T (rows = channels).  Threads 0..255 take the hi planes, 256..511 the lo planes; 8 lanes
-    // copy the 128 bytes of one key (coalesced), all loads first.  K rows go to LDS as they are.  V is transposed on the way:
-    // lanes L and L ^ 8 hold keys 2j and 2j + 1 of the same 8 channels -- they swap half of their data so that each writes
-    // FOUR dwords (key 2j | key 2j + 1 of one channel row) instead of eight scattered halfwords, which cost 8-way bank
-    // conflicts and 6 us of the 35 us a workgroup took (tools/probe_attn_split.py).  Key 257 = zeros (key 256's partner).
-    {
-        constexpr int NCHP = (T_TOK + 1) * 8, NIT = (NCHP + 255) / 256;
-        const int pl = tid >> 8, t8 = tid & 255;
-        const _Float16* Qsrc = (pl ? QKVlo : QKVhi) + tok0 * ld + C + h * 64;
-        _Float16* sK = pl ? sKl : sKh;
-        unsigned* sV = reinterpret_cast<unsigned*>(pl ? sVl : sVh);
-        const bool odd = (lane & 8) != 0;  // key parity: chunk c = t8 + 256 i -> key = c >> 3
-        au32x4 kv[NIT], vv[NIT];
+    // ---- staging of K (rows = keys) and V^T (rows = channels), BY KEY CHUNK (round 6).  Threads 0..255 take the hi planes, 256..511
+    // the lo planes; 8 lanes copy the 128 bytes of one key (coalesced); one "iteration" = 32 keys, three iterations = one chunk of 96
+    // keys = what one pass of the matrix loop below consumes.  K rows go to LDS as they are.  V is transposed on the way: lanes L and
+    // L ^ 8 hold keys 2j and 2j + 1 of the same 8 channels -- they swap half of their data so that each writes FOUR dwords (key 2j |
+    // key 2j + 1 of one channel row) instead of eight scattered halfwords (8-way bank conflicts, tools/probe_attn_split.py).
+    // Staging is written per chunk so that its order is a run-time choice (gp_vit_set_attn_probe): DEFAULT = every chunk staged before
+    // the first matrix pass; probe & 1 = only chunk 0 up front, chunk c + 1 LOADED (global -> registers) before the pass over chunk c and
+    // WRITTEN to its own LDS region after it (one barrier per chunk).  With ONE workgroup per CU (158 KB of LDS) nothing hides the
+    // up-front staging (25.6 of 105.7 us per launch, profiles/r02_probe_attention_split.txt) -- yet the pipelined order measured 5-9 %
+    // SLOWER in the same binary (97-109 us against 92-100 isolated, profiles/r06_attention.txt): the in-flight loads and the LDS writes
+    // land inside the matrix passes, where the vector / LDS pipes are the busy ones.  Built, measured, off.  The 257th query runs last.
+    const int pl = tid >> 8, t8 = tid & 255;
+    const _Float16* Ksrc = (pl ? QKVlo : QKVhi) + tok0 * ld + C + h * 64;
+    _Float16* sKp = pl ? sKl : sKh;
+    unsigned* sVp = reinterpret_cast<unsigned*>(pl ? sVl : sVh);
+    const bool odd = (lane & 8) != 0;  // key parity: piece c = t8 + 256 i -> key = c >> 3
+    au32x4 kv[3], vv[3];
+    auto load_chunk = [&](int c3) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int c = t8 + 256 * i, key = c >> 3, ch = c & 7;
-            kv[i] = au32x4{0u, 0u, 0u, 0u};
-            vv[i] = au32x4{0u, 0u, 0u, 0u};
+        for (int u = 0; u < 3; ++u) {
+            const int c = t8 + 256 * (3 * c3 + u), key = c >> 3, ch8 = c & 7;
+            kv[u] = au32x4{0u, 0u, 0u, 0u};
+            vv[u] = au32x4{0u, 0u, 0u, 0u};
             if (key < T_TOK) {
-                const _Float16* src = Qsrc + (size_t)key * ld + 8 * ch;
-                kv[i] = *reinterpret_cast<const au32x4*>(src);
-                vv[i] = *reinterpret_cast<const au32x4*>(src + C);
+                const _Float16* src = Ksrc + (size_t)key * ld + 8 * ch8;
+                kv[u] = *reinterpret_cast<const au32x4*>(src);
+                vv[u] = *reinterpret_cast<const au32x4*>(src + C);
             }
         }
+    };
+    auto store_chunk = [&](int c3) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int c = t8 + 256 * i, key = c >> 3, ch = c & 7;
-            // every lane takes part in the exchange (chunks past the plane carry zeros)
-            const unsigned r0 = __shfl_xor(odd ? vv[i][0] : vv[i][2], 8), r1 = __shfl_xor(odd ? vv[i][1] : vv[i][3], 8);
-            if (c < NCHP) {
-                *reinterpret_cast<au32x4*>(sK + key * AKS + 8 * ch) = kv[i];
-                const unsigned e0 = odd ? r0 : vv[i][0], e1 = odd ? r1 : vv[i][1];  // the even key's channels 4 odd .. 4 odd + 3
-                const unsigned o0 = odd ? vv[i][2] : r0, o1 = odd ? vv[i][3] : r1;  // the odd key's
-                unsigned* dst = sV + ((8 * ch + (odd ? 4 : 0)) * AVS + (key & ~1)) / 2;
+        for (int u = 0; u < 3; ++u) {
+            const int c = t8 + 256 * (3 * c3 + u), key = c >> 3, ch8 = c & 7;
+            // every lane takes part in the exchange (pieces past the plane carry zeros)
+            const unsigned r0 = __shfl_xor(odd ? vv[u][0] : vv[u][2], 8), r1 = __shfl_xor(odd ? vv[u][1] : vv[u][3], 8);
+            if (key < T_TOK + 1) {   // key 257 = zeros (key 256's partner in the transposition)
+                *reinterpret_cast<au32x4*>(sKp + key * AKS + 8 * ch8) = kv[u];
+                const unsigned e0 = odd ? r0 : vv[u][0], e1 = odd ? r1 : vv[u][1];  // the even key's channels 4 odd .. 4 odd + 3
+                const unsigned o0 = odd ? vv[u][2] : r0, o1 = odd ? vv[u][3] : r1;  // the odd key's
+                unsigned* dst = sVp + ((8 * ch8 + (odd ? 4 : 0)) * AVS + (key & ~1)) / 2;
                 dst[0 * (AVS / 2)] = (e0 & 0xffffu) | (o0 << 16);
                 dst[1 * (AVS / 2)] = (e0 >> 16) | (o0 & 0xffff0000u);
                 dst[2 * (AVS / 2)] = (e1 & 0xffffu) | (o1 << 16);
                 dst[3 * (AVS / 2)] = (e1 >> 16) | (o1 & 0xffff0000u);
             }
         }
-    }
+    };
+    const bool upfront = (probe & 1) == 0;
+    load_chunk(0);
     for (int c = tid; c < 2 * (AKEYS - T_TOK - 1) * 8; c += ATH) {  // keys 258..287: zero rows (masked below)
         const int plane = c >= (AKEYS - T_TOK - 1) * 8 ? 1 : 0, r = c - plane * (AKEYS - T_TOK - 1) * 8;
         *reinterpret_cast<au32x4*>((plane ? sKl : sKh) + (T_TOK + 1 + (r >> 3)) * AKS + 8 * (r & 7)) = au32x4{0u, 0u, 0u, 0u};
@@ -745,7 +782,6 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
             reinterpret_cast<unsigned*>(plane ? sVl : sVh)[((r / ZW) * AVS + T_TOK + 1) / 2 + r % ZW] = 0u;
         }
     }
-
     // ---- this wave's query tile: Q fragments (B operand: column = query, k = 8 half + e inside each 16-d block)
     const int tq = wave * 32 + l31;  // < 256: the eight waves cover queries 0..255
     const size_t qo = (tok0 + tq) * ld + h * 64 + 8 * half;
@@ -753,78 +789,16 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
         const size_t q256 = (tok0 + (T_TOK - 1)) * ld + h * 64 + tid;
         xq[tid] = (float)QKVhi[q256] + (float)QKVlo[q256];
     }
+    store_chunk(0);
+    if (upfront) {
+        load_chunk(1);
+        store_chunk(1);
+        load_chunk(2);
+        store_chunk(2);
+    } else {
+        load_chunk(1);   // in flight under the matrix pass over chunk 0
+    }
     __syncthreads();
-    if (probe == 1) return;  // timing probe (gp_vit_set_attn_probe): staging only
-
-    // ---- query 256 on the vector ALU, all eight waves, before the matrix loop (a ninth wave would put three waves on one
-    // SIMD and its 31 idle query columns would cost as much as a full tile: 141 -> 1xx us per launch).  The
-    // planes are exact f32 values (hi + lo), so plain f32 FMAs over them are at least as accurate as the split products.
-    {
-        float sv = -INFINITY;
-        if (tid < T_TOK) {  // score of key `tid`
-            const _Float16* kh = sKh + tid * AKS;
-            const _Float16* kl = sKl + tid * AKS;
-            float a = 0.f;
-#pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) {
-                const v16x8 h8 = *reinterpret_cast<const v16x8*>(kh + 8 * c8), l8 = *reinterpret_cast<const v16x8*>(kl + 8 * c8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a = __builtin_fmaf((float)h8[e] + (float)l8[e], xq[8 * c8 + e], a);
-            }
-            sv = a * (0.125f * inv_s2);
-        }
-        float mx = sv;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-        if (lane == 0) xred[0][wave] = mx;
-        __syncthreads();
-        mx = xred[0][0];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) mx = fmaxf(mx, xred[0][w]);
-        const float pr = tid < T_TOK ? exp_neg(sv - mx) : 0.f;
-        if (tid < T_TOK) xs[tid] = pr;
-        float ps = pr;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) ps += __shfl_xor(ps, off);
-        if (lane == 0) xred[1][wave] = ps;
-        __syncthreads();
-        // out[d] = sum_key p[key] v[key][d]: thread = (d = lane, key slice = wave: keys 32 w .. 32 w + 31; wave 0 adds key 256)
-        {
-            const _Float16* vh = sVh + lane * AVS + 32 * wave;
-            const _Float16* vl = sVl + lane * AVS + 32 * wave;
-            v16x4 h4[8], l4[8];
-            f32x4 p4[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                h4[u] = *reinterpret_cast<const v16x4*>(vh + 4 * u);
-                l4[u] = *reinterpret_cast<const v16x4*>(vl + 4 * u);
-                p4[u] = *reinterpret_cast<const f32x4*>(xs + 32 * wave + 4 * u);
-            }
-            float a = 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a = __builtin_fmaf((float)h4[u][e] + (float)l4[u][e], p4[u][e], a);
-            if (wave == 0) a = __builtin_fmaf((float)sVh[lane * AVS + T_TOK - 1] + (float)sVl[lane * AVS + T_TOK - 1], xs[T_TOK - 1], a);
-            xo[wave][lane] = a;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            float l = xred[1][0], a = xo[0][tid];
-#pragma unroll
-            for (int w = 1; w < 8; ++w) { l += xred[1][w]; a += xo[w][tid]; }
-            float v = a * (1.0f / l);  // = 8 x O (the V planes carry x 8)
-            asm volatile("" : "+v"(v));
-            const _Float16 hh = (_Float16)v;
-            const size_t o = (tok0 + (T_TOK - 1)) * C + h * 64 + tid;
-            Ohi[o] = hh;
-            Olo[o] = (_Float16)(v - (float)hh);
-        }
-    }
-    if (probe == 2) return;  // timing probe: staging + query 256
-    if (probe >= 3 && wave >= 4) {  // experiment: offset the two wave groups (one wave of each per SIMD) by ~(probe - 2) us
-        for (int i = 0; i < probe - 2; ++i) __builtin_amdgcn_s_sleep(25);
-    }
 
     f32x16 o0, o1;
 #pragma unroll
@@ -865,69 +839,53 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[kb], s[t], 0, 0, 0);
             }
         }
-        // online softmax over this chunk of 96 keys; element pairs (r, r + 1) as 2-vectors: packed f32 multiply / add
-        const f32x2 sc2 = {s_scale, s_scale};
+        // online softmax over this chunk of 96 keys.  Round 6 (vector instructions removed, not stalls): the maximum is taken over the
+        // RAW scores (s_scale > 0: max(c s) = c max(s)) with one v_max3_f32 per pair; scale and reference are folded into ONE fma per
+        // element, d = fma(s, c, -mb) (one rounding instead of the product's and the difference's); 9.5 -> 7 instructions per pair
         float cmax = -INFINITY;
+        if (ch == 2) {  // only the last tile of the last chunk holds keys >= 257 (keys 256..287): a wave-uniform branch, not 24 selects per chunk
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[2][r] = (256 + frag_row(r, lane) < T_TOK) ? s[2][r] : -INFINITY;
+        }
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                f32x2 v = f32x2{s[t][r], s[t][r + 1]} * sc2;
-                if (t == 2) {  // only a chunk's last tile can hold keys >= 257 (chunk 2: keys 256..287)
-                    const int tk = (ch * 3 + 2) * 32 + frag_row(r, lane);
-                    v.x = (tk < T_TOK) ? v.x : -INFINITY;
-                    v.y = (tk + 1 < T_TOK) ? v.y : -INFINITY;
-                }
-                s[t][r] = v.x;
-                s[t][r + 1] = v.y;
-                cmax = fmaxf(cmax, fmaxf(v.x, v.y));
-            }
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+            for (int r = 0; r < 16; r += 2) cmax = attn_max3(cmax, s[t][r], s[t][r + 1]);
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32)) * s_scale;
         // running reference mb = max - 15: P carries x 2^15 for its f16 split (and so does l_part); the SAME rounded value
         // serves the exponentials of this chunk and the rescaling of the earlier ones
         const float mb = fmaxf(m_run, cmax - 15.0f);
         const float alpha = __builtin_amdgcn_exp2f(m_run - mb);     // first chunk: exp2(-inf) = 0
-        const f32x2 mb2 = {mb, mb};
-        f32x2 psum2 = {0.f, 0.f};
+        const float nmb = -mb;
+        float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 d = f32x2{s[t][r], s[t][r + 1]} - mb2;
-                const f32x2 pp = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
-                s[t][r] = pp.x;
-                s[t][r + 1] = pp.y;
-                psum2 += pp;
+            for (int r = 0; r < 16; ++r) {
+                const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], s_scale, nmb));
+                s[t][r] = pp;
+                psum += pp;
             }
-        l_part = l_part * alpha + (psum2.x + psum2.y);
-        {
-            const f32x2 al2 = {alpha, alpha};
+        l_part = l_part * alpha + psum;
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 a0 = f32x2{o0[r], o0[r + 1]} * al2, a1 = f32x2{o1[r], o1[r + 1]} * al2;
-                o0[r] = a0.x; o0[r + 1] = a0.y; o1[r] = a1.x; o1[r + 1] = a1.y;
-            }
-        }
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
         m_run = mb;
         // O^T[d][query] += sum_key V^T[d][key] P^T[key][query], 16 keys per MFMA block (m)
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                v16x8 ph, pl;
+                // P = hi + lo per pair: v_cvt_pk_f16_f32 (hi, rounded) + v_fma_mixlo / mixhi_f16 (lo = f16(p - hi)): 1.5 instructions per
+                // element (round 5: mask + subtract + two conversions, 2.5)
+                au32x4 phu, plu;
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
-                    // hi = the top 11 significant bits (mantissa TRUNCATED to f16's 10: exact in f16, no conversion back), lo =
-                    // f16(p - hi): 11 + 11 bits as with a rounded hi, for 2.5 instead of 4 instructions per element
                     const float px = s[t][8 * m + e], py = s[t][8 * m + e + 1];
-                    const f32x2 pv = {px, py};
-                    const f32x2 top = {__uint_as_float(__float_as_uint(px) & 0xffffe000u), __uint_as_float(__float_as_uint(py) & 0xffffe000u)};
-                    const f32x2 rest = pv - top;
-                    ph[e] = (_Float16)top.x;
-                    ph[e + 1] = (_Float16)top.y;
-                    pl[e] = (_Float16)rest.x;
-                    pl[e + 1] = (_Float16)rest.y;
+                    const unsigned hp = attn_hi_pair(px, py);
+                    phu[e >> 1] = hp;
+                    plu[e >> 1] = attn_lo_pair(px, py, hp);
                 }
+                const v16x8 ph = __builtin_bit_cast(v16x8, phu), pl = __builtin_bit_cast(v16x8, plu);
 #pragma unroll
                 for (int dh = 0; dh < 2; ++dh) {
                     const unsigned vo = 2u * (32 * dh * AVS + t * 32 + 16 * m);
@@ -947,6 +905,11 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
                     }
                 }
             }
+        if (ch < 2 && !upfront) {   // chunk ch + 1: registers -> its LDS region; chunk ch + 2: global -> registers; then the barrier
+            store_chunk(ch + 1);
+            if (ch == 0) load_chunk(2);
+            __syncthreads();
+        }
     }
     // planes out: 8 * O = acc / l  (acc carries 2^15 p x 8 v, l carries 2^15); lane = (query, half): 4 consecutive channels per r4
     const float sc = 1.0f / (l_part + __shfl_xor(l_part, 32));
@@ -956,22 +919,98 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                v16x4 hv, lv;
+                typedef unsigned int au32x2 __attribute__((ext_vector_type(2)));
+                au32x2 hv, lv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = (dh ? o1[4 * r4 + e] : o0[4 * r4 + e]) * sc;
-                    // keep the rounded f32 product: hipcc otherwise folds multiply + conversion into v_fma_mixlo_f16 (ONE
-                    // rounding of the exact product) for hi but subtracts from the f32-rounded product for lo -- at an f16 tie
-                    // the two disagree by one f16 ulp of hi (seen as sparse 2^-k errors)
-                    asm volatile("" : "+v"(v));
-                    const _Float16 hh = (_Float16)v;
-                    hv[e] = hh;
-                    lv[e] = (_Float16)(v - (float)hh);
+                for (int e = 0; e < 4; e += 2) {
+                    float v0 = (dh ? o1[4 * r4 + e] : o0[4 * r4 + e]) * sc, v1 = (dh ? o1[4 * r4 + e + 1] : o0[4 * r4 + e + 1]) * sc;
+                    // keep the rounded f32 products: hipcc otherwise folds multiply + conversion into v_fma_mixlo_f16 (ONE rounding of
+                    // the exact product) for hi while lo subtracts from the f32-rounded product -- at an f16 tie the two disagree by
+                    // one f16 ulp of hi (seen as sparse 2^-k errors)
+                    asm volatile("" : "+v"(v0), "+v"(v1));
+                    const unsigned hp = attn_hi_pair(v0, v1);
+                    hv[e >> 1] = hp;
+                    lv[e >> 1] = attn_lo_pair(v0, v1, hp);
                 }
                 const size_t o = row + 32 * dh + frag_row(4 * r4, lane);
-                *reinterpret_cast<v16x4*>(Ohi + o) = hv;
-                *reinterpret_cast<v16x4*>(Olo + o) = lv;
+                *reinterpret_cast<au32x2*>(Ohi + o) = hv;
+                *reinterpret_cast<au32x2*>(Olo + o) = lv;
             }
+    }
+    // ---- query 256 (257 = 8 x 32 + 1) on the vector ALU, all eight waves, AFTER the matrix loop (every key is resident by now; round 5
+    // ran it first, behind the whole staging).  A ninth wave would put three waves on one SIMD and its 31 idle query columns would cost
+    // as much as a full tile.  The planes are exact f32 values (hi + lo), so plain f32 FMAs over them are at least as accurate as the
+    // split products.
+    {
+        float sv = -INFINITY;
+        if (tid < T_TOK) {  // score of key `tid`
+            const _Float16* kh = sKh + tid * AKS;
+            const _Float16* kl = sKl + tid * AKS;
+            float a = 0.f;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                const v16x8 h8 = *reinterpret_cast<const v16x8*>(kh + 8 * c8), l8 = *reinterpret_cast<const v16x8*>(kl + 8 * c8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {   // hi and lo as two mixed-precision fmas (v_fma_mix_f32 reads the f16 operand in place)
+                    a = __builtin_fmaf((float)h8[e], xq[8 * c8 + e], a);
+                    a = __builtin_fmaf((float)l8[e], xq[8 * c8 + e], a);
+                }
+            }
+            sv = a * (0.125f * inv_s2);
+        }
+        float mx = sv;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if (lane == 0) xred[0][wave] = mx;
+        __syncthreads();
+        mx = xred[0][0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) mx = fmaxf(mx, xred[0][w]);
+        const float pr = tid < T_TOK ? exp_neg(sv - mx) : 0.f;
+        if (tid < T_TOK) xs[tid] = pr;
+        float ps = pr;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ps += __shfl_xor(ps, off);
+        if (lane == 0) xred[1][wave] = ps;
+        __syncthreads();
+        // out[d] = sum_key p[key] v[key][d]: thread = (d = lane, key slice = wave: keys 32 w .. 32 w + 31; wave 0 adds key 256)
+        {
+            const _Float16* vh = sVh + lane * AVS + 32 * wave;
+            const _Float16* vl = sVl + lane * AVS + 32 * wave;
+            v16x4 h4[8], l4[8];
+            f32x4 p4[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                h4[u] = *reinterpret_cast<const v16x4*>(vh + 4 * u);
+                l4[u] = *reinterpret_cast<const v16x4*>(vl + 4 * u);
+                p4[u] = *reinterpret_cast<const f32x4*>(xs + 32 * wave + 4 * u);
+            }
+            float a = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a = __builtin_fmaf((float)h4[u][e], p4[u][e], a);
+                    a = __builtin_fmaf((float)l4[u][e], p4[u][e], a);
+                }
+            if (wave == 0) {
+                a = __builtin_fmaf((float)sVh[lane * AVS + T_TOK - 1], xs[T_TOK - 1], a);
+                a = __builtin_fmaf((float)sVl[lane * AVS + T_TOK - 1], xs[T_TOK - 1], a);
+            }
+            xo[wave][lane] = a;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float l = xred[1][0], a = xo[0][tid];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) { l += xred[1][w]; a += xo[w][tid]; }
+            float v = a * (1.0f / l);  // = 8 x O (the V planes carry x 8)
+            asm volatile("" : "+v"(v));
+            const _Float16 hh = (_Float16)v;
+            const size_t o = (tok0 + (T_TOK - 1)) * C + h * 64 + tid;
+            Ohi[o] = hh;
+            Olo[o] = (_Float16)(v - (float)hh);
+        }
     }
 }
 

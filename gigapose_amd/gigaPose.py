@@ -130,6 +130,7 @@ class GigaPose(_Base):
         self._pending = []        # queued images: (batch, idx_batch, (dataset_name, log_dir, test_setting) when queued)
         self._pending_crops = 0
         self._in_flight = None    # the flush whose kernels are queued on the GPU while the host writes the previous flush's files
+        self._feat_shapes = {}     # output shape of the two backbones (predict: all-padding batches skip them)
         self._sharded_flow = None  # sharded_flow.ShardedFlow: test_step's fixed-size flushes when the template bank is sharded
         # Who computes which image when several ranks run the reference's test loop?  The reference's webdataset pipeline has no
         # split_by_node (reference src/custom_megapose/web_scene_dataset.py:207-215): under a multi-process launch EVERY rank
@@ -307,12 +308,15 @@ class GigaPose(_Base):
 
     # ------------------------------------------------------------------ the hot loop
     @torch.no_grad()
-    def predict(self, tar_img, tar_mask, tar_K, tar_M, labels, dataset_name, sort_pred_by_inliers=True, exchange_aux=None):
+    def predict(self, tar_img, tar_mask, tar_K, tar_M, labels, dataset_name, sort_pred_by_inliers=True, exchange_aux=None, live_rows=None):
         """Device-only part of eval_retrieval (gigaPose.py:511-604): crops -> sorted pose hypotheses.
         labels: (B) int tensor of 1-based object labels.  Returns a PandasTensorCollection with
         id_src, score_src, score_pts, tar_pts, src_pts, relScale, relInplane, idx_failed, M,
         ransac_*, scores (B,k), pred_poses (B,k,4,4).  `exchange_aux` (sharded bank only): a (B,) int32 word per crop that
-        travels with exchange #1; all ranks' words are in `self.match_banks[dataset_name].last_aux` afterwards."""
+        travels with exchange #1; all ranks' words are in `self.match_banks[dataset_name].last_aux` afterwards.  `live_rows`
+        (fixed-size sharded flushes): only the first `live_rows` crops are real, the rest are padding (zero image, zero mask) -- the
+        two backbones run on the real rows only and the padding rows get zero features (their zero masks leave them no live
+        patch, so nothing downstream reads those features)."""
         bank = self.match_banks[dataset_name]
         template_data = self.template_datas[dataset_name]
         n_obj = template_data.ist_features.shape[0]
@@ -337,17 +341,17 @@ class GigaPose(_Base):
             side = self._side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                tar_ist = self.ist_net.forward_by_chunk(tar_img)                 # stage 4a: IST backbone (once)
-        tar_ae = self.ae_net(tar_img)                                            # stage 1: ViT features
+                tar_ist = self._backbone_rows("ist", self.ist_net.forward_by_chunk, tar_img, live_rows)   # stage 4a: IST backbone (once)
+        tar_ae = self._backbone_rows("ae", self.ae_net, tar_img, live_rows)            # stage 1: ViT features
         if self.template_shard is None:
             pred = self.testing_metric.test_bank(bank, tar_ae, tar_mask, labels0)  # stage 3: matching
             if side is None:
-                tar_ist = self.ist_net.forward_by_chunk(tar_img)                 # stage 4a: IST backbone (once)
+                tar_ist = self._backbone_rows("ist", self.ist_net.forward_by_chunk, tar_img, live_rows)   # stage 4a: IST backbone (once)
         else:
             # sharded bank: exchange #1 (query features to every rank) travels while the IST backbone runs
             pending = bank.start_exchange(tar_ae, tar_mask, labels0, exchange_aux)
             if side is None:
-                tar_ist = self.ist_net.forward_by_chunk(tar_img)
+                tar_ist = self._backbone_rows("ist", self.ist_net.forward_by_chunk, tar_img, live_rows)
             pred = bank.finish(pending)                                          # match the shard + exchange #2 + merge
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
@@ -362,6 +366,24 @@ class GigaPose(_Base):
             tar_label=labels, tar_K=tar_K, tar_M=tar_M, pred_src_views=pred.id_src, pred_M=pred.M, labels0=labels0)
         pred.register_tensor("pred_poses", poses)
         return pred
+
+    def _backbone_rows(self, key, net, tar_img, live_rows):
+        """net(tar_img) computed on the first `live_rows` rows only, zero features for the padding rows behind them (an all-padding
+        batch does not run the network at all once its output shape is known)."""
+        B = tar_img.shape[0]
+        if live_rows is None or live_rows >= B:
+            out = net(tar_img)
+            self._feat_shapes[key] = (tuple(out.shape[1:]), out.dtype)
+            return out
+        if live_rows == 0 and key in self._feat_shapes:
+            shape, dtype = self._feat_shapes[key]
+            return torch.zeros((B,) + shape, dtype=dtype, device=tar_img.device)
+        feat = net(tar_img[:max(live_rows, 1)])
+        self._feat_shapes[key] = (tuple(feat.shape[1:]), feat.dtype)
+        out = feat.new_zeros((B,) + tuple(feat.shape[1:]))
+        if live_rows > 0:
+            out[:live_rows] = feat[:live_rows]
+        return out
 
     def eval_retrieval(self, batch, idx_batch, dataset_name, sort_pred_by_inliers=True):
         if dataset_name not in self.template_datas:
@@ -508,7 +530,7 @@ class GigaPose(_Base):
         job["images"] = images
         return job
 
-    def _run_rows(self, inputs, labels_np, dataset_name, aux=None):
+    def _run_rows(self, inputs, labels_np, dataset_name, aux=None, live_rows=None):
         """The device half of a flush: ONE predict() over the rows of `inputs`, queued without a host wait, and what the host needs
         afterwards copied to pinned memory BEHIND the kernels.  `aux` (sharded flow only): an int the ranks exchange with this
         flush (sharded_flow.py)."""
@@ -524,7 +546,7 @@ class GigaPose(_Base):
             aux_t = torch.full((n,), int(aux or 0), dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
         try:
             pred = self.predict(inputs["tar_img"], inputs["tar_mask"], inputs["tar_K"], inputs["tar_M"], torch.from_numpy(labels_np), dataset_name,
-                                exchange_aux=aux_t)
+                                exchange_aux=aux_t, live_rows=live_rows)
         finally:
             recovery.check_asserts = keep_asserts
         # what the files and the guard rails need, to pinned host memory BEHIND the kernels (stream order; no host wait here): scores,

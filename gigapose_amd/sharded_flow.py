@@ -103,7 +103,7 @@ class ShardedFlow:
         self.queued -= n
         flag = DONE if (final and not self.queue) else 0
         inputs, labels = self._inputs(segs, n, F)
-        job = m._run_rows(inputs, labels, dataset_name, aux=flag)
+        job = m._run_rows(inputs, labels, dataset_name, aux=flag, live_rows=n)
         job.update(segs=segs, n_live=n, rows=F)
         return job
 

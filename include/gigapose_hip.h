@@ -303,7 +303,7 @@ void gp_vit_set_planes(int mode); /* 2 (default) = planes + attention in split n
  * replaces HF modeling_dinov2.py:207-229 inside AENet.forward for the split mode. */
 int gp_attention_split(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
                        void* stream);
-void gp_vit_set_attn_probe(int mode); /* timing probe for gp_attention_split: 1 = stop after staging K / V, 2 = after query 256, 0 = off */
+void gp_vit_set_attn_probe(int mode); /* A/B hook of gp_attention_split: 1 = key chunk c + 1 staged under the matrix pass over chunk c (measured slower), 0 = all chunks staged up front */
 int gp_vit_forward_split(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                          const float* const* weights, int n_weights, const void* const* split, int n_split,
                          float* workspace, size_t workspace_bytes, float* out_features, int normalize,

@@ -58,14 +58,16 @@ class _ShardedModel(GigaPose):
         self.recoveries += 1
         return "recalibrated" if self.recoveries <= 2 else False
 
-    def _run_rows(self, inputs, labels_np, dataset_name, aux=None):
+    def _run_rows(self, inputs, labels_np, dataset_name, aux=None, live_rows=None):
         rank, world, _ = self.template_shard
+        assert live_rows is not None and 0 <= live_rows <= len(labels_np)
         imgs = inputs["tar_img"]
         assert imgs.shape[0] == self.accumulate_crops == len(labels_np), "a sharded flush is exactly accumulate_crops rows"
         res = [crop_result(i) for i in imgs]
         status = 4 if (self.trip_on is not None and self.launched in self.trip_on) else 0
         self.launched += 1
         self.live_rows.append(int((imgs.reshape(imgs.shape[0], -1).abs().sum(1) > 0).sum()))
+        assert self.live_rows[-1] == live_rows, "the flow tells the device half how many of its rows are real"
         words = torch.zeros(world, dtype=torch.int32)
         dist.all_gather_into_tensor(words, torch.tensor([status], dtype=torch.int32))                 # the flush's status all-gather
         aux_all = torch.zeros(world * len(labels_np), dtype=torch.int32)

@@ -38,6 +38,14 @@ def family_json(acc, path):
             w = (sum(write) / len(write)) * 1024 if write else None
             out[fam] = {"launches": max(len(fetch), len(write)), "fetch_bytes_per_launch": f, "write_bytes_per_launch": w,
                         "hbm_bytes_per_launch": (f or 0) + (w or 0)}
+    # when, and on which kernels: bench.py quotes both next to the (static) traffic figure
+    import glob, hashlib, os, time
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gigapose_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        h.update(open(f, "rb").read())
+    out["_recorded_at"] = time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime())
+    out["_kernel_sources_sha1"] = h.hexdigest()
     json.dump(out, open(path, "w"), indent=1)
 
 

@@ -29,12 +29,12 @@ fl = 4.0 * B * H * 257 * 257 * 64
 print(f"attention_split_kernel B={B} H={H}: {ms*1e3:.1f} us isolated = {fl/ms/1e9:.1f} TF-equivalent (f32 kernel: 286 us in the bench)")
 if "--plain" in sys.argv:   # PMC passes: only the product kernel
     sys.exit(0)
-for mode, what in ((1, "staging K / V^T only"), (2, "staging + query 256 (vector ALU)")):
-    lib.gp_vit_set_attn_probe(mode)
-    print(f"  probe {mode}: {what}: {timeit(run)*1e3:.1f} us per launch (4 workgroups per CU in sequence)")
-for mode in (3, 4, 5, 6, 8, 10):
-    lib.gp_vit_set_attn_probe(mode)
-    print(f"  probe {mode}: waves 4-7 delayed by ~{mode - 2} us before the matrix loop: {timeit(run)*1e3:.1f} us per launch")
+# round 6: A/B of the staging order inside one binary -- 0 = every chunk staged before the first matrix pass (the product),
+# 1 = key chunk c + 1 staged under the matrix pass over chunk c
+for rep in range(3):
+    for mode, what in ((0, "all chunks staged up front (product)"), (1, "chunk c + 1 staged under the matrix pass over chunk c")):
+        lib.gp_vit_set_attn_probe(mode)
+        print(f"  probe {mode}: {what}: {timeit(run, iters=30)*1e3:.1f} us per launch")
 lib.gp_vit_set_attn_probe(0)
 from test_gpu_split import planes256_gemm
 I, J, K = 4096, 4096, 64

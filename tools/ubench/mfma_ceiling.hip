@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -265,7 +266,9 @@ static void run(const char* name, Data d, int waves, double mfma_per_wave_iter, 
 
 int main(int argc, char** argv)
 {
-    const double seconds = argc > 1 ? atof(argv[1]) : 1.2;
+    // `brief [seconds]`: the four lines bench.py quotes (zeros / random data in registers, the split pattern fed from LDS), 0.4 s each
+    const bool brief = argc > 1 && std::string(argv[1]) == "brief";
+    const double seconds = brief ? (argc > 2 ? atof(argv[2]) : 0.4) : (argc > 1 ? atof(argv[1]) : 1.2);
     v16x8* ops; float* out; Clk* clk;
     if (hipMalloc(&ops, (size_t)LDS_FRAGS * 64 * sizeof(v16x8)) != hipSuccess) { printf("no device\n"); return 1; }
     hipMalloc(&out, sizeof(float) * 512 * 256);
@@ -287,6 +290,14 @@ int main(int argc, char** argv)
     hipFuncSetAttribute((const void*)k_lds_pipe<2, 4, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)k_lds_pipe<2, 4, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)k_lds_pipe<4, 4, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (brief) {
+        run("R  same 2 operand registers every MFMA", ZERO, 8, 16, 4000, ops, clk, [&](int it) { hipLaunchKernelGGL((k_regs<1, 512>), dim3(blocks), dim3(512), 0, 0, ops, out, it, clk); }, seconds);
+        run("R  same 2 operand registers every MFMA", NORMAL, 8, 16, 4000, ops, clk, [&](int it) { hipLaunchKernelGGL((k_regs<1, 512>), dim3(blocks), dim3(512), 0, 0, ops, out, it, clk); }, seconds);
+        run("R  8 + 8 operand registers, rotated", NORMAL, 4, 16, 4000, ops, clk, [&](int it) { hipLaunchKernelGGL((k_regs<8, 256>), dim3(blocks), dim3(256), 0, 0, ops, out, it, clk); }, seconds);
+        run("LPP 2x4 wave tile, two register sets", NORMAL, 8, 24, 2600, ops, clk, [&](int it) { hipLaunchKernelGGL((k_lds_pp<2, 4, 512>), dim3(blocks), dim3(512), lds, 0, ops, out, it, clk); }, seconds);
+        if (g_smi) rsmi_shut_down();
+        return 0;
+    }
     for (Data d : {ZERO, NORMAL}) {   // (a small ramp, round 3's operands, behaves like normal data: profiles/r06_ubench_mfma_ceiling.txt, first run)
         for (int waves : {8, 4}) {
             run("R  same 2 operand registers every MFMA", d, waves, 16, 4000, ops, clk, [&](int it) {

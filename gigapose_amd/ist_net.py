@@ -349,6 +349,11 @@ class ISTNet(nn.Module):
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
     # ------------------------------------------------------------------ HIP regressor
+    head_numerics = None   # None: the MLP heads follow the backbone's numerics; "chain" / "split": on their own (tools/probe_parity_attribution.py)
+
+    def _head_numerics(self):
+        return self.head_numerics or getattr(self.backbone, "numerics", "chain")
+
     @torch.no_grad()
     def _pack(self, device):
         def dev(t):
@@ -358,7 +363,7 @@ class ISTNet(nn.Module):
         for seq in (self.regressor.scale_predictor, self.regressor.inplane_predictor):
             l1, l2, l3 = seq[0], seq[2], seq[4]
             tensors += [dev(l1.weight.t()), dev(l1.bias), dev(l2.weight.t()), dev(l2.bias), dev(l3.weight), dev(l3.bias)]
-        numerics = getattr(self.backbone, "numerics", "chain")
+        numerics = self._head_numerics()
         if numerics == "split":   # the two hidden layers of each head as 3 x f16 MFMA (weights [out][in] as hi / lo planes)
             from .vit import split_planes
 
@@ -373,7 +378,7 @@ class ISTNet(nn.Module):
         ist_bank (O,N,D,16,16); labels0 (B) int32 0-based; id_src (B,k) int64; tar_feat (B,D,16,16);
         src_pts / tar_pts (B,k,256,2) int64 -> relScale (B,k,256), relInplane (B,k,256,2)."""
         dev = tar_feat.device
-        if self._packed is None or self._packed[0] != dev or self._packed[3] != getattr(self.backbone, "numerics", "chain"):
+        if self._packed is None or self._packed[0] != dev or self._packed[3] != self._head_numerics():
             self._pack(dev)
         B, k = id_src.shape
         O, N, D = ist_bank.shape[:3]

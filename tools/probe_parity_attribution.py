@@ -191,6 +191,11 @@ def run_variant(name, golden_dir, report):
         model.testing_metric.numerics = "chain"
     if name == "ist_chain":
         model.ist_net.backbone.set_numerics("chain")
+    if name == "ist_backbone_chain":     # the ResNet in f32 chains, the two MLP heads in split numerics
+        model.ist_net.backbone.set_numerics("chain")
+        model.ist_net.head_numerics = "split"
+    if name == "ist_heads_chain":        # the ResNet in split numerics, the heads in f32 chains
+        model.ist_net.head_numerics = "chain"
     ideal = None
     if name.startswith("ideal:"):
         ideal = name.split(":", 1)[1].split(",")
@@ -225,8 +230,20 @@ def run_variant(name, golden_dir, report):
     x = torch.cat([items[0].rgb[:2], torch.from_numpy(qq["tar_img"][:2]), items[0].rgb[2:62]]).to(DEV)
     mine = model.ae_net(x).cpu().numpy()[:4, ::4].astype(np.float64)
     e = np.abs(mine - g64["feat_f64_templates01_crops01"])
+    # IST regressions against the float64 run's, over the hypotheses both runs hold with identical correspondences
+    o = ours_for_checker(model, p, cap["tiles"], m)
+    ds, dc = [], []
+    for b in range(o["id_src"].shape[0]):
+        for jo, n in enumerate(o["id_src"][b]):
+            jf = np.flatnonzero(m["id_src"][b] == n)
+            if len(jf) and (o["src_pts"][b, jo] == m["src_pts"][b, jf[0]]).all() and (o["tar_pts"][b, jo] == m["tar_pts"][b, jf[0]]).all():
+                ok = m["src_pts"][b, jf[0]][:, 0] != -1
+                ds.append((o["relScale"][b, jo][ok] - m["relScale"][b, jf[0]][ok]).ravel())
+                dc.append((o["relInplane"][b, jo][ok] - m["relInplane"][b, jf[0]][ok]).ravel())
+    ds, dc = np.concatenate(ds), np.concatenate(dc)
+    ist = f"IST vs f64: relScale rms {np.sqrt((ds ** 2).mean()):.2e} max {np.abs(ds).max():.1e}, cos/sin rms {np.sqrt((dc ** 2).mean()):.2e} max {np.abs(dc).max():.1e}"
     line = (f"{name:28s} hyp_same_all {rep['hyp_same_all']:3d} / {rep['hyp']}   unexplained {len(rep['unexplained']):2d}   "
-            f"features vs f64: rms {np.sqrt((e ** 2).mean()):.2e} max {e.max():.1e}   | {px.summary(rep)}   [{time.time() - t0:.0f} s]")
+            f"features vs f64: rms {np.sqrt((e ** 2).mean()):.2e} max {e.max():.1e}   {ist}   | {px.summary(rep)}   [{time.time() - t0:.0f} s]")
     print(line, flush=True)
     report.append(line)
     _lib.check_status()

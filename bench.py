@@ -146,45 +146,6 @@ def matrix_ceiling_on_this_socket():
     return out or None
 
 
-def sustained_matrix_clock_mhz(lib, dev):
-    """The shader clock INSIDE the dominant kernel, measured now on this box: 30 back-to-back launches of gemm_planes256_kernel at the
-    fc2 shape of the headline workload heat the socket to the state the timed region runs in, then the TIMING build of the same
-    kernel (gp_gemm_planes256_timing, tools/probe_planes256.py) reports its own cycle counter against the 100 MHz wall clock over
-    one launch.  ~15 ms, after the timed region.  None if the probe entry is missing."""
-    from gigapose_amd import _lib
-
-    try:
-        lib.gp_gemm_split256_workspace_bytes.restype = ctypes.c_size_t
-        nb = lib.gp_gemm_split256_workspace_bytes()
-        ws = torch.zeros(nb // 4, device=dev)
-        I, J, K = 1024, 16640, 4096
-        W = torch.randn(I, K, device=dev) * 0.03
-        Xt = torch.randn(J, K, device=dev)
-
-        def planes(t, scale):
-            hi = torch.empty(t.shape, dtype=torch.float16, device=dev)
-            lo = torch.empty_like(hi)
-            _lib.call("gp_split_planes", _lib.ptr(t), ctypes.c_size_t(t.numel()), _lib.f(scale), _lib.ptr(hi), _lib.ptr(lo), _lib.stream_ptr())
-            return hi, lo
-
-        whi, wlo = planes(W, 64.0)
-        xhi, xlo = planes(Xt, 8.0)
-        D = torch.empty(I, J, device=dev)
-        out = (ctypes.c_ulonglong * 8)()
-        for _ in range(30):
-            _lib.call("gp_gemm_planes256", _lib.ptr(whi), _lib.ptr(wlo), _lib.ptr(xhi), _lib.ptr(xlo), _lib.ptr(D), _lib.i(J), _lib.ptr(None),
-                      _lib.ptr(None), _lib.i(0), _lib.i(I), _lib.i(J), _lib.i(K), _lib.i(0), _lib.ptr(None), _lib.ptr(None), _lib.ptr(None),
-                      _lib.i(0), _lib.f(1.0 / 512.0), _lib.ptr(ws), ctypes.c_size_t(nb), _lib.stream_ptr())
-        lib.gp_gemm_planes256_timing(_lib.ptr(whi), _lib.ptr(wlo), _lib.ptr(xhi), _lib.ptr(xlo), _lib.ptr(D), J, I, J, K, _lib.ptr(ws), out,
-                                     _lib.stream_ptr())
-        torch.cuda.synchronize()
-        if out[7] == 0:
-            return None
-        return round(out[6] / (out[7] / 100.0), 1)   # cycles / microseconds
-    except Exception:
-        return None
-
-
 def cpu_baseline(variant, n_templates, k, sample_crops=32, threads=None):
     """The reference's CPU path restated operator for operator in torch (oracle/torch_port.py: HF DINOv2 stand-in forward
     in sub-batches of 4 detections, the 170 MB / detection bank gather, LocalSimilarity.test with its materialised
@@ -193,7 +154,7 @@ def cpu_baseline(variant, n_templates, k, sample_crops=32, threads=None):
     (the unmodified reference measured 1.39 crops/s on 8 threads in the build container)."""
     from transformers import Dinov2Config, Dinov2Model
 
-    from gigapose_amd import factory, synthetic as syn
+    from gigapose_testing import factory, synthetic as syn
     from gigapose_amd.vit import VARIANTS
     from oracle import torch_port
 
@@ -370,7 +331,8 @@ def main():
         q = dict(tar_img=torch.zeros(args.batch, 1), tar_mask=None, tar_K=None, tar_M=None, labels=None)
         lib = _StubLib()
     else:
-        from gigapose_amd import _lib, factory
+        from gigapose_amd import _lib
+        from gigapose_testing import factory
 
         model = factory.build_model(args.variant, k=args.k, device=dev, seed=0)
         tset = factory.TemplateSet(args.objects, args.templates, seed=100)
@@ -393,10 +355,10 @@ def main():
             dist.barrier()
         sync()
         if profile == "all":
-            lib.gp_prof_begin()
+            lib.gp_prof_begin(-1, 1)
         elif profile:
             names = [lib.gp_prof_kind_name(i).decode() for i in range(kinds)]
-            lib.gp_prof_begin_sampled(names.index(profile[1]), SAMPLE_STRIDE)
+            lib.gp_prof_begin(names.index(profile[1]), SAMPLE_STRIDE)
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
@@ -514,7 +476,7 @@ def main():
             other[other_mode] = {"error": repr(e)}
         # split128: what the automatic range fallback lands in (gigaPose.py: _widen_split_range) when a checkpoint's activations
         # leave the x8 f16 planes' range (|x| >= 8190): ViT linear layers + IST convolutions on the two-accumulator 128 x 128
-        # kernels (GIGAPOSE_SPLIT_GEMM=128 + GIGAPOSE_SPLIT_CONV=128), everything else as in split
+        # kernels (Dinov2ViT.set_split_gemm("128") + ResNet.conv_kernel = "128"), everything else as in split
         vit, ist = model.ae_net.dinov2_model, model.ist_net.backbone   # bound BEFORE the try: the finally below restores them
         try:
             vit.set_split_gemm("128")
@@ -526,15 +488,15 @@ def main():
         except Exception as e:
             other["split128"] = {"error": repr(e)}
         finally:
-            vit.set_split_gemm(os.environ.get("GIGAPOSE_SPLIT_GEMM", "256"))
-            ist.conv_kernel = os.environ.get("GIGAPOSE_SPLIT_CONV", "256")
+            vit.set_split_gemm("256")
+            ist.conv_kernel = "256"
             ist.invalidate()
-        # split_outliers: the same model with DINOv2-like planted outliers (gigapose_amd/synthetic.py: OUTLIER_SPEC -- massive GELU
+        # split_outliers: the same model with DINOv2-like planted outliers (gigapose_testing/synthetic.py: OUTLIER_SPEC -- massive GELU
         # activations in two layers, a value-projection channel at 9e3, LayerNorm gains of 600 on residual outlier channels): the
         # default x 8 planes would trip the range guard; onboarding calibrates per-tensor plane scales on the templates and every
         # GEMM stays on the 256 x 256 plane kernels (round 4 landed in split128 for such weights)
         try:
-            from gigapose_amd import synthetic as syn_
+            from gigapose_testing import synthetic as syn_
 
             vit = model.ae_net.dinov2_model
             keep_sd = {k: v.detach().clone() for k, v in vit.state_dict().items()}
@@ -793,7 +755,6 @@ def main():
         g = kern_timed.get("gemm_split", {})   # the sampled launches of THE timed region
         alg = g.get("TFLOP/s", 0.0)            # algorithmic 2 I J K flops of the launches / their event-timed duration
         executed = round(3.0 * alg, 2)         # what the matrix core executes: 3 f16 MFMAs per f32-equivalent product block
-        clk = None if stub else sustained_matrix_clock_mhz(lib, dev)
         ceil = None if stub else matrix_ceiling_on_this_socket()
         roofline = {"kernel": "gemm_planes256_kernel (ViT linear layers; 3 x v_mfma_f32_32x32x16_f16 per k-block on f16-split f32 "
                               "operands held as hi / lo planes, f32 accumulate)", "bound": "mfma",
@@ -803,7 +764,6 @@ def main():
                     "achieved_is": "algorithmic f32-equivalent flops (2 I J K per launch) / event-timed launch duration",
                     "executed_tflops": executed,
                     "mfma_util_executed": round(executed / F16_MFMA_PEAK_TFLOPS, 4),
-                    "sustained_matrix_clock_mhz": clk,
                     # round 6: the ceiling is MEASURED on this socket, after the timed region, by an MFMA-only loop on random data (the
                     # guide's 2495 TFLOP/s reproduces with all-zero operands only; random data hits the 1400 W cap at ~0.65 of it)
                     "sustained_mfma_only_tflops": (ceil or {}).get("mfma_only_random_operands", {}).get("tflops"),

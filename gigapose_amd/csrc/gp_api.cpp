@@ -6,8 +6,17 @@
 #include "gp_common.h"
 
 static thread_local char g_err[512] = "";
-static int* g_status = nullptr;  // device int32 owned by the caller (gp_set_status_buffer)
-int* gp_status_buffer() { return g_status; }
+// Guard-rail words: one device int32 per HIP device, owned by the caller (gp_set_status_buffer registers the word of the CURRENT device).
+// A launch takes the word of the device it is issued on: no process-wide pointer to re-point, nothing shared between GPUs or threads
+// (the table is written at registration only; round 5 held ONE pointer the Python side switched per call).
+constexpr int kMaxDevices = 64;
+static int* g_status[kMaxDevices] = {};
+int* gp_status_buffer()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    return g_status[dev];
+}
 
 void gp_set_error(const char* fmt, ...)
 {
@@ -50,19 +59,14 @@ GpProfScope::~GpProfScope()
 }
 
 extern "C" {
-void gp_prof_begin(void)
+void gp_prof_begin(int kind, int stride)   // kind < 0: every launch; else every `stride`-th launch of that family
 {
     for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
     g_recs.clear();
-    g_prof_only = -1;
-    g_prof = true;
-}
-void gp_prof_begin_sampled(int kind, int stride)
-{
-    gp_prof_begin();
-    g_prof_only = kind;
+    g_prof_only = kind < 0 ? -1 : kind;
     g_prof_stride = stride > 0 ? stride : 1;
     g_prof_seen = 0;
+    g_prof = true;
 }
 int gp_prof_end(int max_kinds, double* ms, double* work, long long* launches)
 {
@@ -83,8 +87,13 @@ const char* gp_prof_kind_name(int kind) { return (kind >= 0 && kind < GP_PROF_KI
 const char* gp_last_error(void) { return g_err; }
 int gp_set_status_buffer(int* device_word)
 {
-    g_status = device_word;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        gp_set_error("gp_set_status_buffer: no current HIP device (or its index is beyond %d)", kMaxDevices);
+        return GP_EINVAL;
+    }
+    g_status[dev] = device_word;
     return GP_OK;
 }
-int gp_abi_version(void) { return 1; }
+int gp_abi_version(void) { return 2; }   // 2: round 6 (45 product entry points, per-device status words, probe library split off)
 }

@@ -34,21 +34,12 @@ __device__ __forceinline__ void gp_raise(int* status, int bit)
 }
 constexpr float kSplitPlaneLimit = 65504.0f;  // largest finite f16: |8 x| beyond it would store inf in the hi plane
 
-// LayerNorm folded into the plane GEMMs (gp_split256.hip, epilogues 8-10): where the per-token partial (sum, sum of squares) pairs
-// live.  main: [channels / 256][ld][2] f32 (tile rows), strip: [channels / 32][256][2] (the < 256 ragged rows).
-struct GpLnFold {
-    const float* ln_main; const float* ln_strip;  // consumer: statistics of the rows of B
-    float* st_main; float* st_strip;              // producer: statistics of the rows it writes
-    int ld; float eps;
-};
-
 // Plane producers (LayerNorm, the plane epilogues 6 / 7 of gp_split256.hip, attention): the power of two a tensor is multiplied
 // by before it is split into its f16 hi / lo planes (default 8: |x| < 8190), and -- calibration passes only -- where to record
 // max |x| of what was written (f32 bits, atomic max; gp_vit_forward_split2).  Per tensor, chosen by the host (vit.py).
 struct GpPlaneOut {
     float scale;   // power of two
     float* amax;   // device float or null
-    int park;      // epilogue 3 only: > 1 = run a whole tile's K as `park` parts, each folded into the f32 residual (gp_split256.hip: PARK)
 };
 __device__ __forceinline__ void gp_record_amax(float* amax, float mx_scaled, float inv_scale)
 {

@@ -274,8 +274,10 @@ static bool g_conv_direct = true;
 
 extern "C" {
 
+#ifdef GP_PROBES
 /* test hook: 0 forces the generic gather kernel for every shape (both must agree bit-for-bit) */
 void gp_conv_set_direct(int on) { g_conv_direct = on != 0; }
+#endif
 
 int gp_resize_bilinear_cm(const float* images, float* out, int B, int C, int IH, int IW, int S, void* stream)
 {

@@ -903,7 +903,9 @@ unsigned long long* g_conv_trace = nullptr;
 
 extern "C" {
 
+#ifdef GP_PROBES
 void gp_conv2d_planes_set_trace(unsigned long long* buf) { g_conv_trace = buf; }  // probe: 256 slots x 8 words, see ConvPArgs
+#endif
 
 size_t gp_conv2d_planes_workspace_bytes(void) { return kHeaderBytes + sizeof(float) * kFragFloats * kSlots; }
 
@@ -919,6 +921,7 @@ int gp_planes_from_cm(const float* X, int C, int npix, void* hi, void* lo, void*
 static int g_conv_halo = 1;  // bit 0: 3 x 3 / stride 1 layers take the halo kernel; bit 1 (with it): its parallel split below 256 tiles (A/B hook)
 static int g_conv_par = 1;
 static int g_conv_par_min_cb = 1;  // channel blocks (9 k-steps each) per slot of a split tile at least
+#ifdef GP_PROBES
 int gp_conv2d_planes_set_halo(int on)
 {
     g_conv_halo = (on & 1) ? 1 : 0;
@@ -926,6 +929,7 @@ int gp_conv2d_planes_set_halo(int on)
     g_conv_par_min_cb = (on >> 4) > 0 ? (on >> 4) : 1;   // probe: on = 1 + 16 n -> at least n channel blocks per slot of a split tile
     return GP_OK;
 }
+#endif
 
 // 3 x 3 / stride 1 / pad 1 on 16 x 16 pixel blocks with the halo resident in LDS (conv_halo_kernel); same arguments and results
 // (to f32 round-off) as gp_conv2d_planes.  Needs H, W multiples of 16.

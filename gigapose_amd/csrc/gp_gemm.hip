@@ -342,6 +342,7 @@ int probe_launch(const float* A, int lda, const float* B, int ldb, float* D, int
 }
 }  // namespace
 
+#ifdef GP_PROBES
 extern "C" void gp_gemm_set_streamk(int mode) { g_streamk = mode; }
 extern "C" int gp_gemm_probe_occupancy(void) { return g_probe_occ; }
 extern "C" int gp_gemm_product_occupancy(int streamk)
@@ -377,6 +378,7 @@ extern "C" int gp_gemm_probe(int variant, const float* A, int lda, const float* 
         default: return GP_EINVAL;
     }
 }
+#endif
 
 extern "C" int gp_gemm_kmajor(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I,
                               int J, int K, int epilogue, const float* bias, const float* scale,
@@ -394,6 +396,7 @@ extern "C" int gp_gemm_streamk_reset(float* scratch, void* stream)
     return gp_gemm_streamk_reset_launch(scratch, (hipStream_t)stream);
 }
 
+#ifdef GP_PROBES
 extern "C" int gp_gemm_streamk_error(const float* scratch, void* stream)
 {
     int e = -1;
@@ -403,6 +406,7 @@ extern "C" int gp_gemm_streamk_error(const float* scratch, void* stream)
         return -1;
     return e;
 }
+#endif
 
 extern "C" int gp_gemm_kmajor_sk(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I,
                                  int J, int K, int epilogue, const float* bias, const float* scale,

@@ -510,6 +510,10 @@ __device__ __forceinline__ void match_split_kloop(MatchSplitSmem& sm, f32x16 (&a
 #undef M_MFMA
 }
 
+#ifndef GP_MATCH_BAND
+#define GP_MATCH_BAND 8
+#endif
+constexpr int kSplitBand = GP_MATCH_BAND;
 template <bool BANK_LO, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
     const _Float16* __restrict__ q_hi, const _Float16* __restrict__ q_lo,  // (B, 256, C)
@@ -531,9 +535,11 @@ __global__ __launch_bounds__(512, 2) void match_tiles_split_kernel(
         trace[0] = w_in;
         trace[7] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
     }
-    const int band = q / (8 * N), r8 = q - band * (8 * N);
-    const int gsz = min(8, B - band * 8);
-    const int b = band * 8 + r8 % gsz, n = r8 / gsz;
+    // tile order inside an XCD's chunk: bands of kSplitBand crops x all N templates, crops fastest -- the 32 tiles an XCD runs at a time
+    // are kSplitBand crops x 32 / kSplitBand templates (GP_MATCH_BAND: compile-time A/B, tools/gpu_r06_match.sh)
+    const int band = q / (kSplitBand * N), r8 = q - band * (kSplitBand * N);
+    const int gsz = min(kSplitBand, B - band * kSplitBand);
+    const int b = band * kSplitBand + r8 % gsz, n = r8 / gsz;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;
@@ -853,15 +859,6 @@ int gp_match_tiles_dir(const float* query, const float* bank, const float* qmask
     return GP_OK;
 }
 
-int gp_match_tiles(const float* query, const float* bank, const float* qmask, const float* bmask,
-                   const int* labels, int B, int O, int N, int C, float sim_threshold,
-                   float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
-                   float* sim_avg, void* stream)
-{
-    return gp_match_tiles_dir(query, bank, qmask, bmask, labels, B, O, N, C, sim_threshold, patch_threshold, 0, idx_t2s, score_t2s,
-                              mask_all, sim_avg, stream);
-}
-
 int gp_l2norm_split_mask(const float* x, void* hi, void* lo, int rows, int C, const float* mask_img, int mask_h, int mask_w,
                          float* patch_mask, void* stream)
 {
@@ -875,11 +872,6 @@ int gp_l2norm_split_mask(const float* x, void* hi, void* lo, int rows, int C, co
                        (_Float16*)lo, C, ngrp * 32, mask_img, mask_h, mask_w, patch_mask);
     GP_CHECK_LAUNCH("gp_l2norm_split");
     return GP_OK;
-}
-
-int gp_l2norm_split(const float* x, void* hi, void* lo, int rows, int C, void* stream)
-{
-    return gp_l2norm_split_mask(x, hi, lo, rows, C, nullptr, 0, 0, nullptr, stream);
 }
 
 static int g_match_compact = 1;  // 0: every patch treated as live = the full 256 x 256 tile (A/B hook: gp_match_split_set_compact)
@@ -919,15 +911,6 @@ static int match_tiles_split_launch(const void* q_hi, const void* q_lo, const vo
     return GP_OK;
 }
 
-int gp_match_tiles_split(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
-                         const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
-                         float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
-                         void* stream)
-{
-    return match_tiles_split_launch(q_hi, q_lo, b_hi, b_lo, qmask, bmask, labels, B, O, N, C, sim_threshold, patch_threshold,
-                                    idx_t2s, score_t2s, mask_all, sim_avg, nullptr, stream);
-}
-
 int gp_match_tiles_split_dir(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
                              const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
                              float patch_threshold, int search_direction, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
@@ -937,6 +920,7 @@ int gp_match_tiles_split_dir(const void* q_hi, const void* q_lo, const void* b_h
                                     idx_t2s, score_t2s, mask_all, sim_avg, nullptr, stream, search_direction);
 }
 
+#ifdef GP_PROBES
 // probe build: trace[(tile q) * 8 + i] = 100 MHz wall-clock stamps (0 entry, 1 first slab staged, 2 k loop done, 3 maxima,
 // 4 merge, 5 per-patch outputs, 6 end) and [7] = XCC_ID << 32 | HW_ID (tools/probe_match_fixed.py)
 int gp_match_tiles_split_trace(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
@@ -954,6 +938,7 @@ int gp_match_split_set_compact(int on)
     g_match_compact = on ? 1 : 0;
     return GP_OK;
 }
+#endif
 
 int gp_topk(const float* sim_avg, int B, int N, int k, int* ids, float* scores, void* stream)
 {

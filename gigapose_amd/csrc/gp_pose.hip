@@ -324,14 +324,6 @@ int gp_ransac_scored(const long long* src_pts, const long long* tar_pts, const f
     return GP_OK;
 }
 
-int gp_ransac(const long long* src_pts, const long long* tar_pts, const float* rel_scale,
-              const float* rel_inplane, int R, float patch_size, float pixel_threshold, float* M,
-              unsigned char* failed, long long* inl_src, long long* inl_tar, long long* inl_score, void* stream)
-{
-    return gp_ransac_scored(src_pts, tar_pts, rel_scale, rel_inplane, nullptr, R, patch_size, pixel_threshold, M, failed, inl_src, inl_tar,
-                            inl_score, stream);
-}
-
 int gp_recover_poses(const int* labels, const float* tar_K, const float* tar_M, const long long* id_src,
                      const float* pred_M, const float* tmpl_K, const float* tmpl_M, const float* tmpl_pose, int B,
                      int O, int N, int k, float* poses, int* bad_crop_M, void* stream)

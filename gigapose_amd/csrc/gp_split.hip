@@ -573,6 +573,7 @@ int gp_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* w_hi, c
     return GP_OK;
 }
 
+#ifdef GP_PROBES
 /* probe: the fc-shaped GEMM (act_is_b, no epilogue) with per-phase cycle counters of one mid-grid block;
  * out20 (host): [wave 0..3][gload issue, LDS-read+MFMA issue, MFMA drain, convert+LDS-write, barrier] */
 int gp_gemm_split_set_trace(unsigned long long* dev_buf)
@@ -599,6 +600,7 @@ int gp_gemm_split_timing(const float* act, int ld_act, const void* whi, const vo
     out20[20] = w[0]; out20[21] = w[1]; out20[22] = (unsigned long long)occ;
     return GP_OK;
 }
+#endif
 
 int gp_gemm_split(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J, int K,
                   int act_is_b, int epilogue, const float* bias, const float* scale, const float* residual, int ldr,

@@ -349,21 +349,7 @@ unsigned g_epoch256 = 0;
 // of gemm_split256_kernel; the arithmetic (operand values, k order) is identical, so results are bit-identical to it.
 // Work distribution: data-parallel rounds of whole tiles first (L2 reuse), stream-K only for the last round + remainder.
 enum { PEPI_GELU_PLANES = 6, PEPI_BIAS_I_PLANES = 7 };  // bias along i (6: + GELU), output as activation planes O[j][i] (x 8)
-// LayerNorm folded into its neighbours (round 4).  LN(x)_k = (x_k - mu) r g_k + be_k with per-token mu, r, so
-//     sum_k W_ik LN(x)_k + b_i = r (sum_k (W_ik g_k) x_k - mu s_i) + b'_i,   s_i = sum_k W_ik g_k,  b'_i = b_i + sum_k W_ik be_k:
-// the GEMM runs on the RAW residual planes with the weights W diag(g) and the per-token part moves into the epilogue.  The 48
-// LayerNorm launches of a ViT-L forward (1.7 ms of a 43 ms step: a full read of X and a full write of the planes each) disappear:
-//   10 (producer: proj, fc2)  x = res + scale_i (acc + bias_i) on a TOKEN-MAJOR f32 residual stream res / D [j][i], and the same
-//      x as raw activation planes O[j][i] (x 8) + per-token partial (sum, sum of squares) of the tile's 256 channels;
-//    8 (consumer: q|k|v)      O[j][i] = planes of  r_j (acc - mu_j s_i) + b'_i      (bias = b', scale = s; mu, r from the partials)
-//    9 (consumer: fc1)        the same through GELU.
-// Statistics in f32 as E[x^2] - mu^2 over tree-ordered partial sums (in-lane 8, 3 butterfly steps, 4 waves, K / 256 tiles): the
-// relative error of the variance is ~1e-7 (1 + mu^2 / var) -- mu^2 << var for a transformer's residual stream (tests plant
-// outlier channels and a mean of several sigma); deterministic (fixed order, no atomics).
-enum { PEPI_LNF_BIAS_PLANES = 8, PEPI_LNF_GELU_PLANES = 9, PEPI_RES_PLANES_STATS = 10 };
-template <int EPI> constexpr bool kEpiPlanesOut = EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES || EPI == PEPI_LNF_BIAS_PLANES || EPI == PEPI_LNF_GELU_PLANES;
-template <int EPI> constexpr bool kEpiLnf = EPI == PEPI_LNF_BIAS_PLANES || EPI == PEPI_LNF_GELU_PLANES;
-template <int EPI> constexpr bool kEpiGelu = EPI == PEPI_GELU_PLANES || EPI == PEPI_LNF_GELU_PLANES || EPI == XEPI_BIAS_I_GELU;
+template <int EPI> constexpr bool kEpiPlanesOut = EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES;
 
 struct ArgsP {
     const _Float16* ahi; const _Float16* alo;  // A planes [I][K]
@@ -380,13 +366,6 @@ struct ArgsP {
     int* status;                // guard rails (gp_common.h)
     int strip_j0, strip_fj;     // ragged J: rows [strip_j0, strip_j0 + 32 strip_fj) of B are not tiled, see strip_phase
     int par;                    // fewer tiles than slots: the slots of a tile split its K in PARALLEL (see the kernel)
-    // LayerNorm folded into its neighbour GEMMs (epilogues 8-10, see below).  Statistics travel as per-token partial (sum, sum of
-    // squares) pairs: tile rows as [K / 256][ld][2] (one pair per 256-channel tile of the producer), strip rows as [K / 32][256][2]
-    const float* ln_main; const float* ln_strip;   // consumer (8, 9): statistics of the rows of B
-    float* st_main; float* st_strip;               // producer (10): statistics of the rows it writes
-    int st_ld; float ln_eps;
-    int j_valid;                                   // rows of B that carry data (the last strip fragment may reach beyond them)
-    int park;                                      // PARK builds (epilogue 3): K of a whole tile runs as `park` parts, each folded into the f32 residual (see the kernel)
     float plane_scale;                             // plane epilogues 6 / 7: the output tensor's power-of-two scale (default kActScale = 8)
     float* amax;                                   // calibration launches: max |x| of the planes written (null otherwise)
 };
@@ -404,9 +383,8 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)  // value held by
 // in two rounds, so that every global access is 16 bytes per lane over full 128-byte lines (64 instead of 512
 // instructions per lane for the residual epilogue).  Wave-private: no workgroup barrier between the rounds (LDS
 // operations of one wave execute in order).  Same arithmetic per element as before: results are bit-identical.
-template <int EPI, int NJ = 4, bool BIAS_MUL = false>
-__device__ __forceinline__ void epilogue_f32_lds(const ArgsP& a, f32x16 (&acc)[2][NJ], float* __restrict__ wl, int i_base, int j_base, int ln,
-                                                 float bias_mul = 1.0f)  // BIAS_MUL (PARK builds): 1 for a tile's first K part, 0 for the later ones
+template <int EPI, int NJ = 4>
+__device__ __forceinline__ void epilogue_f32_lds(const ArgsP& a, f32x16 (&acc)[2][NJ], float* __restrict__ wl, int i_base, int j_base, int ln)
 {
     const int l31 = ln & 31, half = ln >> 5;
     constexpr bool kBiasI = EPI == XEPI_BIAS_I || EPI == XEPI_BIAS_I_GELU || EPI == XEPI_BIAS_I_SCALE_RES || EPI == XEPI_BIAS_I_RELU;
@@ -457,7 +435,6 @@ __device__ __forceinline__ void epilogue_f32_lds(const ArgsP& a, f32x16 (&acc)[2
     } else {
         float bias_l = 0.f, scale_l = 0.f;  // lane l holds the value of row i_base + l
         if (kBiasI) bias_l = a.bias[i_base + ln];
-        if (BIAS_MUL) bias_l = bias_l * bias_mul;
         if (EPI == XEPI_BIAS_I_SCALE_RES) scale_l = a.scale[i_base + ln];
         f32x4 bias_j = {0.f, 0.f, 0.f, 0.f};
         if (EPI == XEPI_BIAS_J) bias_j = *reinterpret_cast<const f32x4*>(a.bias + j_base + 4 * l31);
@@ -640,213 +617,6 @@ __device__ __forceinline__ void epilogue_planes_thin(const ArgsP& a, f32x16 (&ac
     if (a.amax) gp_record_amax(a.amax, mx, 1.0f / a.plane_scale);          // calibration launches only (wave-uniform branch)
 }
 
-// Consumer of a folded LayerNorm (8 / 9): planes of  r_j (acc - mu_j s_i) + b'_i  [9: through GELU], the LDS turn and the stores of
-// epilogue_planes_thin.  tab: (mu, r) of this wave's 128 tokens (LDS, written by the tile prologue).
-template <int EPI>
-__device__ __forceinline__ void epilogue_planes_lnf(const ArgsP& a, f32x16 (&acc)[2][4], char* __restrict__ wl, const g32x2* __restrict__ tab,
-                                                    const float* __restrict__ rowc, int i_base, int j_base, int ln)
-{
-    // rowc: this wave's 64 rows of per-row constants in LDS, staged by the tile prologue: [0..63] = b'_i (x 8 in the bias variant),
-    // [256..319] = s_i.  Read where they are used (two 16-byte LDS reads per four rows): held in registers for the whole epilogue
-    // they are 64 VGPRs next to the 128 accumulators and the kernel spills -- and a kernel with a scratch segment pays for it at
-    // every launch, not only where it spills.
-    const int l31 = ln & 31, half = ln >> 5;
-    constexpr bool kGelu = EPI == PEPI_LNF_GELU_PLANES;
-    constexpr float k8 = kGelu ? 1.0f : kActScale;  // 8: the planes' x 8 folded into the affine step (exact); 9: into GELU's 0.5 x
-    const __amdgpu_buffer_rsrc_t r_hi = __builtin_amdgcn_make_buffer_rsrc((void*)a.ohi, 0, 0x7ffffff0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_lo = __builtin_amdgcn_make_buffer_rsrc((void*)a.olo, 0, 0x7ffffff0, 0x00020000);
-    const unsigned v_pl = ((unsigned)(j_base + (ln >> 3)) * (unsigned)a.ldo + (unsigned)(i_base + 8 * (ln & 7))) * 2u;
-    float mx = 0.f;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn) {
-            const int ni = 2 * h + nn, jl = 32 * nn + l31;
-            const g32x2 st = tab[64 * h + jl];
-            const float A = st[1] * (a.out_scale * k8);  // r_j x the exact power of two that undoes the operand scales (x 8)
-            const float Mj = -(st[0] * st[1]) * k8;      // -mu_j r_j
-            char* wrow = wl + jl * 128;
-            const int sw = (jl & 7) << 1;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const f32x4 bq = *reinterpret_cast<const f32x4*>(rowc + 32 * mi + 8 * r4 + 4 * half);
-                    const f32x4 sq = *reinterpret_cast<const f32x4*>(rowc + TB + 32 * mi + 8 * r4 + 4 * half);
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float c = __builtin_fmaf(Mj, sq[e], bq[e]);
-                        const float x = __builtin_fmaf(acc[mi][ni][4 * r4 + e], A, c);
-                        v[e] = kGelu ? gelu_fast_x8(x) : x;
-                    }
-                    u32x2 oh, ol;
-                    oh[0] = pack_hi_pair(v[0], v[1]);
-                    oh[1] = pack_hi_pair(v[2], v[3]);
-                    ol[0] = lo_pair(v[0], v[1], oh[0]);
-                    ol[1] = lo_pair(v[2], v[3], oh[1]);
-                    mx = absmax3(absmax3(mx, v[0], v[1]), v[2], v[3]);
-                    const int c8 = 8 * mi + 2 * r4 + half;  // 8-byte piece of the 128-byte row: rows 4 c8 .. 4 c8 + 3
-                    *reinterpret_cast<u32x2*>(wrow + ((c8 ^ sw) << 3)) = oh;
-                    *reinterpret_cast<u32x2*>(wrow + 8192 + ((c8 ^ sw) << 3)) = ol;
-                }
-        }
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int jl = 8 * it + (ln >> 3), c16 = ln & 7;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(wl + pl * 8192 + jl * 128 + ((c16 ^ (jl & 7)) << 4));
-                // buffer store: one 32-bit lane offset for all sixteen stores + a scalar offset per item (sixteen 64-bit flat
-                // addresses are sixteen register pairs, and this epilogue has none to spare)
-                __builtin_amdgcn_raw_buffer_store_b128(v, pl ? r_lo : r_hi, v_pl, (unsigned)(64 * h + 8 * it) * (unsigned)a.ldo * 2u, 0);
-            }
-        }
-    }
-    if (!(mx <= kSplitPlaneLimit)) gp_raise(a.status, GP_ST_SPLIT_RANGE);  // !(<=): NaN counts (v_maximum3 propagates it)
-}
-
-// Producer of a folded LayerNorm (10): x = res + scale_i (acc out_scale + bias_i) on the token-major f32 residual stream, plus the raw
-// planes of x and the per-token partial statistics of this wave's 64 channels.  The wave turns its 64 (i) x 128 (j) tile through
-// its 16 KiB of LDS as RAW accumulators in two rounds of 64 tokens (token rows of 256 bytes, 16-byte pieces XOR-placed by the
-// token: writes and reads conflict-free); after the turn a lane holds 8 CONSECUTIVE channels of a token, the same 8 for all its
-// items: bias and LayerScale are 4 registers each, every global access is 16 bytes per lane with 8 lanes covering a token's 256 (f32)
-// or 128 (plane) contiguous bytes, and the token's 64-channel sums are three butterfly steps away.  res != D (the residual stream
-// ping-pongs between two buffers): no load waits for a store.  st: [128 tokens][2] partials of this wave (LDS).
-__device__ __forceinline__ void epilogue_res_planes(const ArgsP& a, f32x16 (&acc)[2][4], float* __restrict__ wl, float* __restrict__ st, int i_base,
-                                                    int j_base, int ln)
-{
-    const int l31 = ln & 31, half = ln >> 5, tq = ln >> 3, c8 = ln & 7;
-    const int pm = a.dp >> 2;  // PROBE mask (gp_gemm_planes256_set_dp bits 2..5): 1 no statistics, 2 no plane stores, 4 no D stores, 8 no residual loads
-    // Buffer addressing: one descriptor per array (scalar registers), ONE 32-bit lane offset per element size -- row (j_base + tq),
-    // channels i_base + 8 c8 .. + 7 -- and a scalar offset per item.  (With 64-bit flat addresses the sixteen items' address pairs
-    // of four arrays are what the compiler spills; a kernel with a scratch segment is slower at every launch.)
-    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, 0x7ffffff0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_d = __builtin_amdgcn_make_buffer_rsrc((void*)a.D, 0, 0x7ffffff0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_hi = __builtin_amdgcn_make_buffer_rsrc((void*)a.ohi, 0, 0x7ffffff0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_lo = __builtin_amdgcn_make_buffer_rsrc((void*)a.olo, 0, 0x7ffffff0, 0x00020000);
-    const unsigned ic = (unsigned)(i_base + 8 * c8);
-    const unsigned v_res = ((unsigned)(j_base + tq) * (unsigned)a.ldr + ic) * 4u;
-    const unsigned v_d = ((unsigned)(j_base + tq) * (unsigned)a.ldd + ic) * 4u;
-    const unsigned v_pl = ((unsigned)(j_base + tq) * (unsigned)a.ldo + ic) * 2u;
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + ic), b1 = *reinterpret_cast<const f32x4*>(a.bias + ic + 4);
-    const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.scale + ic), s1 = *reinterpret_cast<const f32x4*>(a.scale + ic + 4);
-    float mx = 0.f;
-    // The residual rows are fetched one batch of FOUR items (eight 16-byte loads per lane) AHEAD of the batch being processed: four
-    // stages (round h, items 4 (s & 1) ..), stage s issuing stage s + 1's loads before it touches its own.  With two items fetched
-    // and used at a time the epilogue ran at the latency of a cold 67 MB read: 61 us of a 135 us proj launch inside a forward
-    // (profiles/r04_lnfold_masks.txt); the loads do not depend on anything the epilogue computes (res != D).
-    u32x4 rr[2][4][2];
-    auto fetch = [&](int stage) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned so = (unsigned)(64 * (stage >> 1) + 8 * (4 * (stage & 1) + u)) * (unsigned)a.ldr * 4u;
-            if (pm & 8) { rr[stage & 1][u][0] = __builtin_bit_cast(u32x4, b0); rr[stage & 1][u][1] = __builtin_bit_cast(u32x4, b1); continue; }
-            rr[stage & 1][u][0] = __builtin_amdgcn_raw_buffer_load_b128(r_res, v_res, so, 0);
-            rr[stage & 1][u][1] = __builtin_amdgcn_raw_buffer_load_b128(r_res, v_res + 16u, so, 0);
-        }
-    };
-    fetch(0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn) {
-            const int ni = 2 * h + nn, jl = 32 * nn + l31;
-            float* wrow = wl + jl * 64;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    f32x4 v;
-                    v[0] = acc[mi][ni][4 * r4 + 0]; v[1] = acc[mi][ni][4 * r4 + 1];
-                    v[2] = acc[mi][ni][4 * r4 + 2]; v[3] = acc[mi][ni][4 * r4 + 3];
-                    const int piece = 8 * mi + 2 * r4 + half;  // channels 4 piece .. 4 piece + 3 of the wave's 64
-                    *reinterpret_cast<f32x4*>(wrow + ((piece ^ (jl & 15)) << 2)) = v;
-                }
-        }
-#pragma unroll
-        for (int q4 = 0; q4 < 2; ++q4) {
-            const int stage = 2 * h + q4;
-            if (stage < 3) fetch(stage + 1);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int it = 4 * q4 + u;
-                const int jl = 8 * it + tq;
-                const float* wrow = wl + jl * 64;
-                const f32x4 t0 = *reinterpret_cast<const f32x4*>(wrow + (((2 * c8) ^ (jl & 15)) << 2));
-                const f32x4 t1 = *reinterpret_cast<const f32x4*>(wrow + (((2 * c8 + 1) ^ (jl & 15)) << 2));
-                const f32x4 r0 = __builtin_bit_cast(f32x4, rr[stage & 1][u][0]), r1 = __builtin_bit_cast(f32x4, rr[stage & 1][u][1]);
-                f32x4 x0, x1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    x0[e] = __builtin_fmaf(s0[e], __builtin_fmaf(t0[e], a.out_scale, b0[e]), r0[e]);
-                    x1[e] = __builtin_fmaf(s1[e], __builtin_fmaf(t1[e], a.out_scale, b1[e]), r1[e]);
-                }
-                if (!(pm & 4)) {
-                    const unsigned so = (unsigned)(64 * h + 8 * it) * (unsigned)a.ldd * 4u;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x0), r_d, v_d, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x1), r_d, v_d + 16u, so, 0);
-                }
-                if (!(pm & 1)) {
-                    // statistics of the token's 8 channels here, tree order: pairs, fours, eight
-                    float sm = ((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3]));
-                    float sq = __builtin_fmaf(x0[3], x0[3], __builtin_fmaf(x0[2], x0[2], __builtin_fmaf(x0[1], x0[1], x0[0] * x0[0])));
-                    sq = sq + __builtin_fmaf(x1[3], x1[3], __builtin_fmaf(x1[2], x1[2], __builtin_fmaf(x1[1], x1[1], x1[0] * x1[0])));
-                    sm = sum8_lanes(sm);
-                    sq = sum8_lanes(sq);
-                    if (c8 == 0) {
-                        g32x2 pr;
-                        pr[0] = sm;
-                        pr[1] = sq;
-                        *reinterpret_cast<g32x2*>(st + 2 * (64 * h + jl)) = pr;
-                    }
-                }
-                // raw planes (x 8)
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = x0[e] * kActScale; v[4 + e] = x1[e] * kActScale; }
-                u32x4 oh, ol;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    oh[q] = pack_hi_pair(v[2 * q], v[2 * q + 1]);
-                    ol[q] = lo_pair(v[2 * q], v[2 * q + 1], oh[q]);
-                    mx = absmax3(mx, v[2 * q], v[2 * q + 1]);
-                }
-                if (!(pm & 2)) {
-                    const unsigned so = (unsigned)(64 * h + 8 * it) * (unsigned)a.ldo * 2u;
-                    __builtin_amdgcn_raw_buffer_store_b128(oh, r_hi, v_pl, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(ol, r_lo, v_pl, so, 0);
-                }
-            }
-        }
-    }
-    if (!(mx <= kSplitPlaneLimit)) gp_raise(a.status, GP_ST_SPLIT_RANGE);
-}
-
-// (mu, r) of one token from its partial (sum, sum of squares) pairs: np pairs `stride` floats apart, added in index order
-__device__ __forceinline__ g32x2 ln_finish(const float* __restrict__ p, int np, size_t stride, int K, float eps)
-{
-    float s = 0.f, q = 0.f;
-    for (int u0 = 0; u0 < np; u0 += 4) {  // four pairs in flight at a time (np = 4 / 16 for the tile rows, 32 / 128 for the strip): one
-        g32x2 v[4];                        // memory round trip per group instead of one per pair
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const g32x2*>(p + (size_t)min(u0 + u, np - 1) * stride);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (u0 + u < np) {
-                s = s + v[u][0];
-                q = q + v[u][1];
-            }
-        }
-    }
-    const float mu = s / (float)K;
-    const float var = fmaxf(__builtin_fmaf(-mu, mu, q / (float)K), 0.f);
-    g32x2 o;
-    o[0] = mu;
-    o[1] = 1.0f / __builtin_sqrtf(var + eps);
-    return o;
-}
-
 // Strip fragments are handed out on demand: a slot asks for the next fragment when it has finished its tiles.  The per-slot
 // time stamps show slots of different XCDs finishing equal work 8-11 % apart (k-step 2.33 us on the fastest XCD, 2.66 on the
 // slowest, the same order in every launch of a box), and with the static split (fragment f to slot f) the 64 fragments of a
@@ -906,9 +676,8 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         // epilogue operands of this fragment (used by wave 0 only, requested now: their latency hides behind the K loop)
         constexpr bool kBiasI = EPI == XEPI_BIAS_I || EPI == XEPI_BIAS_I_GELU || EPI == XEPI_BIAS_I_SCALE_RES || EPI == XEPI_BIAS_I_RELU ||
-                                EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES || kEpiLnf<EPI> || EPI == PEPI_RES_PLANES_STATS;
+                                EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES;
         f32x4 pre_bias[4], pre_scale[4], pre_res[4];
-        g32x2 pre_ln = {0.f, 1.f};  // 8 / 9: (mu, r) of this lane's token
         if (wave == 0) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
@@ -1018,67 +787,10 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
             const int j = j0 + l31;
             int bad = 0;
             float strip_mx = 0.f;          // 6 / 7: max |scaled value| this lane wrote (calibration launches record it)
-            float st_s = 0.f, st_q = 0.f;  // 10: this lane's 16 channels of token j
-            // the folded-LayerNorm epilogues fetch their extra operands HERE, after the K loop (one exposed round trip per fragment,
-            // a few fragments per launch): requested before it they are 40 more registers next to the loop's 128 and the kernel spills
-            if (kEpiLnf<EPI> || EPI == PEPI_RES_PLANES_STATS) {
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int i = i0 + frag_row(4 * r4, lane);
-                    pre_scale[r4] = *reinterpret_cast<const f32x4*>(a.scale + i);  // s_i (8, 9) / LayerScale (10)
-                    if (EPI == PEPI_RES_PLANES_STATS)  // token-major residual stream: this lane's four rows are 16 contiguous bytes
-                        pre_res[r4] = *reinterpret_cast<const f32x4*>(a.res + (size_t)(unsigned)j * (unsigned)a.ldr + (unsigned)i);
-                }
-                if (kEpiLnf<EPI>)  // the token's K / 32 strip partials (written by the producer's strip fragments, one per 32 channels)
-                    pre_ln = ln_finish(a.ln_strip + 2 * (size_t)(j - a.strip_j0), a.K >> 5, 2 * 256, a.K, a.ln_eps);
-            }
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int i = i0 + frag_row(4 * r4, lane);
-                if (kEpiLnf<EPI>) {  // r_j (acc - mu_j s_i) + b'_i, the tile epilogue's arithmetic (epilogue_planes_lnf)
-                    constexpr bool kGelu = EPI == PEPI_LNF_GELU_PLANES;
-                    constexpr float k8 = kGelu ? 1.0f : kActScale;
-                    const float A = pre_ln[1] * (a.out_scale * k8), Mj = -(pre_ln[0] * pre_ln[1]) * k8;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float c = __builtin_fmaf(Mj, pre_scale[r4][e], kGelu ? pre_bias[r4][e] : pre_bias[r4][e] * k8);
-                        const float x = __builtin_fmaf(acc[4 * r4 + e], A, c);
-                        v[e] = kGelu ? gelu_fast_x8(x) : x;
-                        bad |= !(fabsf(v[e]) <= kSplitPlaneLimit);
-                    }
-                    u32x2 oh, ol;
-                    oh[0] = pack_hi_pair(v[0], v[1]); oh[1] = pack_hi_pair(v[2], v[3]);
-                    ol[0] = lo_pair(v[0], v[1], oh[0]); ol[1] = lo_pair(v[2], v[3], oh[1]);
-                    const size_t o = (size_t)(unsigned)j * (unsigned)a.ldo + (unsigned)i;
-                    *reinterpret_cast<u32x2*>(a.ohi + o) = oh;
-                    *reinterpret_cast<u32x2*>(a.olo + o) = ol;
-                } else if (EPI == PEPI_RES_PLANES_STATS) {  // epilogue_res_planes' arithmetic on this lane's four channels of token j
-                    f32x4 x;
-                    float v[4];
-                    // Rows beyond the data (the last fragment's padding): the stream stays ZERO there.  Their operand rows hold whatever
-                    // the buffers' previous users left, and a residual stream that feeds on its own padding through 24 layers grows
-                    // without bound (the unfolded path normalised these rows in every LayerNorm launch); zeros give mu = 0, var = 0 and
-                    // a consumer output of b' -- finite, and never read by the attention kernel.
-                    const bool pad = j >= a.j_valid;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        x[e] = __builtin_fmaf(pre_scale[r4][e], __builtin_fmaf(acc[4 * r4 + e], a.out_scale, pre_bias[r4][e]), pre_res[r4][e]);
-                        if (pad) x[e] = 0.f;
-                        v[e] = x[e] * kActScale;
-                        bad |= !(fabsf(v[e]) <= kSplitPlaneLimit);
-                    }
-                    *reinterpret_cast<f32x4*>(a.D + (size_t)(unsigned)j * (unsigned)a.ldd + (unsigned)i) = x;
-                    u32x2 oh, ol;
-                    oh[0] = pack_hi_pair(v[0], v[1]); oh[1] = pack_hi_pair(v[2], v[3]);
-                    ol[0] = lo_pair(v[0], v[1], oh[0]); ol[1] = lo_pair(v[2], v[3], oh[1]);
-                    const size_t o = (size_t)(unsigned)j * (unsigned)a.ldo + (unsigned)i;
-                    *reinterpret_cast<u32x2*>(a.ohi + o) = oh;
-                    *reinterpret_cast<u32x2*>(a.olo + o) = ol;
-                    st_s = st_s + ((x[0] + x[1]) + (x[2] + x[3]));
-                    st_q = st_q + __builtin_fmaf(x[3], x[3], __builtin_fmaf(x[2], x[2], __builtin_fmaf(x[1], x[1], x[0] * x[0])));
-                } else if (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES) {
-                    g16x4 oh, ol;
+                if (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES) {                    g16x4 oh, ol;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float x = acc[4 * r4 + e] * a.out_scale + pre_bias[r4][e];
@@ -1106,16 +818,6 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
                     }
                 }
             }
-            if (EPI == PEPI_RES_PLANES_STATS) {  // the fragment's 32 channels of token j: this lane's 16 + the other half-wave's 16
-                st_s = st_s + __shfl_xor(st_s, 32);
-                st_q = st_q + __shfl_xor(st_q, 32);
-                if (half == 0) {
-                    g32x2 pr;
-                    pr[0] = st_s;
-                    pr[1] = st_q;
-                    *reinterpret_cast<g32x2*>(a.st_strip + 2 * ((size_t)(i0 >> 5) * 256 + (size_t)(j - a.strip_j0))) = pr;
-                }
-            }
             if (bad) gp_raise(a.status, GP_ST_SPLIT_RANGE);
             if ((EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES) && a.amax) gp_record_amax(a.amax, strip_mx, 1.0f / a.plane_scale);
         }
@@ -1126,30 +828,20 @@ __device__ __forceinline__ void strip_phase(const ArgsP& a, float* __restrict__ 
 // NJ: 32-row matrix tiles of B per wave -- 4: the 256 x 256 tile; 2: a 256 x 128 tile (wave tile 64 x 64, half the rows of the B
 // planes staged and half the matrix instructions per k-step) for launches whose 256 x 256 tiles fill at most half the slots: twice
 // the tiles, so half the slots per tile and half-size partial accumulators, or no split at all (round 4; B <= 16 crops at ViT-L).
-// PARK (round 5; epilogue 3 = x += scale (acc + bias) in place, whole tiles only): the K range of a tile runs as a.park PARTS, each from
-// a zero accumulator and each folded into the f32 residual by the tile's own epilogue (the first part carries the bias).  The one f32
-// accumulator then sees K / park instead of K products' roundings -- fc2's K = 4096 is 768 roundings of ONE accumulator (64 k16 blocks x
-// 3 products x 4), the only stage of the plane path measurably worse than a blocked CPU GEMM (profiles/r04_stage_errors.txt: 7.2e-7
-// vs 3.5e-7 of the output's rms).  Cost: one more epilogue + pipeline restart per part and tile.  Its own instantiation: the default
-// kernel's code and registers (251 VGPRs, no scratch) are untouched.
 // PSPLIT (PAR builds): false = the parallel-split reduction is compiled OUT (every tile whole on its own slot, S = 1).  With the 256 x 128
 // tiles taking every launch of at most 128 tiles, the 256 x 256 PAR build only ever runs 129-255 WHOLE tiles (ViT-L: q|k|v at 11-21
 // crops, proj / fc2 at 33-63) -- yet it carried the reduction's registers: 256 VGPRs + 150-200 bytes of scratch, and in round 5 an
 // unrelated edit moved those spills into the k loop (q|k|v at 16 crops 100 -> 214 us per launch, the 16-crop step 14.1 -> 16.5 ms;
 // profiles/r05_b16_regression.txt).  The no-split instantiation has nothing to spill.
-template <int EPI, bool TIMING = false, bool PAR = false, int NJ = 4, bool PARK = false, bool PSPLIT = true>
+template <int EPI, bool TIMING = false, bool PAR = false, int NJ = 4, bool PSPLIT = true>
 __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
 {
-    static_assert(NJ == 4 || (NJ == 2 && !kEpiLnf<EPI> && EPI != PEPI_RES_PLANES_STATS), "half-width tiles: epilogues 0-7 only");
-    static_assert(!PARK || (EPI == XEPI_BIAS_I_SCALE_RES && !PAR && NJ == 4 && !TIMING), "PARK: the in-place residual epilogue on whole 256 x 256 tiles");
+    static_assert(NJ == 4 || NJ == 2, "256 x 256 or 256 x 128 tiles");
     constexpr int TJ = 64 * NJ;  // rows of B (columns j) per tile
     unsigned long long tc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     const unsigned long long k_c0 = TIMING ? __builtin_readcyclecounter() : 0, k_w0 = TIMING ? wall_clock64() : 0;
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * TBUF + 2048];  // 128 KiB of operand buffers (+ 4 KiB: the strip's padded rows)
     __shared__ int strip_next;
-    // folded LayerNorm: (mu, r) of the tile's 256 tokens (consumer, 2 KiB) / per wave-row partial sums of its 256 tokens (producer, 8 KiB)
-    // + (consumer) the tile's 256 rows of b'_i and s_i (2 KiB)
-    __shared__ __attribute__((aligned(16))) float ln_lds[(kEpiLnf<EPI> ? 4 * TB : (EPI == PEPI_RES_PLANES_STATS ? 4 * 2 * TB : 4))];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1, grp = wave >> 2;
@@ -1172,7 +864,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
     // part n % S of tile n / S, slots beyond S * tiles have no tile (they take strip fragments).  S = 1: whole tiles, no exchange.
     // (the GELU build keeps whole tiles, S = 1: with the partial-sum loop next to its epilogue hipcc spills 273 registers, and a
     // launch of T < 256 whole tiles on T slots is within 10 % of the split one at the sizes where it occurs -- fc1 below 16 crops)
-    constexpr bool kParSplit = PAR && PSPLIT && EPI != PEPI_GELU_PLANES && EPI != PEPI_LNF_GELU_PLANES;
+    constexpr bool kParSplit = PAR && PSPLIT && EPI != PEPI_GELU_PLANES;
     const int par_S = kParSplit ? max(1, min(a.par, slots_x / max(n_t, 1))) : 1;  // a.par: the host's cap (k-steps per slot, see the launch)
     if (PAR) {
         const int tile = n / par_S, part = n - tile * par_S;
@@ -1220,11 +912,7 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
         const int gsz = min(a.group, a.tiles_i - first_i);
         const int i0 = (first_i + rr % gsz) * TB, j0 = (rr / gsz) * TJ;
 
-        // PARK: a whole tile's k range in n_parts parts (split tiles -- head / rest segments -- keep their single range)
-        const int n_parts = (PARK && !is_head && !is_rest) ? max(1, min(a.park, (seg_s1 - seg_s0) / 4)) : 1;
-        for (int part = 0; part < n_parts; ++part) {
-        const int s0 = PARK ? seg_s0 + (seg_s1 - seg_s0) * part / n_parts : seg_s0;
-        const int s1 = PARK ? seg_s0 + (seg_s1 - seg_s0) * (part + 1) / n_parts : seg_s1;
+        const int s0 = seg_s0, s1 = seg_s1;
         f32x16 acc[2][NJ];
         if (!PAR && is_rest) {
             if (tid == 0) {
@@ -1296,18 +984,6 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
         };
         gload(0);
         stage(0);
-        if (kEpiLnf<EPI>) {
-            // (mu, r) of this tile's 256 tokens for the epilogue, from the K / 256 partial pairs the producer's tiles wrote: thread t
-            // = token j0 + t.  Requested behind the first slab (vector-memory results return in order: the wait costs nothing extra),
-            // read again only after the k loop's barriers; the previous segment's readers are behind its closing barrier.
-            if (tid < TB) {
-                *reinterpret_cast<g32x2*>(ln_lds + 2 * tid) = ln_finish(a.ln_main + 2 * (size_t)(j0 + tid), a.K >> 8, 2 * (size_t)a.st_ld, a.K, a.ln_eps);
-            } else {  // the other half of the workgroup: the tile's per-row constants b'_i (x 8 where the epilogue folds the planes' scale) and s_i
-                const int r = tid - TB;
-                ln_lds[2 * TB + r] = a.bias[i0 + r] * (EPI == PEPI_LNF_GELU_PLANES ? 1.0f : kActScale);
-                ln_lds[3 * TB + r] = a.scale[i0 + r];
-            }
-        }
         __builtin_amdgcn_sched_barrier(0);
         if (ns > 1) gload(1);
         __syncthreads();
@@ -1448,33 +1124,12 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
             asm volatile("" : "+v"(tid_));  // keep the epilogue's address arithmetic inside the segment loop
             __syncthreads();                // every wave has read its last operand fragments: the buffers are free
             char* wl = reinterpret_cast<char*>(lds) + (tid_ >> 6) * 16384;
-            if constexpr (kEpiLnf<EPI> && NJ == 4)
-                epilogue_planes_lnf<EPI>(a, acc, wl, reinterpret_cast<const g32x2*>(ln_lds) + 128 * wc, ln_lds + 2 * TB + 64 * wr, i0 + 64 * wr, j0 + 128 * wc,
-                                         tid_ & 63);
-            else if constexpr (EPI == PEPI_RES_PLANES_STATS && NJ == 4)
-                epilogue_res_planes(a, acc, reinterpret_cast<float*>(wl), ln_lds + 2 * (TB * wr + 128 * wc), i0 + 64 * wr, j0 + 128 * wc, tid_ & 63);
-            else if constexpr (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES)
+            if constexpr (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES)
                 epilogue_planes_thin<EPI, NJ>(a, acc, wl, i0 + 64 * wr, j0 + 32 * NJ * wc, tid_ & 63);
-            else if constexpr (PARK)
-                epilogue_f32_lds<EPI, NJ, true>(a, acc, reinterpret_cast<float*>(wl), i0 + 64 * wr, j0 + 32 * NJ * wc, tid_ & 63, part == 0 ? 1.0f : 0.0f);
             else
                 epilogue_f32_lds<EPI, NJ>(a, acc, reinterpret_cast<float*>(wl), i0 + 64 * wr, j0 + 32 * NJ * wc, tid_ & 63);
             __syncthreads();  // LDS buffer 0 is re-staged by the next segment's prologue
-            if constexpr (EPI == PEPI_RES_PLANES_STATS) {
-                // the tile's partial statistics: the four wave rows' 64-channel sums of token j0 + t, added in wave-row order, as ONE
-                // (sum, sum of squares) pair per token and 256-channel tile (coalesced: consecutive threads, consecutive tokens).
-                // ln_lds is rewritten by the next tile's epilogue, many barriers from here.
-                if (tid_ < TB) {
-                    const g32x2 p0 = *reinterpret_cast<const g32x2*>(ln_lds + 2 * tid_), p1 = *reinterpret_cast<const g32x2*>(ln_lds + 2 * (TB + tid_));
-                    const g32x2 p2 = *reinterpret_cast<const g32x2*>(ln_lds + 2 * (2 * TB + tid_)), p3 = *reinterpret_cast<const g32x2*>(ln_lds + 2 * (3 * TB + tid_));
-                    g32x2 t;
-                    t[0] = (p0[0] + p1[0]) + (p2[0] + p3[0]);
-                    t[1] = (p0[1] + p1[1]) + (p2[1] + p3[1]);
-                    *reinterpret_cast<g32x2*>(a.st_main + 2 * ((size_t)(i0 / TB) * (size_t)a.st_ld + (size_t)(j0 + tid_))) = t;
-                }
-            }
         }
-        }  // part
         if (TIMING && a.trace && tid == 0 && seg < 7) a.trace[(size_t)p * 32 + 5 + 4 * seg] = wall_clock64();
     }
     if (a.strip_fj > 0) strip_phase<EPI>(a, reinterpret_cast<float*>(lds), &strip_next, threadIdx.x);
@@ -1531,22 +1186,20 @@ int gp_gemm_split256_launch(const float* act, int ld_act, const void* whi, const
     a.epoch = (int)(0x40000000u | g_epoch256);    // flags) with gp_gemm.hip's stream-K inside one forward
     GpProfScope prof(GP_PROF_GEMM_SPLIT, 2.0 * I * J * K, st);
     switch (epilogue) {
+#ifdef GP_PROBES   // plain / ReLU epilogues: tests of the tile machinery only (the ViT's f32-activation fallback uses 1-4)
         case XEPI_NONE: launch256<XEPI_NONE>(a, act_is_b != 0, kSlots, st); break;
+        case XEPI_BIAS_I_RELU: launch256<XEPI_BIAS_I_RELU>(a, act_is_b != 0, kSlots, st); break;
+#endif
         case XEPI_BIAS_I: launch256<XEPI_BIAS_I>(a, act_is_b != 0, kSlots, st); break;
         case XEPI_BIAS_I_GELU: launch256<XEPI_BIAS_I_GELU>(a, act_is_b != 0, kSlots, st); break;
         case XEPI_BIAS_I_SCALE_RES: launch256<XEPI_BIAS_I_SCALE_RES>(a, act_is_b != 0, kSlots, st); break;
         case XEPI_BIAS_J: launch256<XEPI_BIAS_J>(a, act_is_b != 0, kSlots, st); break;
-        case XEPI_BIAS_I_RELU: launch256<XEPI_BIAS_I_RELU>(a, act_is_b != 0, kSlots, st); break;
-        default: GP_REQUIRE(false, "gp_gemm_split256: unknown epilogue %d", epilogue);
+        default: GP_REQUIRE(false, "gp_gemm_split256: epilogue %d is not built (product: 1-4; 0 and 5 need -DGP_PROBES)", epilogue);
     }
     GP_CHECK_LAUNCH("gp_gemm_split256");
     return GP_OK;
 }
 
-int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
-                                void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
-                                const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace,
-                                const GpLnFold* ln, const GpPlaneOut* po = nullptr);
 static int g_planes_dp = 1;  // 1: data-parallel rounds before the stream-K remainder (0: everything stream-K; A/B hook)
 
 // internal entry (gp_vit.hip): D[i][j] = epi( out_scale * sum_k A[i][k] B[j][k] ), A / B = pre-split planes (see above)
@@ -1586,17 +1239,6 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
                              const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace,
                              const GpPlaneOut* po = nullptr)
 {
-    return gp_gemm_planes256_launch_ln(ahi, alo, bhi, blo, D, ldd, ohi, olo, ldo, I, J, J_valid, K, epilogue, bias, scale, res, ldr, out_scale,
-                                       scratch, st, trace, nullptr, po);
-}
-
-// + the folded-LayerNorm epilogues (8, 9: consumer -- ln->ln_main / ln_strip hold the statistics of B's rows, bias = b', scale = s;
-// 10: producer -- D / res token-major [J][I], planes out, statistics to ln->st_main / st_strip).  ln->ld = tokens per partial row.
-int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
-                                void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
-                                const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace,
-                                const GpLnFold* ln, const GpPlaneOut* po)
-{
     GP_REQUIRE(gp_gemm_planes256_usable(I, J, J_valid, K),
                "gp_gemm_planes256: I=%d, J=%d must be multiples of 256 with >= 8 tiles below J_valid=%d, K=%d of 32", I, J, J_valid, K);
     int J_main, strip_fj;
@@ -1606,8 +1248,7 @@ int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bh
                    ((uintptr_t)bhi % 16 == 0) && ((uintptr_t)blo % 16 == 0) && ((uintptr_t)scratch % 16 == 0),
                "gp_gemm_planes256: null / misaligned operand");
     GP_REQUIRE((long long)I * K * 2 < (1ll << 31) && (long long)J * K * 2 < (1ll << 31), "gp_gemm_planes256: operand planes too large");
-    const bool lnf = epilogue == PEPI_LNF_BIAS_PLANES || epilogue == PEPI_LNF_GELU_PLANES, resp = epilogue == PEPI_RES_PLANES_STATS;
-    const bool planes_out = epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES || lnf || resp;
+    const bool planes_out = epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES;
     if (planes_out)
         GP_REQUIRE(ohi && olo && ldo % 4 == 0 && ((uintptr_t)ohi % 8 == 0) && ((uintptr_t)olo % 8 == 0) && bias, "gp_gemm_planes256: bad plane output");
     if (!planes_out)
@@ -1616,38 +1257,32 @@ int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bh
                    "gp_gemm_planes256: bad f32 output (16-byte rows)");
     if (planes_out)
         GP_REQUIRE(ldo % 8 == 0 && ((uintptr_t)ohi % 16 == 0) && ((uintptr_t)olo % 16 == 0), "gp_gemm_planes256: plane output rows must be 16-byte aligned");
-    if (lnf)
-        GP_REQUIRE(ln && ln->ln_main && ln->ln_strip && scale && K % 256 == 0 && ln->ld >= J && ((uintptr_t)bias % 16 == 0) && ((uintptr_t)scale % 16 == 0) &&
-                       ((uintptr_t)ln->ln_main % 8 == 0) && ((uintptr_t)ln->ln_strip % 8 == 0),
-                   "gp_gemm_planes256: epilogue %d needs the statistics of B's rows (K %% 256 == 0), s_i and b'_i", epilogue);
-    if (resp)
-        GP_REQUIRE(ln && ln->st_main && ln->st_strip && scale && D && res && (D != res || ldd == ldr) && ldd % 4 == 0 && ldr % 4 == 0 && ln->ld >= J &&
-                       ((uintptr_t)D % 16 == 0) && ((uintptr_t)res % 16 == 0) && ((uintptr_t)bias % 16 == 0) && ((uintptr_t)scale % 16 == 0) &&
-                       (long long)J * ldd < (1ll << 31) && (long long)J * ldr < (1ll << 31) && ((uintptr_t)ln->st_main % 8 == 0) && ((uintptr_t)ln->st_strip % 8 == 0),
-                   "gp_gemm_planes256: epilogue 10 needs a token-major residual stream (res != D), LayerScale, and the statistics buffers");
     ArgsP a{(const _Float16*)ahi, (const _Float16*)alo, (const _Float16*)bhi, (const _Float16*)blo, D, ldd, (_Float16*)ohi, (_Float16*)olo, ldo,
             K, bias, scale, res, ldr, I / TB, J_main / TB, 4, reinterpret_cast<int*>(scratch),
             reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + kHeaderBytes), 0, out_scale, g_planes_dp, trace, gp_status_buffer(),
             J_main, strip_fj, (long long)(I / TB) * (J_main / TB) < kSlots ? max(1, (K / TBK) / g_planes_par_min_steps) : 0};
-    a.j_valid = (J_valid > 0 && J_valid < J) ? J_valid : J;
     a.plane_scale = kActScale;
     a.amax = nullptr;
-    a.park = 0;
-    if (po) {   // per-tensor output scale of the plane epilogues 6 / 7 (the folded-LayerNorm epilogues keep the default)
-        GP_REQUIRE(po->scale > 0.f && (epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES || (po->scale == kActScale && !po->amax)),
+    if (po) {   // per-tensor output scale of the plane epilogues 6 / 7
+        GP_REQUIRE(po->scale > 0.f && (planes_out || (po->scale == kActScale && !po->amax)),
                    "gp_gemm_planes256: a plane scale other than 8 needs epilogue 6 or 7 (got %d)", epilogue);
         a.plane_scale = po->scale;
         a.amax = po->amax;
-        a.park = po->park;
-    }
-    if (ln) {
-        a.ln_main = ln->ln_main; a.ln_strip = ln->ln_strip; a.st_main = ln->st_main; a.st_strip = ln->st_strip;
-        a.st_ld = ln->ld; a.ln_eps = ln->eps;
     }
     g_epoch256 = (g_epoch256 + 1) & 0x3fffffff;
     a.epoch = (int)(0x40000000u | g_epoch256);
     GpProfScope prof(GP_PROF_GEMM_SPLIT, 2.0 * I * (J_valid > 0 && J_valid < J ? J_valid : J) * K, st);
-    if (trace && a.par) {  // probe build of the parallel split-K kernel
+    // The product's three epilogues (the ViT plane path: 3 = in-place residual, 6 = GELU -> planes, 7 = bias -> planes); the f32-output
+    // epilogues 0, 1, 2, 4, 5 are instantiated in probe builds only (-DGP_PROBES: tests of the tile / strip / split-K machinery on
+    // plain GEMMs, the f32-attention A/B path of the ViT)
+#ifdef GP_PROBES
+#define GP_PLANES_EXTRA(...)                                                                                              \
+    case XEPI_NONE: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_NONE, __VA_ARGS__>), dim3(kSlots), dim3(TNT), 0, st, a); break;           \
+    case XEPI_BIAS_I: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I, __VA_ARGS__>), dim3(kSlots), dim3(TNT), 0, st, a); break;       \
+    case XEPI_BIAS_I_GELU: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_GELU, __VA_ARGS__>), dim3(kSlots), dim3(TNT), 0, st, a); break; \
+    case XEPI_BIAS_J: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_J, __VA_ARGS__>), dim3(kSlots), dim3(TNT), 0, st, a); break;       \
+    case XEPI_BIAS_I_RELU: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_RELU, __VA_ARGS__>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+    if (trace && a.par) {  // probe build of the parallel split-K kernel with per-slot time stamps
         switch (epilogue) {
             case XEPI_BIAS_I_SCALE_RES: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES, true, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
             case PEPI_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_GELU_PLANES, true, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
@@ -1668,11 +1303,15 @@ int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bh
         GP_CHECK_LAUNCH("gp_gemm_planes256_trace");
         return GP_OK;
     }
-    // 256 x 128 tiles where the 256 x 256 ones fill at most half the slots (ViT-L below ~16 crops; epilogues 3 / 6 / 7): the parallel
-    // split-K build on twice the tiles -- proj / fc2 split every tile over half as many slots with half-size partial accumulators,
-    // q|k|v and fc1 stop splitting / fill the chip with whole tiles.  (Between 128 and 256 whole tiles, twice as many half-width tiles
-    // cut stream-K style over all slots by the serial hand-over build was measured too: ViT-L forward at 12 / 16 / 40 / 48 crops
-    // 8.55 -> 8.95, 10.39 -> 10.44, 22.95 -> 22.5, 25.19 -> 25.55 ms -- the hand-overs cost what the balance gains; not kept.)
+#else
+#define GP_PLANES_EXTRA(...)
+    GP_REQUIRE(!trace, "gp_gemm_planes256: time-stamped launches need the probe build (-DGP_PROBES)");
+#endif
+    // 256 x 128 tiles where the 256 x 256 ones fill at most half the slots (ViT-L below ~16 crops): the parallel split-K build on twice
+    // the tiles -- proj / fc2 split every tile over half as many slots with half-size partial accumulators, q|k|v and fc1 stop
+    // splitting / fill the chip with whole tiles.  (Between 128 and 256 whole tiles, twice as many half-width tiles cut stream-K
+    // style over all slots by the serial hand-over build was measured too: ViT-L forward at 12 / 16 / 40 / 48 crops 8.55 -> 8.95,
+    // 10.39 -> 10.44, 22.95 -> 22.5, 25.19 -> 25.55 ms -- the hand-overs cost what the balance gains; not kept.)
     const long long T256 = (long long)a.tiles_i * a.tiles_j;
     const bool epi_half = epilogue == XEPI_BIAS_I_SCALE_RES || epilogue == PEPI_GELU_PLANES || epilogue == PEPI_BIAS_I_PLANES;
     if (a.par && g_planes_half && epi_half && 2 * T256 <= kSlots) {
@@ -1689,58 +1328,36 @@ int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bh
         // 129-255 whole tiles, one per slot (S = floor(256 / tiles) = 1): the PAR build WITHOUT the split-K reduction (see PSPLIT)
         a.par = 1;
         if (epilogue == XEPI_BIAS_I_SCALE_RES)
-            hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES, false, true, 4, false, false>), dim3(kSlots), dim3(TNT), 0, st, a);
+            hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES, false, true, 4, false>), dim3(kSlots), dim3(TNT), 0, st, a);
         else
-            hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES, false, true, 4, false, false>), dim3(kSlots), dim3(TNT), 0, st, a);
+            hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES, false, true, 4, false>), dim3(kSlots), dim3(TNT), 0, st, a);
         GP_CHECK_LAUNCH("gp_gemm_planes256/par-whole");
         return GP_OK;
     }
     if (a.par) {  // fewer tiles than slots: the parallel split-K build (its own instantiation: the serial hand-over kernel keeps its registers)
         switch (epilogue) {
-            case XEPI_NONE: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_NONE, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-            case XEPI_BIAS_I: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-            case XEPI_BIAS_I_GELU: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_GELU, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+            GP_PLANES_EXTRA(false, true)
             case XEPI_BIAS_I_SCALE_RES: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-            case XEPI_BIAS_J: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_J, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-            case XEPI_BIAS_I_RELU: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_RELU, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
             case PEPI_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_GELU_PLANES, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
             case PEPI_BIAS_I_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-            case PEPI_LNF_BIAS_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_LNF_BIAS_PLANES, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-            case PEPI_LNF_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_LNF_GELU_PLANES, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-            case PEPI_RES_PLANES_STATS: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_RES_PLANES_STATS, false, true>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-            default: GP_REQUIRE(false, "gp_gemm_planes256: unknown epilogue %d", epilogue);
+            default: GP_REQUIRE(false, "gp_gemm_planes256: epilogue %d is not built (product: 3, 6, 7; the others need -DGP_PROBES)", epilogue);
         }
         GP_CHECK_LAUNCH("gp_gemm_planes256/par");
         return GP_OK;
     }
-    if (a.park > 1 && epilogue == XEPI_BIAS_I_SCALE_RES && D == res && ldd == ldr) {   // in place: a later part reads what an earlier part wrote
-        hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES, false, false, 4, true>), dim3(kSlots), dim3(TNT), 0, st, a);
-        GP_CHECK_LAUNCH("gp_gemm_planes256/park");
-        return GP_OK;
-    }
     switch (epilogue) {
-        case XEPI_NONE: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_NONE>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-        case XEPI_BIAS_I: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-        case XEPI_BIAS_I_GELU: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_GELU>), dim3(kSlots), dim3(TNT), 0, st, a); break;
+        GP_PLANES_EXTRA(false)
         case XEPI_BIAS_I_SCALE_RES: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_SCALE_RES>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-        case XEPI_BIAS_J: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_J>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-        case XEPI_BIAS_I_RELU: hipLaunchKernelGGL((gemm_planes256_kernel<XEPI_BIAS_I_RELU>), dim3(kSlots), dim3(TNT), 0, st, a); break;
         case PEPI_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_GELU_PLANES>), dim3(kSlots), dim3(TNT), 0, st, a); break;
         case PEPI_BIAS_I_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_BIAS_I_PLANES>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-        case PEPI_LNF_BIAS_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_LNF_BIAS_PLANES>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-        case PEPI_LNF_GELU_PLANES: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_LNF_GELU_PLANES>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-        case PEPI_RES_PLANES_STATS: hipLaunchKernelGGL((gemm_planes256_kernel<PEPI_RES_PLANES_STATS>), dim3(kSlots), dim3(TNT), 0, st, a); break;
-        default: GP_REQUIRE(false, "gp_gemm_planes256: unknown epilogue %d", epilogue);
+        default: GP_REQUIRE(false, "gp_gemm_planes256: epilogue %d is not built (product: 3, 6, 7; the others need -DGP_PROBES)", epilogue);
     }
+#undef GP_PLANES_EXTRA
     GP_CHECK_LAUNCH("gp_gemm_planes256");
     return GP_OK;
 }
 
 extern "C" {
-
-int gp_gemm_planes256_ragged(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
-                             void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
-                             const float* residual, int ldr, float out_scale, float* scratch, size_t scratch_bytes, void* stream);
 
 size_t gp_gemm_split256_workspace_bytes(void) { return gp_gemm_split256_scratch_bytes(); }
 
@@ -1763,6 +1380,31 @@ int gp_gemm_split256(const float* act, int ld_act, const void* whi, const void* 
                                    (hipStream_t)stream);
 }
 
+int gp_split_planes(const float* X, size_t count, float scale, void* hi, void* lo, void* stream)
+{
+    GP_REQUIRE(X && hi && lo && count > 0, "gp_split_planes: bad arguments");
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, count, scale,
+                       (_Float16*)hi, (_Float16*)lo);
+    GP_CHECK_LAUNCH("gp_split_planes");
+    return GP_OK;
+}
+
+/* The plane GEMM as a stage entry: D / planes = epi(out_scale * A B^T) on pre-split planes, J_valid <= J rows of B carrying data (tiles +
+ * ragged strip), the output planes of epilogues 6 / 7 carrying the power-of-two plane_scale (8 = the default; the consumer GEMM then runs
+ * with out_scale = 1 / (plane_scale * 64)) and, for calibration passes, a device float that receives max |x| of the planes written. */
+int gp_gemm_planes256_scaled(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
+                             void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
+                             const float* residual, int ldr, float out_scale, float plane_scale, float* amax, float* scratch,
+                             size_t scratch_bytes, void* stream)
+{
+    GP_REQUIRE(scratch && scratch_bytes >= gp_gemm_split256_scratch_bytes(), "gp_gemm_planes256_scaled: scratch too small");
+    if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
+    const GpPlaneOut po{plane_scale, amax};
+    return gp_gemm_planes256_launch(a_hi, a_lo, b_hi, b_lo, D, ldd, out_hi, out_lo, ldo, I, J, J_valid, K, epilogue, bias, scale, residual, ldr,
+                                    out_scale, scratch, (hipStream_t)stream, nullptr, &po);
+}
+
+#ifdef GP_PROBES
 /* probe: proj-shaped launch (act_is_b, no epilogue) with per-phase cycle counters; out6 (host): stage, k16-0 issue,
  * k16-1 issue, MFMA drain, barrier, steps */
 int gp_gemm_split256_timing(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J, int K,
@@ -1778,74 +1420,6 @@ int gp_gemm_split256_timing(const float* act, int ld_act, const void* whi, const
     GP_CHECK_LAUNCH("gp_gemm_split256_timing");
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
     return hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_t256), 6 * sizeof(unsigned long long)) == hipSuccess ? GP_OK : GP_ELAUNCH;
-}
-
-
-int gp_split_planes(const float* X, size_t count, float scale, void* hi, void* lo, void* stream)
-{
-    GP_REQUIRE(X && hi && lo && count > 0, "gp_split_planes: bad arguments");
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, count, scale,
-                       (_Float16*)hi, (_Float16*)lo);
-    GP_CHECK_LAUNCH("gp_split_planes");
-    return GP_OK;
-}
-
-int gp_gemm_planes256(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
-                      void* out_lo, int ldo, int I, int J, int K, int epilogue, const float* bias, const float* scale,
-                      const float* residual, int ldr, float out_scale, float* scratch, size_t scratch_bytes, void* stream)
-{
-    return gp_gemm_planes256_ragged(a_hi, a_lo, b_hi, b_lo, D, ldd, out_hi, out_lo, ldo, I, J, J, K, epilogue, bias, scale, residual, ldr,
-                                    out_scale, scratch, scratch_bytes, stream);
-}
-
-int gp_gemm_planes256_ragged(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
-                             void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
-                             const float* residual, int ldr, float out_scale, float* scratch, size_t scratch_bytes, void* stream)
-{
-    GP_REQUIRE(scratch && scratch_bytes >= gp_gemm_split256_scratch_bytes(), "gp_gemm_planes256: scratch too small");
-    if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
-    return gp_gemm_planes256_launch(a_hi, a_lo, b_hi, b_lo, D, ldd, out_hi, out_lo, ldo, I, J, J_valid, K, epilogue, bias, scale, residual, ldr,
-                                    out_scale, scratch, (hipStream_t)stream, nullptr);
-}
-
-/* gp_gemm_planes256_ragged with the output tensor's plane scale (a power of two; epilogues 6 / 7; the consumer GEMM then runs with
- * out_scale = 1 / (plane_scale * 64)) and, for calibration passes, a device float that receives max |x| of the planes written. */
-int gp_gemm_planes256_scaled(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
-                             void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
-                             const float* residual, int ldr, float out_scale, float plane_scale, float* amax, float* scratch,
-                             size_t scratch_bytes, void* stream)
-{
-    GP_REQUIRE(scratch && scratch_bytes >= gp_gemm_split256_scratch_bytes(), "gp_gemm_planes256_scaled: scratch too small");
-    if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
-    const GpPlaneOut po{plane_scale, amax, 0};
-    return gp_gemm_planes256_launch(a_hi, a_lo, b_hi, b_lo, D, ldd, out_hi, out_lo, ldo, I, J, J_valid, K, epilogue, bias, scale, residual, ldr,
-                                    out_scale, scratch, (hipStream_t)stream, nullptr, &po);
-}
-
-/* gp_gemm_planes256_ragged, epilogue 3 in place (D == residual): D[i][j] += scale_i (out_scale sum_k A B + bias_i) with the K range of
- * every whole tile run as `park` parts, each from a zero accumulator and each folded into D by the tile's own epilogue -- a long K
- * (fc2: 4096) then costs an f32 accumulator K / park products' roundings instead of K's.  park <= 1: gp_gemm_planes256_ragged. */
-int gp_gemm_planes256_park(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, int I, int J, int J_valid,
-                           int K, const float* bias, const float* scale, float out_scale, int park, float* scratch, size_t scratch_bytes,
-                           void* stream)
-{
-    GP_REQUIRE(scratch && scratch_bytes >= gp_gemm_split256_scratch_bytes(), "gp_gemm_planes256_park: scratch too small");
-    if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
-    const GpPlaneOut po{kActScale, nullptr, park};
-    return gp_gemm_planes256_launch(a_hi, a_lo, b_hi, b_lo, D, ldd, nullptr, nullptr, 0, I, J, J_valid, K, XEPI_BIAS_I_SCALE_RES, bias, scale, D, ldd,
-                                    out_scale, scratch, (hipStream_t)stream, nullptr, &po);
-}
-
-int gp_gemm_planes256_ln(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi, void* out_lo,
-                         int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale, const float* residual,
-                         int ldr, float out_scale, const float* ln_main, const float* ln_strip, float* st_main, float* st_strip, int stats_ld,
-                         float ln_eps, float* scratch, size_t scratch_bytes, void* stream)
-{
-    GP_REQUIRE(scratch && scratch_bytes >= gp_gemm_split256_scratch_bytes(), "gp_gemm_planes256_ln: scratch too small");
-    if (hipMemsetAsync(scratch, 0, kHeaderBytes, (hipStream_t)stream) != hipSuccess) return GP_ELAUNCH;
-    const GpLnFold ln{ln_main, ln_strip, st_main, st_strip, stats_ld, ln_eps};
-    return gp_gemm_planes256_launch_ln(a_hi, a_lo, b_hi, b_lo, D, ldd, out_hi, out_lo, ldo, I, J, J_valid, K, epilogue, bias, scale, residual, ldr,
-                                       out_scale, scratch, (hipStream_t)stream, nullptr, &ln);
 }
 
 /* probe: no-epilogue launch with per-phase cycle counters of wave 0 of block 100; out6 (host, 8 entries): matrix phase,
@@ -1866,7 +1440,7 @@ int gp_gemm_planes256_timing(const void* a_hi, const void* a_lo, const void* b_h
     return hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_t256), 8 * sizeof(unsigned long long)) == hipSuccess ? GP_OK : GP_ELAUNCH;
 }
 
-/* probe: the launch of gp_gemm_planes256 (epilogues 0, 3, 6, 7) from a build with time stamps: trace (device,
+/* probe: the launch of gp_gemm_planes256_scaled (epilogues 0, 3, 6, 7, default plane scale) from a build with time stamps: trace (device,
  * 256 x 32 u64) receives per slot: [0] start, [1] segments, then per segment (first 7): kind << 32 | k-steps, start of its
  * k loop (after the accumulator hand-over wait, if any), end of the k loop, end of its epilogue / publish -- 100 MHz ticks */
 int gp_gemm_planes256_trace(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
@@ -1881,7 +1455,7 @@ int gp_gemm_planes256_trace(const void* a_hi, const void* a_lo, const void* b_hi
 
 int gp_gemm_planes256_set_dp(int mode)  // bit 0: data-parallel rounds (default on); bit 1: test hook, head fragments are never published
 {
-    g_planes_dp = mode & 63;  // bits 2..5: probe mask of epilogue 10 (epilogue_res_planes)
+    g_planes_dp = mode & 3;
     return GP_OK;
 }
 
@@ -1907,5 +1481,6 @@ int gp_gemm_split256_error(const float* scratch, void* stream)
         return -1;
     return e;
 }
+#endif  // GP_PROBES
 
 }  // extern "C"

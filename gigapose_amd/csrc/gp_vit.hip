@@ -30,11 +30,6 @@ int gp_gemm_planes256_launch(const void* ahi, const void* alo, const void* bhi, 
                              const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace = nullptr,
                              const GpPlaneOut* po = nullptr);
 
-int gp_gemm_planes256_launch_ln(const void* ahi, const void* alo, const void* bhi, const void* blo, float* D, int ldd, void* ohi,
-                                void* olo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
-                                const float* res, int ldr, float out_scale, float* scratch, hipStream_t st, unsigned long long* trace,
-                                const GpLnFold* ln, const GpPlaneOut* po = nullptr);
-
 namespace {
 
 constexpr int PATCH = 14, IMG = 224, KPE = 588, KPE_PAD = 592, T_TOK = 257;
@@ -331,110 +326,11 @@ __global__ __launch_bounds__(512) void layernorm_planes_reg_kernel(const float* 
     if (amax) gp_record_amax(amax, vmax, 1.0f / plane_scale);
 }
 
-// ---- Folded LayerNorm (gp_split256.hip, epilogues 8-10): entry and exit of the token-major residual stream.
-// Once per forward, after the embedding: X [C][Mpad] (channel-major) -> Xt [Mpad][C] f32, the raw activation planes of x (x 8) for
-// the first q|k|v GEMM, and each token's (sum, sum of squares) over all C channels in BOTH layouts the plane GEMM's epilogues
-// read -- tile rows [C / 256][Mpad][2] and strip rows [C / 32][256][2] -- as partial 0, the other partials zero (the GEMM
-// epilogues of the following layers write one partial per 256- / 32-channel piece).  The thread layout is
-// layernorm_planes_reg_kernel's: 32 tokens x 16 channel slices per block, X read once.
-template <int NK>
-__global__ __launch_bounds__(512) void raw_planes_stats_kernel(const float* __restrict__ X, float* __restrict__ Xt, _Float16* __restrict__ Yhi,
-                                                                _Float16* __restrict__ Ylo, float* __restrict__ st_main, float* __restrict__ st_strip,
-                                                                int Mpad, int strip_j0, int* __restrict__ status)
-{
-    constexpr int C = 128 * NK, TP = 132;
-    __shared__ float red[2][16][32];
-    __shared__ __attribute__((aligned(16))) float tile[2][32 * TP];
-    const int tok = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const size_t tok0 = (size_t)blockIdx.x * 32;
-    float xv[NK][8];
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int k = 0; k < NK; ++k)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            xv[k][e] = X[(size_t)(128 * k + 8 * sl + e) * Mpad + tok0 + tok];
-            s += xv[k][e];
-            q = __builtin_fmaf(xv[k][e], xv[k][e], q);
-        }
-    red[0][sl][tok] = s;
-    red[1][sl][tok] = q;
-    __syncthreads();
-    {   // statistics: thread (sl = partial index p, tok): p = 0 carries the token's totals, every other partial of either layout is zero
-        const size_t j = tok0 + tok;
-        float ts = 0.f, tq = 0.f;
-        if (sl == 0) {
-#pragma unroll
-            for (int u = 0; u < 16; ++u) { ts += red[0][u][tok]; tq += red[1][u][tok]; }
-        }
-        for (int pp = sl; pp < C / 256; pp += 16) {
-            st_main[2 * ((size_t)pp * Mpad + j)] = pp == 0 ? ts : 0.f;
-            st_main[2 * ((size_t)pp * Mpad + j) + 1] = pp == 0 ? tq : 0.f;
-        }
-        if (j >= (size_t)strip_j0 && j < (size_t)strip_j0 + 256)
-            for (int pp = sl; pp < C / 32; pp += 16) {
-                st_strip[2 * ((size_t)pp * 256 + (j - strip_j0))] = pp == 0 ? ts : 0.f;
-                st_strip[2 * ((size_t)pp * 256 + (j - strip_j0)) + 1] = pp == 0 ? tq : 0.f;
-            }
-    }
-    const int g2 = threadIdx.x & 15, t2 = threadIdx.x >> 4;  // store phase: 16 lanes = the 16 eight-channel pieces of token t2
-    const size_t row = (tok0 + t2) * C + 8 * g2;
-    float mx = 0.f;
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        float* T = tile[k & 1];
-        f32x4 w0 = {xv[k][0], xv[k][1], xv[k][2], xv[k][3]}, w1 = {xv[k][4], xv[k][5], xv[k][6], xv[k][7]};
-        *reinterpret_cast<f32x4*>(T + tok * TP + 8 * sl) = w0;
-        *reinterpret_cast<f32x4*>(T + tok * TP + 8 * sl + 4) = w1;
-        __syncthreads();  // one barrier per chunk: the other tile is rewritten only after every thread passed this one
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(T + t2 * TP + 8 * g2), r1 = *reinterpret_cast<const f32x4*>(T + t2 * TP + 8 * g2 + 4);
-        *reinterpret_cast<f32x4*>(Xt + row + 128 * k) = r0;
-        *reinterpret_cast<f32x4*>(Xt + row + 128 * k + 4) = r1;
-        v16x8 h, l;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v = (e < 4 ? r0[e] : r1[e - 4]) * kPlaneScale;   // exact product: hi and lo see the same value
-            const _Float16 hh = (_Float16)v;
-            h[e] = hh;
-            l[e] = (_Float16)(v - (float)hh);
-            mx = __builtin_elementwise_maximum(mx, __builtin_fabsf(v));
-        }
-        *reinterpret_cast<v16x8*>(Yhi + row + 128 * k) = h;
-        *reinterpret_cast<v16x8*>(Ylo + row + 128 * k) = l;
-    }
-    if (!(mx <= kSplitPlaneLimit)) gp_raise(status, GP_ST_SPLIT_RANGE);  // !(<=): a NaN / inf residual stream counts
-}
 
-// Once per forward, after the last block: Xt [Mpad][C] -> X [C][Mpad] (what features_kernel and forward_features read)
-__global__ __launch_bounds__(256) void transpose_tm_to_cm_kernel(const float* __restrict__ Xt, float* __restrict__ X, int C, int Mpad)
-{
-    __shared__ float t[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const size_t j0 = (size_t)blockIdx.x * 32, c0 = (size_t)blockIdx.y * 32;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) t[ty + 8 * u][tx] = Xt[(j0 + ty + 8 * u) * C + c0 + tx];
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; ++u) X[(c0 + ty + 8 * u) * Mpad + j0 + tx] = t[tx][ty + 8 * u];
-}
-
-// LayerNorm folded into its neighbour GEMMs: BUILT, TESTED, OFF by default (gp_vit_set_ln_fold / GIGAPOSE_LN_FOLD=1; 2 = with a
-// ping-pong residual stream).  Measured on MI355X, ViT-L at 64 crops inside a forward (profiles/r04_lnfold_masks.txt): the 48 LayerNorm
-// launches it removes cost 33.9 us each = 1.63 ms; the producer epilogue (proj, fc2: residual + raw planes + statistics) is 34 us
-// longer than the plain residual epilogue -- a wash -- and the consumers (q|k|v, fc1) are 4.6 / 9.5 us longer: 32.4 ms against
-// 32.0 ms per forward.  The LayerNorm kernel moves its 134 MB at 3.9 TB/s on the whole chip; the same bytes in a GEMM's tail are
-// moved while 256 workgroups have nothing else to do.  0 = LayerNorm as its own launches (layernorm_planes_reg_kernel).
-// Whether a forward folds is decided PER CALL by what its caller packed (n_split = 28 * depth: the folded operands are there); this
-// process-wide value is only an A/B override on top of that: -1 (default) = follow the packing, 0 = never fold, 1 = fold in place,
-// 2 = fold with a ping-pong residual stream.  (Until round 5 it was the decision itself, set at pack time: with two models in one
-// process the last one packed decided for both -- ADVICE r4.)
-static int g_ln_fold = -1;
-extern "C" void gp_vit_set_ln_fold(int on) { g_ln_fold = (on >= -1 && on <= 2) ? on : -1; }
-
-static int g_attn_probe = 0;     // A/B hook (gp_vit_set_attn_probe): 1 = key chunk c + 1 staged under the matrix pass over chunk c (measured slower; default 0 = all chunks up front)
-extern "C" void gp_vit_set_attn_probe(int mode) { g_attn_probe = mode; }
 static int g_ln_planes_reg = 1;  // A/B hook (gp_vit_set_ln_reg): 0 = the three-pass kernel, 2 = always the 32-token blocks
+#ifdef GP_PROBES
 extern "C" void gp_vit_set_ln_reg(int on) { g_ln_planes_reg = (on >= 0 && on <= 2) ? on : 1; }
+#endif
 
 int launch_layernorm_planes(const float* X, _Float16* hi, _Float16* lo, const float* g, const float* b, int C, int Mpad, float eps,
                             hipStream_t st, float plane_scale = kPlaneScale, float* amax = nullptr)
@@ -707,7 +603,7 @@ __device__ __forceinline__ float attn_max3(float a, float b, float c)
 
 __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __restrict__ QKVhi, const _Float16* __restrict__ QKVlo,
                                                                _Float16* __restrict__ Ohi, _Float16* __restrict__ Olo, int B, int H,
-                                                               int C, int Mpad, int probe, float inv_s2)
+                                                               int C, int Mpad, float inv_s2)
 {   // inv_s2 = 1 / s^2, s = the power-of-two scale the q | k | v planes carry (1 / 64 for the default x 8); the output planes carry s too
     __shared__ __attribute__((aligned(16))) _Float16 sm[2 * AKEYS * AKS + 2 * 64 * AVS];  // 157,696 bytes
     __shared__ __attribute__((aligned(16))) float xq[64], xs[T_TOK + 3], xred[2][8], xo[8][64];  // the 257th query's VALU path
@@ -726,12 +622,11 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
     // keys = what one pass of the matrix loop below consumes.  K rows go to LDS as they are.  V is transposed on the way: lanes L and
     // L ^ 8 hold keys 2j and 2j + 1 of the same 8 channels -- they swap half of their data so that each writes FOUR dwords (key 2j |
     // key 2j + 1 of one channel row) instead of eight scattered halfwords (8-way bank conflicts, tools/probe_attn_split.py).
-    // Staging is written per chunk so that its order is a run-time choice (gp_vit_set_attn_probe): DEFAULT = every chunk staged before
-    // the first matrix pass; probe & 1 = only chunk 0 up front, chunk c + 1 LOADED (global -> registers) before the pass over chunk c and
-    // WRITTEN to its own LDS region after it (one barrier per chunk).  With ONE workgroup per CU (158 KB of LDS) nothing hides the
-    // up-front staging (25.6 of 105.7 us per launch, profiles/r02_probe_attention_split.txt) -- yet the pipelined order measured 5-9 %
-    // SLOWER in the same binary (97-109 us against 92-100 isolated, profiles/r06_attention.txt): the in-flight loads and the LDS writes
-    // land inside the matrix passes, where the vector / LDS pipes are the busy ones.  Built, measured, off.  The 257th query runs last.
+    // Everything is staged before the first matrix pass.  Round 6 also built the pipelined order -- only chunk 0 up front, chunk c + 1
+    // loaded (global -> registers) before the pass over chunk c and written to its own LDS region after it, one barrier per chunk -- to
+    // hide the 24 % of a launch that staging takes with ONE workgroup per CU: measured 5-9 % SLOWER in the same binary (97-109 us against
+    // 92-100 isolated, profiles/r06_attention.txt: the in-flight loads and LDS writes land inside the matrix passes, where the vector /
+    // LDS pipes are the busy ones) and removed.  The 257th query runs last.
     const int pl = tid >> 8, t8 = tid & 255;
     const _Float16* Ksrc = (pl ? QKVlo : QKVhi) + tok0 * ld + C + h * 64;
     _Float16* sKp = pl ? sKl : sKh;
@@ -769,7 +664,6 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
             }
         }
     };
-    const bool upfront = (probe & 1) == 0;
     load_chunk(0);
     for (int c = tid; c < 2 * (AKEYS - T_TOK - 1) * 8; c += ATH) {  // keys 258..287: zero rows (masked below)
         const int plane = c >= (AKEYS - T_TOK - 1) * 8 ? 1 : 0, r = c - plane * (AKEYS - T_TOK - 1) * 8;
@@ -790,14 +684,10 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
         xq[tid] = (float)QKVhi[q256] + (float)QKVlo[q256];
     }
     store_chunk(0);
-    if (upfront) {
-        load_chunk(1);
-        store_chunk(1);
-        load_chunk(2);
-        store_chunk(2);
-    } else {
-        load_chunk(1);   // in flight under the matrix pass over chunk 0
-    }
+    load_chunk(1);
+    store_chunk(1);
+    load_chunk(2);
+    store_chunk(2);
     __syncthreads();
 
     f32x16 o0, o1;
@@ -905,11 +795,6 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
                     }
                 }
             }
-        if (ch < 2 && !upfront) {   // chunk ch + 1: registers -> its LDS region; chunk ch + 2: global -> registers; then the barrier
-            store_chunk(ch + 1);
-            if (ch == 0) load_chunk(2);
-            __syncthreads();
-        }
     }
     // planes out: 8 * O = acc / l  (acc carries 2^15 p x 8 v, l carries 2^15); lane = (query, half): 4 consecutive channels per r4
     const float sc = 1.0f / (l_part + __shfl_xor(l_part, 32));
@@ -1121,9 +1006,13 @@ __global__ __launch_bounds__(576, 1) void attention_lds_kernel(const float* __re
 // split numerics too (Q | K | V as planes, attention_split_kernel); 1: f32 attention on f32 Q, K, V (bit-identical to 0);
 // 0: f32 activations and the lock-step kernels (kept for A/B runs and the bit-identity test)
 static int g_vit_planes = 2;
+#ifdef GP_PROBES
 extern "C" void gp_vit_set_planes(int mode) { g_vit_planes = (mode >= 0 && mode <= 2) ? mode : 2; }
+#endif
 static int g_attn_nq = 1;  // 0: LDS-shared K/V kernel; 1 / 2: register-resident kernel with 1 / 2 query tiles per wave
+#ifdef GP_PROBES
 extern "C" void gp_attention_set_nq(int nq) { g_attn_nq = (nq >= 0 && nq <= 2) ? nq : 1; }
+#endif
 
 // ---- x_prenorm[:, 1:] -> (B, C, 256), F.normalize over C (ae_net.py:64-69); fixed fmaf order
 __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__ X, float* __restrict__ out,
@@ -1160,7 +1049,6 @@ __global__ __launch_bounds__(256) void features_kernel(const float* __restrict__
 }
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
-inline size_t fold_offset(size_t sk_bytes) { return (sk_bytes + 255) / 256 * 256; }  // the fold buffers start 256-byte aligned behind the scratch
 
 }  // namespace
 
@@ -1180,36 +1068,19 @@ size_t gp_vit_workspace_bytes(int B, int dim, int mlp_dim)
     const size_t pe_need = (size_t)KPE_PAD * B * GP_P + (size_t)dim * B * GP_P;
     if (pe_need > f) f = pe_need;
     // + the stream-K scratch of the GEMMs (gp_gemm.hip), behind the activations
-    // + (folded LayerNorm, plane path) the second residual buffer the token-major stream ping-pongs with and the per-token partial
-    //   statistics: tile rows [dim / 256][Mpad][2], strip rows [dim / 32][256][2]
-    return sizeof(float) * ((size_t)5 * dim * Mpad + f) + fold_offset(gp_gemm_streamk_bytes()) +
-           sizeof(float) * ((size_t)dim * Mpad + (size_t)2 * (dim / 256 + 1) * Mpad + (size_t)2 * (dim / 32 + 1) * 256);
+    return sizeof(float) * ((size_t)5 * dim * Mpad + f) + gp_gemm_streamk_bytes();
 }
 
 // per-layer table of pre-split weight planes (f16 hi / lo, PyTorch-native [out][in]) for the split-f16 mode
 // (entries 10..19, optional: the same five weights as x64 single-accumulator planes for the 256 x 256 kernel of gp_split256.hip)
 enum { S_QK_HI = 0, S_QK_LO, S_V_HI, S_V_LO, S_PROJ_HI, S_PROJ_LO, S_FC1_HI, S_FC1_LO, S_FC2_HI, S_FC2_LO, S_PER_LAYER = 10 };
-// entries 20..27 (optional, n_split = 28 * depth): the folded-LayerNorm operands of the plane path -- x64 planes of W_qkv diag(g1) (3 dim,
-// dim) and W_fc1 diag(g2) (mlp, dim), and per output row s_i = sum_k (W_ik g_k) [of the plane values] and b'_i = b_i + sum_k W_ik be_k (f32)
-enum { S_QKVG_HI = 20, S_QKVG_LO, S_FC1G_HI, S_FC1G_LO, S_QKV_S, S_QKV_BP, S_FC1_S, S_FC1_BP, S_FOLD_STRIDE = 28 };
-
-int gp_vit_forward_split(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
-                         const float* const* weights, int n_weights, const void* const* split, int n_split,
-                         float* workspace, size_t workspace_bytes, float* out_features, int normalize,
-                         int stop_after_layers, void* stream);
 int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                           const float* const* weights, int n_weights, const void* const* split, int n_split,
                           float* workspace, size_t workspace_bytes, float* out_features, int normalize,
-                          int stop_after_layers, const float* plane_scales, float* plane_amax, int fc2_park, void* stream);
+                          int stop_after_layers, const float* plane_scales, float* plane_amax, void* stream);
 
 int gp_attention_split_scaled(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
                               float qkv_scale, void* stream);
-int gp_attention_split(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
-                       void* stream)
-{
-    return gp_attention_split_scaled(qkv_hi, qkv_lo, out_hi, out_lo, B, heads, dim, Mpad, kPlaneScale, stream);
-}
-
 /* q | k | v planes (and the output planes) carry the power-of-two `qkv_scale` instead of the default 8 */
 int gp_attention_split_scaled(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
                               float qkv_scale, void* stream)
@@ -1218,26 +1089,8 @@ int gp_attention_split_scaled(const void* qkv_hi, const void* qkv_lo, void* out_
     GP_REQUIRE(qkv_hi && qkv_lo && out_hi && out_lo && B > 0 && heads > 0 && dim == heads * 64 && Mpad >= B * T_TOK,
                "gp_attention_split: bad arguments");
     hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(ATH), 0, (hipStream_t)stream,
-                       (const _Float16*)qkv_hi, (const _Float16*)qkv_lo, (_Float16*)out_hi, (_Float16*)out_lo, B, heads, dim, Mpad, g_attn_probe, 1.0f / (qkv_scale * qkv_scale));
+                       (const _Float16*)qkv_hi, (const _Float16*)qkv_lo, (_Float16*)out_hi, (_Float16*)out_lo, B, heads, dim, Mpad, 1.0f / (qkv_scale * qkv_scale));
     GP_CHECK_LAUNCH("gp_attention_split");
-    return GP_OK;
-}
-
-/* stage entry (tests): what the folded-LayerNorm plane path runs once per forward after the embedding.  X [C][Mpad] f32 channel-major ->
- * Xt [Mpad][C] f32, raw planes hi / lo [Mpad][C] (x 8), per-token (sum, sum of squares) as partial 0 of the tile layout
- * st_main [C / 256][Mpad][2] and (tokens strip_j0 .. strip_j0 + 255) of the strip layout st_strip [C / 32][256][2], other partials 0. */
-int gp_raw_planes_stats(const float* X, float* Xt, void* out_hi, void* out_lo, float* st_main, float* st_strip, int C, int Mpad, int strip_j0,
-                        void* stream)
-{
-    GP_REQUIRE(X && Xt && out_hi && out_lo && st_main && st_strip && (C == 1024 || C == 768) && Mpad > 0 && Mpad % 32 == 0 && strip_j0 >= 0,
-               "gp_raw_planes_stats: bad arguments (C must be 768 or 1024)");
-    if (C == 1024)
-        hipLaunchKernelGGL(raw_planes_stats_kernel<8>, dim3(Mpad / 32), dim3(512), 0, (hipStream_t)stream, X, Xt, (_Float16*)out_hi, (_Float16*)out_lo,
-                           st_main, st_strip, Mpad, strip_j0, gp_status_buffer());
-    else
-        hipLaunchKernelGGL(raw_planes_stats_kernel<6>, dim3(Mpad / 32), dim3(512), 0, (hipStream_t)stream, X, Xt, (_Float16*)out_hi, (_Float16*)out_lo,
-                           st_main, st_strip, Mpad, strip_j0, gp_status_buffer());
-    GP_CHECK_LAUNCH("gp_raw_planes_stats");
     return GP_OK;
 }
 
@@ -1256,17 +1109,8 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
                    const float* const* weights, int n_weights, float* workspace, size_t workspace_bytes,
                    float* out_features, int normalize, int stop_after_layers, void* stream)
 {
-    return gp_vit_forward_split(images, B, dim, depth, heads, mlp_dim, ln_eps, weights, n_weights, nullptr, 0, workspace,
-                                workspace_bytes, out_features, normalize, stop_after_layers, stream);
-}
-
-int gp_vit_forward_split(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
-                         const float* const* weights, int n_weights, const void* const* split, int n_split,
-                         float* workspace, size_t workspace_bytes, float* out_features, int normalize,
-                         int stop_after_layers, void* stream)
-{
-    return gp_vit_forward_split2(images, B, dim, depth, heads, mlp_dim, ln_eps, weights, n_weights, split, n_split, workspace, workspace_bytes,
-                                 out_features, normalize, stop_after_layers, nullptr, nullptr, 0, stream);
+    return gp_vit_forward_split2(images, B, dim, depth, heads, mlp_dim, ln_eps, weights, n_weights, nullptr, 0, workspace,
+                                 workspace_bytes, out_features, normalize, stop_after_layers, nullptr, nullptr, stream);
 }
 
 /* gp_vit_forward_split with PER-TENSOR plane scales (round 5).  The plane path keeps four activation tensors per layer as f16 hi / lo
@@ -1279,16 +1123,13 @@ int gp_vit_forward_split(const float* images, int B, int dim, int depth, int hea
  *                 (atomic max on the f32 bits; zero it first), from which the host picks the scales (vit.py: calibrate_plane_scales).
  * A smaller scale only moves the f16 subnormal floor of the lo plane up (absolute error 2^-25 / s per element instead of 2^-28); the
  * consumers undo it exactly (out_scale = 1 / (64 s)), so with all scales 8 nothing changes.  Shapes that do not take the plane path
- * (f32 activations, 128 x 128 kernels: range 65504) ignore both arrays.
- *   fc2_park      > 1: fc2's K = mlp_dim runs as that many parts, each folded into the f32 residual stream by the tile's own epilogue
- *                 (gp_split256.hip: PARK) -- 768 roundings of ONE f32 accumulator become 768 / fc2_park; 0 / 1 = one part. */
+ * (f32 activations, 128 x 128 kernels: range 65504) ignore both arrays. */
 int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                           const float* const* weights, int n_weights, const void* const* split, int n_split,
                           float* workspace, size_t workspace_bytes, float* out_features, int normalize,
-                          int stop_after_layers, const float* plane_scales, float* plane_amax, int fc2_park, void* stream)
+                          int stop_after_layers, const float* plane_scales, float* plane_amax, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    GP_REQUIRE(fc2_park >= 0 && fc2_park <= 16, "gp_vit_forward_split2: fc2_park must be in 0..16");
     enum { PS_LN1 = 0, PS_QKV, PS_LN2, PS_GELU, PS_PER_LAYER = 4 };
     bool default_scales = true;
     if (plane_scales)
@@ -1307,11 +1148,9 @@ int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int he
     GP_REQUIRE(images && weights && workspace && out_features, "gp_vit_forward: null pointer");
     GP_REQUIRE(workspace_bytes >= gp_vit_workspace_bytes(B, dim, mlp_dim), "gp_vit_forward: workspace too small");
     for (int i = 0; i < n_weights; ++i) GP_REQUIRE(weights[i], "gp_vit_forward: weight pointer %d is null", i);
-    GP_REQUIRE(split == nullptr || n_split == depth * S_PER_LAYER || n_split == 2 * depth * S_PER_LAYER || n_split == depth * S_FOLD_STRIDE,
-               "gp_vit_forward_split: expected %d (or %d, or %d) split planes, got %d", depth * S_PER_LAYER, 2 * depth * S_PER_LAYER,
-               depth * S_FOLD_STRIDE, n_split);
-    const bool have_fold = split && n_split == depth * S_FOLD_STRIDE;
-    const int sp_stride = have_fold ? S_FOLD_STRIDE : ((split && n_split == 2 * depth * S_PER_LAYER) ? 2 * S_PER_LAYER : S_PER_LAYER);
+    GP_REQUIRE(split == nullptr || n_split == depth * S_PER_LAYER || n_split == 2 * depth * S_PER_LAYER,
+               "gp_vit_forward_split: expected %d (or %d) split planes, got %d", depth * S_PER_LAYER, 2 * depth * S_PER_LAYER, n_split);
+    const int sp_stride = (split && n_split == 2 * depth * S_PER_LAYER) ? 2 * S_PER_LAYER : S_PER_LAYER;
     const bool have_x64 = split && sp_stride >= 2 * S_PER_LAYER;
     if (split) {
         GP_REQUIRE(dim % 32 == 0 && mlp_dim % 32 == 0, "gp_vit_forward_split: dim / mlp_dim must be multiples of 32");
@@ -1352,74 +1191,8 @@ int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int he
     const bool planes = have_x64 && g_vit_planes && gp_gemm_planes256_usable(2 * C, Mpad, Mtok, C) &&
                         gp_gemm_planes256_usable(C, Mpad, Mtok, C) && gp_gemm_planes256_usable(mlp_dim, Mpad, Mtok, C) &&
                         gp_gemm_planes256_usable(C, Mpad, Mtok, mlp_dim) && (g_vit_planes == 2 || gp_gemm_split256_usable(Mpad, C, C));
-    // Plane path with LayerNorm folded into its neighbour GEMMs (gp_split256.hip, epilogues 8-10): per layer q|k|v, attention, proj,
-    // fc1, fc2 -- five launches, no LayerNorm kernel.  The residual stream is token-major f32 and ping-pongs between X2 and X (a
-    // producer epilogue reads one and writes the other: no load waits for a store); its raw planes (what the next GEMM multiplies)
-    // are written by proj into the (dead) q|k|v region and by fc2 into the (dead) attention-output region.
-    const bool fold = planes && have_fold && g_ln_fold != 0 && g_vit_planes == 2 && nl > 0 && C % 256 == 0 && (C == 1024 || C == 768) &&
-                      gp_gemm_planes256_usable(3 * C, Mpad, Mtok, C) && default_scales && !plane_amax;   // the folded epilogues keep the x 8
     GP_REQUIRE(g_vit_planes == 2 || !planes || (default_scales && !plane_amax), "gp_vit_forward_split2: plane scales need the full plane path (gp_vit_set_planes(2))");
-    if (fold) {
-        float* X2 = reinterpret_cast<float*>(reinterpret_cast<char*>(SK) + fold_offset(gp_gemm_streamk_bytes()));
-        float* st_main = X2 + (size_t)C * Mpad;
-        float* st_strip = st_main + (size_t)2 * (C / 256 + 1) * Mpad;
-        _Float16* Hhi = reinterpret_cast<_Float16*>(Hn);
-        _Float16* Hlo = Hhi + (size_t)C * Mpad;
-        _Float16* Ahi = reinterpret_cast<_Float16*>(QK);          // q | k | v planes [Mpad][3C]
-        _Float16* Alo = Ahi + (size_t)3 * C * Mpad;
-        _Float16* Phi = reinterpret_cast<_Float16*>(QK);          // raw residual planes [Mpad][C] written by proj (q | k | v are dead by then)
-        _Float16* Plo = Phi + (size_t)C * Mpad;
-        _Float16* Fhi = reinterpret_cast<_Float16*>(F);
-        _Float16* Flo = Fhi + (size_t)mlp_dim * Mpad;
-        const float os = 1.0f / (8.0f * 64.0f);
-        const int J_main = (Mtok / 256) * 256;
-        GpLnFold ln{st_main, st_strip, st_main, st_strip, Mpad, ln_eps};
-        {
-            GpProfScope prof(GP_PROF_LN, 16.0 * C * Mpad, st);  // reads X, writes Xt + two planes
-            if (C == 1024)
-                hipLaunchKernelGGL(raw_planes_stats_kernel<8>, dim3(Mpad / 32), dim3(512), 0, st, X, X2, Hhi, Hlo, st_main, st_strip, Mpad, J_main, gp_status_buffer());
-            else
-                hipLaunchKernelGGL(raw_planes_stats_kernel<6>, dim3(Mpad / 32), dim3(512), 0, st, X, X2, Hhi, Hlo, st_main, st_strip, Mpad, J_main, gp_status_buffer());
-        }
-        GP_CHECK_LAUNCH("gp_vit_forward/raw_planes_stats");
-        // In place (res == D): a lane writes exactly the 32 bytes it read, and every read of an item is issued before any store that
-        // could alias it (epilogue_res_planes fetches a batch ahead).  A ping-pong between two buffers was measured slower inside a
-        // forward (+20 us per launch: the write-allocate of a second 67 MB stream next to the planes; profiles/r04_lnfold_masks.txt).
-        float* Xa = X2;  // holds the stream
-        float* Xb = g_ln_fold == 2 ? X : X2;  // gp_vit_set_ln_fold(2): the ping-pong variant (A/B)
-        for (int l = 0; l < nl; ++l) {
-            const float* const* w = weights + W_HEADER + l * L_PER_LAYER;
-            const void* const* sf = split + l * sp_stride;
-            const void* const* sq = sf + S_PER_LAYER;
-            // q | k | v = LN1(x) W^T + b as planes: raw planes x (W diag(g1)), statistics in the epilogue
-            if ((rc = gp_gemm_planes256_launch_ln(sf[S_QKVG_HI], sf[S_QKVG_LO], Hhi, Hlo, nullptr, 0, Ahi, Alo, 3 * C, 3 * C, Mpad, Mtok, C,
-                                                  8 /*LN-folded bias -> planes*/, (const float*)sf[S_QKV_BP], (const float*)sf[S_QKV_S], nullptr, 0, os, SK,
-                                                  st, nullptr, &ln)))
-                return rc;
-            {
-                GpProfScope prof(GP_PROF_ATTN, 4.0 * B * heads * 257.0 * 257.0 * 64.0, st);
-                hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(ATH), 0, st, Ahi, Alo, Hhi, Hlo, B, heads, C, Mpad, 0, 1.0f / 64.0f);
-            }
-            GP_CHECK_LAUNCH("gp_vit_forward/attention_split");
-            // x = x + ls1 * proj(attn): token-major f32 + raw planes (into the q | k | v region) + statistics
-            if ((rc = gp_gemm_planes256_launch_ln(sq[S_PROJ_HI], sq[S_PROJ_LO], Hhi, Hlo, Xb, C, Phi, Plo, C, C, Mpad, Mtok, C,
-                                                  10 /*residual + planes + statistics*/, w[L_PROJ_B], w[L_LS1], Xa, C, os, SK, st, nullptr, &ln)))
-                return rc;
-            // gelu(fc1(LN2(x))) as planes
-            if ((rc = gp_gemm_planes256_launch_ln(sf[S_FC1G_HI], sf[S_FC1G_LO], Phi, Plo, nullptr, 0, Fhi, Flo, mlp_dim, mlp_dim, Mpad, Mtok, C,
-                                                  9 /*LN-folded GELU -> planes*/, (const float*)sf[S_FC1_BP], (const float*)sf[S_FC1_S], nullptr, 0, os, SK,
-                                                  st, nullptr, &ln)))
-                return rc;
-            // x = x + ls2 * fc2(.): back into the first buffer, raw planes into the attention-output region
-            if ((rc = gp_gemm_planes256_launch_ln(sq[S_FC2_HI], sq[S_FC2_LO], Fhi, Flo, Xa, C, Hhi, Hlo, C, C, Mpad, Mtok, mlp_dim,
-                                                  10, w[L_FC2_B], w[L_LS2], Xb, C, os, SK, st, nullptr, &ln)))
-                return rc;
-        }
-        // back to the channel-major layout the feature epilogue (and forward_features) read
-        hipLaunchKernelGGL(transpose_tm_to_cm_kernel, dim3(Mpad / 32, C / 32), dim3(256), 0, st, Xa, X, C, Mpad);
-        GP_CHECK_LAUNCH("gp_vit_forward/transpose");
-    }
-    if (planes && !fold) {
+    if (planes) {
         _Float16* Hhi = reinterpret_cast<_Float16*>(Hn);
         _Float16* Hlo = Hhi + (size_t)C * Mpad;
         _Float16* Fhi = reinterpret_cast<_Float16*>(F);
@@ -1434,8 +1207,7 @@ int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int he
             const float os = 1.0f / (kPlaneScale * 64.0f);  // g_vit_planes == 1 (probe path): activations x 8, weights x 64
             const float os_ln1 = 1.0f / (ps[PS_LN1] * 64.0f), os_qkv = 1.0f / (ps[PS_QKV] * 64.0f), os_ln2 = 1.0f / (ps[PS_LN2] * 64.0f),
                         os_gelu = 1.0f / (ps[PS_GELU] * 64.0f);   // a consumer undoes its B operand's scale and the weights' x 64, exactly
-            const GpPlaneOut po_qkv{ps[PS_QKV], am ? am + PS_QKV : nullptr, 0}, po_gelu{ps[PS_GELU], am ? am + PS_GELU : nullptr, 0};
-            const GpPlaneOut po_fc2{kPlaneScale, nullptr, fc2_park};   // fc2 (K = mlp_dim): K in fc2_park parts (gp_split256.hip: PARK; 0 / 1 = off)
+            const GpPlaneOut po_qkv{ps[PS_QKV], am ? am + PS_QKV : nullptr}, po_gelu{ps[PS_GELU], am ? am + PS_GELU : nullptr};
             launch_layernorm_planes(X, Hhi, Hlo, w[L_LN1_G], w[L_LN1_B], C, Mpad, ln_eps, st, ps[PS_LN1], am ? am + PS_LN1 : nullptr);
             GP_CHECK_LAUNCH("gp_vit_forward/layernorm_planes");
             if (g_vit_planes == 2) {
@@ -1462,7 +1234,7 @@ int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int he
                 {
                     GpProfScope prof(GP_PROF_ATTN, 4.0 * B * heads * 257.0 * 257.0 * 64.0, st);
                     hipLaunchKernelGGL(attention_split_kernel, dim3(xcd_chunked_grid(B * heads)), dim3(ATH), 0, st, Ahi, Alo, Hhi, Hlo, B,
-                                       heads, C, Mpad, 0, 1.0f / (ps[PS_QKV] * ps[PS_QKV]));
+                                       heads, C, Mpad, 1.0f / (ps[PS_QKV] * ps[PS_QKV]));
                 }
                 GP_CHECK_LAUNCH("gp_vit_forward/attention_split");
             } else {
@@ -1493,7 +1265,7 @@ int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int he
                 return rc;
             // x = x + ls2 * fc2(.)
             if ((rc = gp_gemm_planes256_launch(sq[S_FC2_HI], sq[S_FC2_LO], Fhi, Flo, X, Mpad, nullptr, nullptr, 0, C, Mpad, Mtok, mlp_dim,
-                                               3 /*BIAS_I_SCALE_RES*/, w[L_FC2_B], w[L_LS2], X, Mpad, os_gelu, SK, st, nullptr, &po_fc2)))
+                                               3 /*BIAS_I_SCALE_RES*/, w[L_FC2_B], w[L_LS2], X, Mpad, os_gelu, SK, st)))
                 return rc;
         }
     }

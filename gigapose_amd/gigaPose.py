@@ -170,12 +170,12 @@ class GigaPose(_Base):
         vit = getattr(self.ae_net, "dinov2_model", None)
         if bits & 4 and vit is not None and getattr(vit, "numerics", None) == "split" and getattr(vit, "split_gemm", "128") != "128":
             vit.set_split_gemm("128")
-            changed.append("ViT linear layers -> 128 x 128 two-accumulator kernels (GIGAPOSE_SPLIT_GEMM=128)")
+            changed.append("ViT linear layers -> 128 x 128 two-accumulator kernels (Dinov2ViT.set_split_gemm('128'))")
         ist = getattr(self.ist_net, "backbone", None)
         if bits & 16 and ist is not None and getattr(ist, "numerics", None) == "split" and getattr(ist, "conv_kernel", "128") != "128":
             ist.conv_kernel = "128"
             ist.invalidate()
-            changed.append("IST convolutions -> 128 x 128 two-accumulator kernel (GIGAPOSE_SPLIT_CONV=128)")
+            changed.append("IST convolutions -> 128 x 128 two-accumulator kernel (ResNet.conv_kernel = '128')")
         if changed:
             warnings.warn("split numerics: an activation left the range of the f16 planes (|x| >= 8190); falling back for this model: "
                           + "; ".join(changed) + ".  Template banks are rebuilt.", RuntimeWarning)

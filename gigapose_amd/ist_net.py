@@ -66,7 +66,7 @@ class ResNet(nn.Module):
         self.numerics = _lib.default_numerics()  # "split" (default) | "chain" 
         # split numerics: "256" = conv_planes_kernel (gp_conv256.hip: 256-pixel tiles, single accumulator, plane GEMM loop;
         # needs B*OH*OW % 256 == 0, always true from the 16 x 16 output grid up); "128" = the first-generation 128 x 128 kernel
-        self.conv_kernel = os.environ.get("GIGAPOSE_SPLIT_CONV", "256")
+        self.conv_kernel = "256"
 
     def set_numerics(self, mode):
         if mode not in ("chain", "split"):
@@ -161,8 +161,6 @@ class ResNet(nn.Module):
         need = lib.gp_conv2d_planes_workspace_bytes()
         if self._conv_scratch is None or self._conv_scratch.device != dev:
             self._conv_scratch = torch.zeros((need + 3) // 4, dtype=torch.float32, device=dev)
-        if "GIGAPOSE_CONV_HALO" in os.environ:   # A/B probe: 0 = every convolution through the per-tap gather kernel
-            lib.gp_conv2d_planes_set_halo(int(os.environ["GIGAPOSE_CONV_HALO"]))
         _lib.call("gp_conv2d_planes", _lib.ptr(x[0]), _lib.ptr(x[1]), _lib.ptr(w[0]), _lib.ptr(w[1]),
                   _lib.ptr(cv["alpha"]), _lib.ptr(cv["beta"]), _lib.ptr(None if residual is None else residual[0]),
                   _lib.ptr(None if residual is None else residual[1]), _lib.i(B), _lib.i(H), _lib.i(W), _lib.i(cv["cin"]),

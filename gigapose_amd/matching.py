@@ -33,6 +33,12 @@ def patch_grid_mask(mask224):
 default_numerics = _lib.default_numerics   # "split" unless GIGAPOSE_NUMERICS=chain (the verification mode)
 
 
+def _l2norm_split(x, hi, lo, rows, C):
+    """gp_l2norm_split_mask without a mask image: the split normalisation alone."""
+    _lib.call("gp_l2norm_split_mask", _lib.ptr(x), _lib.ptr(hi), _lib.ptr(lo), _lib.i(rows), _lib.i(C), _lib.ptr(None), _lib.i(0), _lib.i(0),
+              _lib.ptr(None), _lib.stream_ptr())
+
+
 def normalize_split(feats, mask224=None):
     """(rows, C, 256) f32 -> matcher-normalised, x32, split into f16 planes (hi, lo), each (rows, 256, Cp) with
     Cp = round_up(C, 32) (zero padded: the split matcher consumes 32 channels per step).  With mask224 (rows, H, W) f32 the same
@@ -42,12 +48,12 @@ def normalize_split(feats, mask224=None):
     hi = torch.empty(rows, P, (C + 31) // 32 * 32, dtype=torch.float16, device=x.device)
     lo = torch.empty_like(hi)
     if mask224 is None:
-        _lib.call("gp_l2norm_split", _lib.ptr(x), _lib.ptr(hi), _lib.ptr(lo), _lib.i(rows), _lib.i(C), _lib.stream_ptr())
+        _l2norm_split(x, hi, lo, rows, C)
         return hi, lo
     fused = (mask224.dtype == torch.float32 and mask224.is_contiguous() and mask224.dim() == 3 and mask224.shape[0] == rows
              and mask224.shape[1] % 16 == 0 and mask224.shape[2] % 16 == 0)
     if not fused:   # another dtype / layout: the strided copy
-        _lib.call("gp_l2norm_split", _lib.ptr(x), _lib.ptr(hi), _lib.ptr(lo), _lib.i(rows), _lib.i(C), _lib.stream_ptr())
+        _l2norm_split(x, hi, lo, rows, C)
         return hi, lo, patch_grid_mask(mask224)
     qmask = torch.empty(rows, P, dtype=torch.float32, device=x.device)
     _lib.call("gp_l2norm_split_mask", _lib.ptr(x), _lib.ptr(hi), _lib.ptr(lo), _lib.i(rows), _lib.i(C), _lib.ptr(mask224),
@@ -132,8 +138,6 @@ class LocalSimilarity(torch.nn.Module):
         avg = torch.empty(B, N, dtype=torch.float32, device=dev)
         direction = 1 if (search_direction or self.search_direction) == "src2tar" else 0   # reference matching.py:239-244
         if split:
-            if "GIGAPOSE_MATCH_COMPACT" in os.environ:   # A/B probe: 0 = full 256 x 256 tiles (masked-out patches computed as zeros)
-                _lib.lib().gp_match_split_set_compact(int(os.environ["GIGAPOSE_MATCH_COMPACT"]))
             _lib.call("gp_match_tiles_split_dir", _lib.ptr(query[0]), _lib.ptr(query[1]), _lib.ptr(bank.hi), _lib.ptr(bank.lo),
                       _lib.ptr(qmask), _lib.ptr(bank.masks), _lib.ptr(labels0), _lib.i(B), _lib.i(bank.O), _lib.i(N),
                       _lib.i(C), _lib.f(self.sim_threshold), _lib.f(self.patch_threshold), _lib.i(direction), _lib.ptr(idx),

@@ -86,10 +86,7 @@ class Dinov2ViT(nn.Module):
         # split numerics: "256" = single-accumulator plane kernels (activations x 8 in f16 planes: |x| < 8190, guarded);
         # "128" = every GEMM on the two-accumulator 128 x 128 kernel (range 65504, slower).  GigaPose switches to "128" by itself
         # when the range guard trips (gigaPose.py: _widen_split_range) -- DINOv2 checkpoints are known for a few massive activations
-        self.split_gemm = os.environ.get("GIGAPOSE_SPLIT_GEMM", "256")
-        # LayerNorm folded into the neighbouring plane GEMMs (gp_split256.hip, epilogues 8-10): built and tested, measured 1 % slower
-        # than the LayerNorm launches it removes (csrc/gp_vit.hip: g_ln_fold) -- off unless GIGAPOSE_LN_FOLD=1 (2: ping-pong stream)
-        self.ln_fold = int(os.environ.get("GIGAPOSE_LN_FOLD", "0"))
+        self.split_gemm = "256"
         # Per-tensor plane scales of the split plane path (gp_vit_forward_split2; round 5).  Four activation tensors per layer travel as
         # f16 hi / lo planes of s x -- LayerNorm-1 out, q|k|v (+ attention out), LayerNorm-2 out, GELU out -- with s a power of two
         # <= 8 chosen per (layer, tensor) from a calibration pass over real inputs (GigaPose onboarding: the templates) so that
@@ -98,11 +95,7 @@ class Dinov2ViT(nn.Module):
         # single-accumulator 256 x 256 kernels (the old remedy moved the WHOLE ViT to the 128 x 128 kernels: -43 %).
         self.plane_scales = None      # list of depth * 4 floats, or None
         self.plane_amax = None        # running max |x| per (layer, tensor) over every calibration pass: numpy (depth, 4)
-        self.plane_headroom = float(os.environ.get("GIGAPOSE_PLANE_HEADROOM", "4"))
-        # fc2 (K = 4 dim) accumulated in parts, each folded into the f32 residual stream (gp_split256.hip: PARK): the single f32
-        # accumulator of the plane GEMM sees K / fc2_park products' roundings instead of K's (the one stage of
-        # the plane path measurably worse than a blocked CPU GEMM).  0 / 1 = off.  GIGAPOSE_FC2_PARK.
-        self.fc2_park = int(os.environ.get("GIGAPOSE_FC2_PARK", "0"))
+        self.plane_headroom = 4.0
 
     def set_split_gemm(self, mode):
         if mode not in ("256", "128"):
@@ -247,35 +240,7 @@ class Dinov2ViT(nn.Module):
                     split += [qkv_hi[:2 * C], qkv_lo[:2 * C], qkv_hi[2 * C:], qkv_lo[2 * C:]]
                     for w in ws[2:]:
                         split += list(split_planes_x64(w))
-                    # entries 20..27: LayerNorm folded into q|k|v and fc1 (gp_split256.hip, epilogues 8-10): the GEMM multiplies the RAW
-                    # residual planes with W diag(gamma); its epilogue applies r_j (acc - mu_j s_i) + b'_i with s_i = sum_k (W gamma)_ik --
-                    # summed over the VALUES THE PLANES HOLD, so that the mean's contribution cancels against exactly what the matrix
-                    # core accumulated -- and b'_i = b_i + sum_k W_ik beta_k (both in float64, stored f32)
-                    for lin, norm in ((blk.attn.qkv, blk.norm1), (blk.mlp.fc1, blk.norm2)) if self.ln_fold else ():
-                        w64 = lin.weight.detach().to(device).double()
-                        g, be = norm.weight.detach().to(device).float(), norm.bias.detach().to(device).double()
-                        hi, lo = split_planes_x64(lin.weight.detach().to(device).float() * g[None, :])
-                        fold_planes = [hi, lo]
-                        s_i = ((hi.double() + lo.double()).sum(dim=1) / 64.0).float().contiguous()
-                        b_p = (lin.bias.detach().to(device).double() + w64 @ be).float().contiguous()
-                        split += fold_planes
-                        if lin is blk.attn.qkv:
-                            pend = [s_i, b_p]
-                        else:
-                            split += pend + [s_i, b_p]
             split_table = (ctypes.c_void_p * len(split))(*[t.data_ptr() for t in split])
-            if "GIGAPOSE_VIT_PLANES" in os.environ:  # A/B probes (csrc/gp_vit.hip): 0 f32 activations, 1 f32 attention, 2 default
-                _lib.lib().gp_vit_set_planes(int(os.environ["GIGAPOSE_VIT_PLANES"]))
-            if "GIGAPOSE_PLANES_PAR" in os.environ:  # A/B probe: 0 = fewer tiles than slots (B < 64 at ViT-L) -> 128 x 128 kernels; n >= 2: >= n k-steps per slot of a split tile
-                _lib.lib().gp_gemm_planes256_set_par(int(os.environ["GIGAPOSE_PLANES_PAR"]))
-            if "GIGAPOSE_PLANES_HALF" in os.environ:  # A/B probe: 0 = no 256 x 128 tiles below half a tile per slot
-                _lib.lib().gp_gemm_planes256_set_half_tiles(int(os.environ["GIGAPOSE_PLANES_HALF"]))
-            if "GIGAPOSE_LN_REG" in os.environ:      # A/B probe: 2 = LayerNorm always in 32-token blocks (default: 16-token blocks up to 128 blocks), 0 = the three-pass kernel
-                _lib.lib().gp_vit_set_ln_reg(int(os.environ["GIGAPOSE_LN_REG"]))
-            if "GIGAPOSE_PLANES_DP" in os.environ:   # A/B probe: 0 = every plane-GEMM tile cut stream-K style
-                _lib.lib().gp_gemm_planes256_set_dp(int(os.environ["GIGAPOSE_PLANES_DP"]))
-            if self.ln_fold == 2:   # A/B probe of the ping-pong residual stream; folding itself follows the packing (n_split = 28 per
-                _lib.lib().gp_vit_set_ln_fold(2)   # layer), per call: two models in one process no longer decide for each other
         self._packed = (device, tensors, table, split, split_table)
 
     def _workspace(self, B, device):
@@ -392,8 +357,7 @@ class Dinov2ViT(nn.Module):
         _lib.call("gp_vit_forward_split2", _lib.ptr(x), _lib.i(B), _lib.i(self.dim), _lib.i(self.depth),
                   _lib.i(self.heads), _lib.i(self.mlp_dim), _lib.f(1e-6), table, _lib.i(len(tensors)),
                   split_table, _lib.i(len(split)), _lib.ptr(ws), ctypes.c_size_t(need), _lib.ptr(out),
-                  _lib.i(1 if normalize else 0), _lib.i(stop_after_layers), scales, _lib.ptr(plane_amax), _lib.i(self.fc2_park),
-                  _lib.stream_ptr())
+                  _lib.i(1 if normalize else 0), _lib.i(stop_after_layers), scales, _lib.ptr(plane_amax), _lib.stream_ptr())
         return out
 
     @torch.no_grad()

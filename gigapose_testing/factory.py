@@ -8,12 +8,13 @@ import types
 import numpy as np
 import torch
 
+from gigapose_amd.ae_net import AENet
+from gigapose_amd.gigaPose import GigaPose
+from gigapose_amd.ist_net import ISTNet, Regressor, ResNet
+from gigapose_amd.matching import LocalSimilarity
+from gigapose_amd.vit import VARIANTS, Dinov2ViT
+
 from . import synthetic as syn
-from .ae_net import AENet
-from .gigaPose import GigaPose
-from .ist_net import ISTNet, Regressor, ResNet
-from .matching import LocalSimilarity
-from .vit import VARIANTS, Dinov2ViT
 
 IST_CFG = dict(n_heads=0, input_dim=3, input_size=256, initial_dim=128, block_dims=[128, 192, 256, 512],
                descriptor_size=256)

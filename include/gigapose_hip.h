@@ -11,6 +11,9 @@
  *     asserts at the same places, cited per function);
  *   - tensors are dense, row-major in the order written, f32 unless stated otherwise;
  *   - P = 256 patches (16x16 grid of 14-px patches on a 224x224 crop).
+ * This header is the PRODUCT interface: what gigapose_amd/*.py, bench.py and a host integration call.  A/B switches, time-stamped probe
+ * builds, test-only epilogues and error-word readers live in gigapose_hip_probe.h and exist only in libgigapose_hip_probe.so (the same
+ * sources compiled with -DGP_PROBES; tests and tools/ load it where they need a hook).
  */
 #ifndef GIGAPOSE_HIP_H
 #define GIGAPOSE_HIP_H
@@ -26,8 +29,10 @@ const char* gp_last_error(void);
 /* Guard rails: conditions that the reference turns into Python exceptions (IndexError at `ae_features[label - 1]`,
  * gigaPose.py:520) or that have no counterpart there (a lost stream-K accumulator hand-over; an activation outside the
  * range of the split-f16 planes, |x| >= 8190 or non-finite) are OR-ed by the kernels into ONE device int32 owned by the
- * caller.  The host reads it at its next synchronisation point (gigapose_amd/_lib.py: check_status) and raises.
- * device_word == NULL switches the reporting off.  Bits: */
+ * caller PER DEVICE.  The host reads it at its next synchronisation point (gigapose_amd/_lib.py: check_status) and raises.
+ * gp_set_status_buffer registers the word of the CURRENT HIP device (hipGetDevice) in a per-device table; every launch takes the word of
+ * the device it is issued on, so several GPUs driven from one process (or from several threads) never share or re-point a word.
+ * device_word == NULL switches the reporting off for that device.  Bits: */
 #define GP_STATUS_HANDOFF_SPLIT 1 /* split GEMM: a hand-over timed out, the tile it fed is garbage */
 #define GP_STATUS_HANDOFF_CHAIN 2 /* f32 (chain) GEMM: same */
 #define GP_STATUS_SPLIT_RANGE 4   /* split numerics: plane value out of range / NaN (use numerics "chain" or GIGAPOSE_SPLIT_GEMM=128) */
@@ -40,11 +45,10 @@ int gp_set_status_buffer(int* device_word);
  * roofline figure; not part of the reference interface).  gp_prof_begin() starts recording;
  * gp_prof_end() stops, synchronises and returns per-kind totals: ms[k], work[k] (flops, or bytes for
  * layernorm), launches[k]; its return value is the number of kinds; names via gp_prof_kind_name(). */
-void gp_prof_begin(void);
-/* Light instrumentation for a timed region: events only around every `stride`-th launch of ONE kernel family (an event pair per launch
- * costs ~3 us of queue time: 1.4 ms on a 46 ms step when all ~210 launches are bracketed).  Choose a stride coprime with the
- * family's launches per layer so that the sample cycles through its shapes. */
-void gp_prof_begin_sampled(int kind, int stride);
+/* kind < 0: every launch of every family.  kind >= 0: light instrumentation for a timed region -- events only around every `stride`-th
+ * launch of THAT kernel family (an event pair per launch costs ~3 us of queue time: 1.4 ms on a 46 ms step when all ~210 launches are
+ * bracketed); choose a stride coprime with the family's launches per layer so that the sample cycles through its shapes. */
+void gp_prof_begin(int kind, int stride);
 int gp_prof_end(int max_kinds, double* ms, double* work, long long* launches);
 const char* gp_prof_kind_name(int kind);
 
@@ -82,14 +86,9 @@ int gp_l2norm_cp(const float* x, float* out, int rows, int C, void* stream);
  *                                    matching.py:222,227)
  *   labels (B) int32: 0-based object index per detection (reference: label-1, gigaPose.py:520)
  * outputs: idx_t2s u8 (B,N,256), score_t2s (B,N,256), mask_all (B,N,256), sim_avg (B,N).
- * Requires C % 16 == 0. */
-int gp_match_tiles(const float* query, const float* bank, const float* qmask, const float* bmask,
-                   const int* labels, int B, int O, int N, int C, float sim_threshold,
-                   float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
-                   float* sim_avg, void* stream);
-
-/* The same launch with the reference's `search_direction` ctor argument (matching.py:18, :239-244): 0 = "tar2src" (default:
- * gp_match_tiles), 1 = "src2tar" (the row / column argmax pairs exchange roles; masks stay positional as in the reference).
+ * Requires C % 16 == 0.
+ * search_direction = the reference's ctor argument (matching.py:18, :239-244): 0 = "tar2src" (its default), 1 = "src2tar" (the row /
+ * column argmax pairs exchange roles; masks stay positional as in the reference).
  * patch_threshold <= 0 in any of the match entry points = no cycle check (matching.py:256-257: mask_cycle = ones). */
 int gp_match_tiles_dir(const float* query, const float* bank, const float* qmask, const float* bmask,
                        const int* labels, int B, int O, int N, int C, float sim_threshold,
@@ -102,30 +101,17 @@ int gp_match_tiles_dir(const float* query, const float* bank, const float* qmask
  * (rows, 256, Cp), Cp = round_up(C, 32), zero padded (value ~= (hi + lo) / 32).
  * gp_match_tiles_split: query planes (B,256,Cp), bank planes (O,N,256,Cp); C here = Cp; everything else as
  * gp_match_tiles. */
-int gp_l2norm_split(const float* x, void* hi, void* lo, int rows, int C, void* stream);
-/* + in the same launch the rows' 16 x 16 patch masks: patch_mask (rows, 256) f32 = mask_img (rows, mask_h, mask_w) f32 sampled at pixel
- * (i mask_h / 16, j mask_w / 16) = F.interpolate(mask, (16, 16)) nearest (matching.py:222, 227); patch_mask NULL = gp_l2norm_split. */
+/* gp_l2norm_split_mask: the split normalisation and, in the same launch, the rows' 16 x 16 patch masks: patch_mask (rows, 256) f32 =
+ * mask_img (rows, mask_h, mask_w) f32 sampled at pixel (i mask_h / 16, j mask_w / 16) = F.interpolate(mask, (16, 16)) nearest
+ * (matching.py:222, 227); mask_img = patch_mask = NULL: the normalisation alone. */
 int gp_l2norm_split_mask(const float* x, void* hi, void* lo, int rows, int C, const float* mask_img, int mask_h, int mask_w,
                          float* patch_mask, void* stream);
-int gp_match_tiles_split(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
-                         const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
-                         float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
-                         void* stream);
 int gp_match_tiles_split_dir(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
                              const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
                              float patch_threshold, int search_direction, uint8_t* idx_t2s, float* score_t2s, float* mask_all,
                              float* sim_avg, void* stream);
-/* probe build of gp_match_tiles_split (two-plane bank) writing 8 time stamps per tile, see gp_match.hip */
-int gp_match_tiles_split_trace(const void* q_hi, const void* q_lo, const void* b_hi, const void* b_lo, const float* qmask,
-                         const float* bmask, const int* labels, int B, int O, int N, int C, float sim_threshold,
-                         float patch_threshold, uint8_t* idx_t2s, float* score_t2s, float* mask_all, float* sim_avg,
-                         unsigned long long* trace, void* stream);
-
 /* torch.topk(sim_avg, k, dim=1) (matching.py:279); ties: lower template index first.
  * Fails (-1) when k > N, like torch.topk raises. ids int32 (B,k), scores (B,k). */
-/* A/B hook of gp_match_tiles_split: 1 (default) = tiles are built from the live (mask != 0) patches only, block-cyclically dealt
- * to the waves, 1..2 x 1..4 matrix tiles per wave; 0 = every patch counts as live (the full 2 x 4).  Outputs are bit-identical. */
-int gp_match_split_set_compact(int on);
 int gp_topk(const float* sim_avg, int B, int N, int k, int* ids, float* scores, void* stream);
 
 /* Gather the per-patch records of the selected templates (matching.py:282-285):
@@ -154,9 +140,6 @@ int gp_select_topk(const float* sim_avg, const uint8_t* idx_t2s, const float* sc
  * epilogue: 0 none | 1 +bias[i] | 2 gelu_erf(+bias[i]) | 3 residual[i][j] + scale[i]*(acc+bias[i])
  *           (D may alias residual) | 4 +bias[j] | 5 relu(+bias[i]).
  * Requires I % 128 == 0, J % 128 == 0, K % 16 == 0, lda/ldb % 4 == 0, 16-byte aligned A/B. */
-void gp_gemm_set_streamk(int mode); /* test hook: 0 = one workgroup per tile even with a scratch, 1 = by the built-in rule
-                                      (default), 2 = split whenever the tile count allows (results identical) */
-void gp_gemm_set_group(int g);    /* tuning hook: tiles are ordered in bands of g i-tiles (default 8; results identical) */
 int gp_gemm_kmajor(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J,
                    int K, int epilogue, const float* bias, const float* scale, const float* residual,
                    int ldr, void* stream);
@@ -165,12 +148,10 @@ int gp_gemm_kmajor(const float* A, int lda, const float* B, int ldb, float* D, i
  * of the resident workgroups ("chain-preserving stream-K", gp_gemm.hip): a tile split between two workgroups
  * is handed over as an accumulator fragment, so the per-output fmaf chain -- and every output bit -- is the
  * same as gp_gemm_kmajor's.  scratch: gp_gemm_streamk_workspace_bytes() bytes, 16-byte aligned, one per
- * stream; call gp_gemm_streamk_reset() on it once before first use (zeroes the hand-off flags).
- * gp_gemm_streamk_error() synchronises the stream and returns the scratch's error word (0 = every hand-off
- * arrived; test hook). */
+ * stream; call gp_gemm_streamk_reset() on it once before first use (zeroes the hand-off flags).  A hand-over that never
+ * arrives raises GP_STATUS_HANDOFF_CHAIN in the status word. */
 size_t gp_gemm_streamk_workspace_bytes(void);
 int gp_gemm_streamk_reset(float* scratch, void* stream);
-int gp_gemm_streamk_error(const float* scratch, void* stream);
 int gp_gemm_kmajor_sk(const float* A, int lda, const float* B, int ldb, float* D, int ldd, int I, int J,
                       int K, int epilogue, const float* bias, const float* scale, const float* residual,
                       int ldr, float* scratch, size_t scratch_bytes, void* stream);
@@ -210,133 +191,67 @@ int gp_vit_forward(const float* images, int B, int dim, int depth, int heads, in
                    const float* const* weights, int n_weights, float* workspace, size_t workspace_bytes,
                    float* out_features, int normalize, int stop_after_layers, void* stream);
 
-void gp_attention_set_nq(int nq); /* tuning / test hook: 1 (default) / 2 = register-resident kernel with 1 / 2 query tiles
-                                     per wave; 0 = K/V shared through LDS (results identical) */
-
 /* Second-generation split GEMM (gp_split256.hip): 256 x 256 tiles, ONE accumulator on operands pre-scaled by powers
  * of two (activations x 8 while staging, weights x 64 in the planes made by gp_split256_weights: hi = f16(64 w),
  * lo = f16(64 w - hi)), work balanced by stream-K with deterministic accumulator hand-offs.  Same arguments as
  * gp_gemm_split plus a device scratch of gp_gemm_split256_workspace_bytes() bytes (one per stream); requires
- * I, J % 256 == 0, K % 32 == 0, (I/256)*(J/256) >= 256, |activation| < 8190.  gp_gemm_split256_error: scratch error
- * word (0 = every hand-off arrived). */
+ * I, J % 256 == 0, K % 32 == 0, (I/256)*(J/256) >= 256, |activation| < 8190; epilogues 1-4 (0 and 5 in the probe library).  A lost
+ * hand-over raises GP_STATUS_HANDOFF_SPLIT in the status word. */
 size_t gp_gemm_split256_workspace_bytes(void);
 int gp_split256_weights(const float* W, size_t count, void* hi, void* lo, void* stream);
 int gp_gemm_split256(const float* act, int ld_act, const void* whi, const void* wlo, float* D, int ldd, int I, int J, int K,
                      int act_is_b, int epilogue, const float* bias, const float* scale, const float* residual, int ldr,
                      float* scratch, size_t scratch_bytes, void* stream);
-int gp_gemm_split256_error(const float* scratch, void* stream);
 
-/* Third generation (gp_split256.hip, gemm_planes256_kernel): BOTH operands as pre-split f16 planes, A [I][K] and
- * B [J][K] (k contiguous; gp_split_planes makes them: hi = f16(scale x), lo = f16(scale x - hi); weights use scale 64,
- * activations 8), the two wave groups of a workgroup running half a k-step apart (one issues MFMAs while the other
- * stages).  D[i][j] = epi(out_scale * sum_k A[i][k] B[j][k]), out_scale = 1 / (scale_a * scale_b); epilogues 0-5 as
- * gp_gemm_split (f32 D, ldd); 6 = bias along i + GELU, 7 = bias along i, both written as activation planes
- * out_hi/out_lo[j][i] (x 8, row stride ldo) for the next kernel.  Same shape rules, scratch and error word as gp_gemm_split256; results bit-identical
- * to it. */
+/* Third generation (gp_split256.hip, gemm_planes256_kernel): BOTH operands as pre-split f16 planes, A [I][K] and B [J][K] (k contiguous;
+ * gp_split_planes makes them: hi = f16(scale x), lo = f16(scale x - hi); weights use scale 64, activations a power of two s, 8 by
+ * default), the two wave groups of a workgroup running half a k-step apart (one issues MFMAs while the other stages).
+ *   D[i][j] = epi(out_scale * sum_k A[i][k] B[j][k]),  out_scale = 1 / (scale_a * scale_b);
+ *   epilogue 3 = residual[i][j] + scale[i] * (acc + bias[i]) as f32 D (ldd; D may alias residual); 6 = bias along i + GELU, 7 = bias
+ *   along i, both written as activation planes out_hi / out_lo [j][i] (x plane_scale, row stride ldo) for the next kernel; the probe
+ *   library adds the plain f32 epilogues 0, 1, 2, 4, 5.
+ * Ragged J (257 tokens per crop are never a multiple of 256): only rows < J_valid of B carry data (J, the padded row count of the
+ * buffers, stays a multiple of 256).  The 256 x 256 tiles cover floor(J_valid / 256) * 256 rows -- at B = 64 crops exactly one / three /
+ * four whole tiles per CU, no stream-K hand-over -- and the remaining < 256 rows are computed as 32 x 32 fragments with the same
+ * per-accumulator instruction sequence (bit-identical to tiled results).  Rows >= round_up(J_valid, 32) of the outputs are not written.
+ * Needs (I / 256) * (J_valid / 256) >= 8 tiles and at least one k-step per slot; below 256 tiles the slots of a tile split its K in
+ * parallel (fixed-order reduction), below 128 the tiles are 256 x 128.
+ * plane_scale: the power of two the OUTPUT planes of epilogues 6 / 7 carry (the consumer GEMM then runs with out_scale = 1 / (64 s));
+ * amax: NULL, or (calibration passes) a device float that receives max |x| of the planes written (atomic max on the f32 bits). */
 int gp_split_planes(const float* X, size_t count, float scale, void* hi, void* lo, void* stream);
-int gp_gemm_planes256(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
-                      void* out_lo, int ldo, int I, int J, int K, int epilogue, const float* bias, const float* scale,
-                      const float* residual, int ldr, float out_scale, float* scratch, size_t scratch_bytes, void* stream);
-
-/* gp_vit_forward with the linear layers in split-f16 numerics: `split` = HOST array of n_split = 10*depth DEVICE
- * pointers, per layer: qk_hi, qk_lo (2dim, dim), v_hi, v_lo (dim, dim), proj_hi, proj_lo (dim, dim),
- * fc1_hi, fc1_lo (mlp, dim), fc2_hi, fc2_lo (dim, mlp) -- f16 planes of the PyTorch-native [out][in] weights,
- * w ~= hi + lo * 2^-11.  With n_split = 20*depth each layer carries ten more pointers: the same five weights as
- * gp_split256_weights planes; GEMMs whose shape fills the chip with 256 x 256 tiles then use gp_gemm_split256.
- * When all five GEMMs of a layer do (ViT-L from B = 64), the activations between the kernels travel as token-major
- * f16 planes written by LayerNorm, attention and fc1's GELU epilogue, and every GEMM is gp_gemm_planes256 (results
- * bit-identical to the f32-activation kernels; gp_vit_set_planes(0) switches this off).
- * split == NULL: identical to gp_vit_forward.  (Patch embedding, LayerNorm statistics, attention and the feature
- * epilogue are the same f32 arithmetic in both modes.) */
-int gp_gemm_planes256_set_dp(int mode); /* bit 0 (default 1): data-parallel rounds before the stream-K remainder; bit 1: TEST hook,
-                                           head fragments are never published (every waiter times out -> GP_STATUS_HANDOFF_SPLIT) */
-int gp_gemm_planes256_set_par(int on); /* default 1: shapes with 8 <= tiles < 256 (ViT-L below 64 crops) run with the slots of a tile splitting
-                                          its K in parallel (partial accumulators added in a fixed order by the slot holding the last k
-                                          range, at least 16 k-steps per slot); 0: such shapes are refused and gp_vit_forward_split falls back to the 128 x 128
-                                          kernels; n >= 2 (probe hook): at least n k-steps per slot of a split tile */
-int gp_gemm_planes256_set_half_tiles(int on); /* default 1: launches whose 256 x 256 tiles fill at most half of the 256 slots (ViT-L below
-                                                 ~16 crops; epilogues 3 / 6 / 7) run on 256 x 128 tiles -- half the slots per split tile,
-                                                 half-size partial accumulators, q|k|v and fc1 unsplit; 0: always 256 x 256 (A/B hook) */
-/* Ragged J (257 tokens per crop are never a multiple of 256): only rows < J_valid of B carry data (J, the padded row
- * count of the buffers, stays a multiple of 256).  The 256 x 256 tiles cover floor(J_valid / 256) * 256 rows -- at
- * B = 64 crops exactly one / two / four whole tiles per CU, no stream-K hand-over -- and the remaining < 256 rows are
- * computed as 32 x 32 fragments with the same per-accumulator instruction sequence (bit-identical to tiled results).
- * Rows >= round_up(J_valid, 32) of the outputs are not written.  Needs (I / 256) * (J_valid / 256) >= 8 tiles, at least one
- * k-step per slot, and (with fewer than 256 tiles) gp_gemm_planes256_set_par(1). */
-int gp_gemm_planes256_ragged(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
+int gp_gemm_planes256_scaled(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
                              void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
-                             const float* residual, int ldr, float out_scale, float* scratch, size_t scratch_bytes, void* stream);
-/* probe build of gp_gemm_planes256_ragged (epilogues 0, 3, 6, 7) with per-slot time stamps, see gp_split256.hip */
-int gp_gemm_planes256_trace(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
-                            void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
-                            const float* residual, int ldr, float out_scale, float* scratch, unsigned long long* trace, void* stream);
-/* LayerNorm folded into its neighbour GEMMs (round 4; HF modeling_dinov2.py:342-380: norm1 -> attention, norm2 -> mlp).
- * sum_k W_ik LN(x)_k + b_i = r (sum_k (W_ik g_k) x_k - mu s_i) + b'_i with per-token mu, r: the GEMM multiplies the RAW residual planes
- * with W diag(g) and the per-token part moves into its epilogue; the producing GEMM (proj, fc2) writes those raw planes and the
- * per-token partial (sum, sum of squares) pairs next to the f32 residual stream.  gp_gemm_planes256_ln = gp_gemm_planes256_ragged +
- *   epilogue 10 (producer): x = residual + scale_i (out_scale acc + bias_i) on a TOKEN-MAJOR f32 stream D / residual [J][I] (ldd, ldr;
- *               D != residual), the same x as planes out_hi / out_lo [J][I] (x 8), statistics to st_main [I / 256][stats_ld][2]
- *               (rows below floor(J_valid / 256) * 256) and st_strip [I / 32][256][2] (the ragged rows above);
- *   epilogue 8 / 9 (consumer; 9 through GELU): planes of r_j (out_scale acc - mu_j s_i) + b'_i with bias = b', scale = s, mu / r from
- *               ln_main [K / 256][stats_ld][2] / ln_strip [K / 32][256][2] and ln_eps; needs K % 256 == 0.
- * gp_raw_planes_stats: the entry of the token-major stream (once per forward, after the embedding), see gp_vit.hip.
- * gp_vit_forward_split takes the path when n_split = 28 * depth (entries 20..27 per layer: x64 planes of W_qkv diag(g1) and
- * W_fc1 diag(g2), then s and b' of each as f32 vectors) and every GEMM of a layer fills the plane kernel; gp_vit_set_ln_fold(0)
- * keeps LayerNorm as its own launches (A/B hook). */
-int gp_gemm_planes256_ln(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi, void* out_lo,
-                         int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale, const float* residual,
-                         int ldr, float out_scale, const float* ln_main, const float* ln_strip, float* st_main, float* st_strip, int stats_ld,
-                         float ln_eps, float* scratch, size_t scratch_bytes, void* stream);
-int gp_raw_planes_stats(const float* X, float* Xt, void* out_hi, void* out_lo, float* st_main, float* st_strip, int C, int Mpad, int strip_j0,
-                        void* stream);
-void gp_vit_set_ln_fold(int on); /* A/B override: -1 (default) a forward folds iff its n_split carries the folded operands, 0 never, 1 in place, 2 ping-pong */
-/* stage entry of the plane path (tests, tools/probe_stage_errors.py): LayerNorm over C of X [C][Mpad] f32 (channel-major, as the
- * residual stream is kept) -> token-major activation planes hi / lo [Mpad][C] (x 8); HF modeling_dinov2.py:342-380 norm1 / norm2. */
+                             const float* residual, int ldr, float out_scale, float plane_scale, float* amax, float* scratch,
+                             size_t scratch_bytes, void* stream);
+/* LayerNorm over C of X [C][Mpad] f32 (channel-major, as the residual stream is kept) -> token-major activation planes hi / lo
+ * [Mpad][C] (x 8); HF modeling_dinov2.py:342-380 norm1 / norm2.  Stage entry of the plane path. */
 int gp_layernorm_planes(const float* X, void* out_hi, void* out_lo, const float* gamma, const float* beta, int C, int Mpad, float eps,
                         void* stream);
-void gp_vit_set_ln_reg(int mode); /* A/B hook of the plane path's LayerNorm: 1 (default) 32-token blocks, 16-token blocks when the launch has at most
-                                    128 of them (ViT-L up to 15 crops: +1.3 % at 8 crops; slower above); 2 always 32-token blocks; 0 the first-generation three-pass kernel */
-void gp_vit_set_planes(int mode); /* 2 (default) = planes + attention in split numerics, 1 = planes + f32 attention, 0 = off */
-
-/* softmax(q k^T / 8) v per (image, head) in split numerics (attention_split_kernel): qkv_hi/lo = f16 planes [Mpad][3 dim]
- * of Q | K | V (x 8, token b*257 + t in row order), out_hi/lo = planes [Mpad][dim] (x 8) of the attention output;
+/* softmax(q k^T / 8) v per (image, head) in split numerics (attention_split_kernel): qkv_hi/lo = f16 planes [Mpad][3 dim] of Q | K | V
+ * (x qkv_scale, a power of two; token b*257 + t in row order), out_hi/lo = planes [Mpad][dim] (x qkv_scale) of the attention output;
  * replaces HF modeling_dinov2.py:207-229 inside AENet.forward for the split mode. */
-int gp_attention_split(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
-                       void* stream);
-void gp_vit_set_attn_probe(int mode); /* A/B hook of gp_attention_split: 1 = key chunk c + 1 staged under the matrix pass over chunk c (measured slower), 0 = all chunks staged up front */
-int gp_vit_forward_split(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
-                         const float* const* weights, int n_weights, const void* const* split, int n_split,
-                         float* workspace, size_t workspace_bytes, float* out_features, int normalize,
-                         int stop_after_layers, void* stream);
-/* Per-tensor plane scales (round 5; replaces the all-or-nothing fallback to the 128 x 128 kernels when a checkpoint's activations leave
- * the x 8 planes' range -- DINOv2's massive activations; arithmetic: HF modeling_dinov2.py:342-380, the same forward).  The plane path
- * keeps four activation tensors per layer as f16 hi / lo planes of s x: [0] LayerNorm-1 output, [1] q | k | v and the attention output,
- * [2] LayerNorm-2 output, [3] GELU output; s is a power of two PER (layer, tensor):
- *   plane_scales  HOST array [depth][4] or NULL (= all 8: bit-identical to gp_vit_forward_split); each in [2^-10, 64];
+int gp_attention_split_scaled(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
+                              float qkv_scale, void* stream);
+
+/* gp_vit_forward with the linear layers in split-f16 numerics: `split` = HOST array of n_split = 10*depth DEVICE pointers, per layer:
+ * qk_hi, qk_lo (2dim, dim), v_hi, v_lo (dim, dim), proj_hi, proj_lo (dim, dim), fc1_hi, fc1_lo (mlp, dim), fc2_hi, fc2_lo (dim, mlp) --
+ * f16 planes of the PyTorch-native [out][in] weights, w ~= hi + lo * 2^-11.  With n_split = 20*depth each layer carries ten more
+ * pointers: the same five weights as gp_split256_weights planes; GEMMs whose shape fills the chip with 256 x 256 tiles then use
+ * gp_gemm_split256.  When all five GEMMs of a layer fit the plane kernel (ViT-L from 8 crops; dim a multiple of 256), the activations
+ * between the kernels travel as token-major f16 planes written by LayerNorm, attention and fc1's GELU epilogue, and every GEMM is
+ * gemm_planes256_kernel.  split == NULL: identical to gp_vit_forward.  (Patch embedding, LayerNorm statistics and the feature epilogue
+ * are the same f32 arithmetic in both modes.)
+ * Per-tensor plane scales (round 5; DINOv2's massive activations; arithmetic: HF modeling_dinov2.py:342-380, the same forward).  The
+ * plane path keeps four activation tensors per layer as f16 hi / lo planes of s x: [0] LayerNorm-1 output, [1] q | k | v and the
+ * attention output, [2] LayerNorm-2 output, [3] GELU output; s is a power of two PER (layer, tensor):
+ *   plane_scales  HOST array [depth][4] or NULL (= all 8); each in [2^-10, 64];
  *   plane_amax    DEVICE array [depth][4] f32 or NULL; non-NULL = calibration pass: every plane producer records max |x| of what it
  *                 wrote (atomic max on the f32 bits; the caller zeroes it) -- gigapose_amd/vit.py picks s from it with headroom.
  * Consumers undo the scale exactly (out_scale = 1 / (64 s)); the range guard (GP_STATUS_SPLIT_RANGE) stays |s x| <= 65504. */
 int gp_vit_forward_split2(const float* images, int B, int dim, int depth, int heads, int mlp_dim, float ln_eps,
                           const float* const* weights, int n_weights, const void* const* split, int n_split,
                           float* workspace, size_t workspace_bytes, float* out_features, int normalize,
-                          int stop_after_layers, const float* plane_scales, float* plane_amax, int fc2_park, void* stream);
-/* stage entries of the same (tests): gp_gemm_planes256_ragged whose plane epilogue (6 / 7) writes s x with s = plane_scale (the
- * consumer GEMM then takes out_scale = 1 / (64 s)), optionally recording max |x| into the device float `amax`; gp_attention_split on
- * q | k | v planes that carry qkv_scale instead of 8 (its output planes carry the same scale). */
-int gp_gemm_planes256_scaled(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, void* out_hi,
-                             void* out_lo, int ldo, int I, int J, int J_valid, int K, int epilogue, const float* bias, const float* scale,
-                             const float* residual, int ldr, float out_scale, float plane_scale, float* amax, float* scratch,
-                             size_t scratch_bytes, void* stream);
-int gp_attention_split_scaled(const void* qkv_hi, const void* qkv_lo, void* out_hi, void* out_lo, int B, int heads, int dim, int Mpad,
-                              float qkv_scale, void* stream);
-/* Long-K accumulation in parts (round 5; fc2 of the ViT MLP, HF modeling_dinov2.py:272-299: K = 4 dim).  The single-accumulator plane GEMM
- * rounds its f32 accumulator once per matrix-instruction pass: K = 4096 is 768 roundings (64 k16 blocks x 3 products x 4), where a
- * blocked CPU GEMM sees a few dozen.  gp_gemm_planes256_park runs the K range of every whole tile of an in-place residual GEMM
- * (epilogue 3, D == residual) as `park` parts, each from a zero accumulator, each folded into D by the tile's own epilogue (the bias
- * goes with the first part).  gp_vit_forward_split2's `fc2_park` applies it to fc2 (0 / 1 = off). */
-int gp_gemm_planes256_park(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* D, int ldd, int I, int J, int J_valid,
-                           int K, const float* bias, const float* scale, float out_scale, int park, float* scratch, size_t scratch_bytes,
-                           void* stream);
+                          int stop_after_layers, const float* plane_scales, float* plane_amax, void* stream);
 
 /* ---- IST backbone: ResNet.forward (src/models/network/resnet.py:364-381, BasicBlock :26-50) -- */
 
@@ -351,7 +266,6 @@ int gp_resize_bilinear_cm(const float* images, float* out, int B, int C, int IH,
  * Wt: (Kpad, Cout), row k = ci*KH*KW + dy*KW + dx, Kpad = round_up(Cin*KH*KW, 16), extra rows zero.
  * Implicit GEMM on the f32 matrix core; accumulation = sequential fmaf over k.
  * Requires Cout % 64 == 0 and B*OH*OW % 256 == 0. */
-void gp_conv_set_direct(int on); /* test hook: 0 = always use the generic gather kernel (results identical) */
 int gp_conv2d_cm(const float* X, const float* Wt, float* Y, const float* alpha, const float* beta,
                  const float* residual, int Cin, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
                  int relu, int nchw_out, void* stream);
@@ -377,13 +291,10 @@ int gp_conv2d_nhwc_split(const void* x_hi, const void* x_lo, const void* w_hi, c
  * gp_conv2d_planes_workspace_bytes() bytes (stream-K hand-overs; zeroed ONCE by the caller at allocation -- launches tag their
  * hand-off flags with a per-launch epoch and never reset them).  gp_planes_from_cm: f32 [C][npix] -> such planes [npix][C]. */
 size_t gp_conv2d_planes_workspace_bytes(void);
-void gp_conv2d_planes_set_trace(unsigned long long* device_buf); /* probe: per slot segments / k-steps / ticks, NULL = off */
 int gp_planes_from_cm(const float* X, int C, int npix, void* hi, void* lo, void* stream);
 /* 3 x 3 / stride 1 / pad 1 convolutions on images whose sides are multiples of 16 run conv_halo_kernel (16 x 16 pixel blocks whose
  * 18 x 18 halo is staged in LDS once per 32 input channels; the nine taps read it at shifted rows) -- same arguments, results equal
- * to conv_planes_kernel's to f32 round-off (summation order (channel block, tap) instead of (tap, channel block)).  0 = A/B hook;
- * 5 = without the parallel split of layers with fewer tiles than slots; 1 + 16 n (probe): at least n channel blocks per slot of a split tile. */
-int gp_conv2d_planes_set_halo(int on);
+ * to conv_planes_kernel's to f32 round-off (summation order (channel block, tap) instead of (tap, channel block)). */
 int gp_conv2d_planes(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* alpha, const float* beta,
                      const void* res_hi, const void* res_lo, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                      int relu, void* out_hi, void* out_lo, float* out_f32_nchw, float* scratch, size_t scratch_bytes, void* stream);
@@ -423,12 +334,9 @@ int gp_ist_regress(const float* tar_feat, const float* src_bank, const int* labe
  * correspondence proposes M = [s*R | t]; inliers = other correspondences within pixel_threshold;
  * first maximum wins.  Outputs: M (R,3,3); failed (R) u8 = (best count == 0); the winner's inliers
  * packed at the front of inl_src/inl_tar (R,256,2) int64 (pad -1) and inl_score (R,256) int64 (pad 0).
- * No valid correspondence: M = I, failed = 0. */
-int gp_ransac(const long long* src_pts, const long long* tar_pts, const float* rel_scale,
-              const float* rel_inplane, int R, float patch_size, float pixel_threshold, float* M,
-              unsigned char* failed, long long* inl_src, long long* inl_tar, long long* inl_score, void* stream);
-/* RANSAC.forward(batch, scores=...) (ransac.py:108-121, 98): `score` (R,256) f32 weights every correspondence (NULL = ones =
- * gp_ransac): a candidate's score is the f32 sum, in ascending order, of the weights of the other correspondences within the
+ * No valid correspondence: M = I, failed = 0.
+ * RANSAC.forward(batch, scores=...) (ransac.py:108-121, 98): `score` (R,256) f32 weights every correspondence (NULL = ones, the plain
+ * forward above): a candidate's score is the f32 sum, in ascending order, of the weights of the other correspondences within the
  * threshold; failed = (best score == 0); inl_score = the winners' weights cast to int64 as the reference's assignment does. */
 int gp_ransac_scored(const long long* src_pts, const long long* tar_pts, const float* rel_scale,
                      const float* rel_inplane, const float* score, int R, float patch_size, float pixel_threshold, float* M,

@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import ref_shim  # noqa: E402
-from gigapose_amd import synthetic as syn  # noqa: E402
+from gigapose_testing import synthetic as syn  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 

@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import ref_shim  # noqa: E402
 from oracle import make_goldens as mg  # noqa: E402
-from gigapose_amd import synthetic as syn  # noqa: E402
+from gigapose_testing import synthetic as syn  # noqa: E402
 
 P = 256
 CLIP = 1e-3

@@ -18,7 +18,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import make_goldens as mg, ref_shim, torch_port  # noqa: E402
-from gigapose_amd import synthetic as syn  # noqa: E402
+from gigapose_testing import synthetic as syn  # noqa: E402
 
 
 def main(threads=8, n_crops=32, n_templates=162):
@@ -53,7 +53,7 @@ def main(threads=8, n_crops=32, n_templates=162):
     crops = {n: torch.from_numpy(q[n]) for n in ["tar_img", "tar_mask", "tar_K", "tar_M"]}
     crops["labels"] = torch.from_numpy(q["labels"])
     geom = (td.K.numpy(), td.M.numpy(), td.poses.numpy())
-    from gigapose_amd import factory
+    from gigapose_testing import factory
     ist_port = factory.build_model("dinov2_vits14", k=5, device="cpu", seed=0).ist_net      # reference-shaped ISTNet mirror (same operators)
     t0 = time.time()
     torch_port.eval_retrieval(backbone.m, ist_port, td.ae_features, td.ist_features, td.mask, geom, crops, 5, dets_per_forward=4)

@@ -67,7 +67,7 @@ def pose_rel_err(a, b):
 def geometry(seed, O, N, B):
     """The camera / crop geometry of an end-to-end golden (oracle/make_goldens.py: e2e_inputs; tests/test_gpu_e2e.py: e2e_inputs),
     regenerated from its seed: labels (B,) 1-based, tar_K / tar_M (B,3,3), template K (O,3,3), M (O,N,3,3), poses (O,N,4,4)."""
-    from gigapose_amd import synthetic as syn
+    from gigapose_testing import synthetic as syn
 
     tK, tM, tP = syn.template_geometry(seed + 1, O, N)
     labels = np.random.RandomState(seed).randint(1, O + 1, B)

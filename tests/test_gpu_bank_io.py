@@ -3,7 +3,9 @@ template shards cut at load time equal the shards cut at onboarding (both numeri
 import pytest
 import torch
 
-from gigapose_amd import bank_io, factory
+from gigapose_amd import bank_io
+
+from gigapose_testing import factory
 
 pytestmark = pytest.mark.gpu
 
@@ -90,7 +92,7 @@ def test_bank_file_carries_the_plane_scale_calibration(tmp_path):
     import warnings
 
     from gigapose_amd import _lib
-    from gigapose_amd import synthetic as syn
+    from gigapose_testing import synthetic as syn
     from gigapose_amd.vit import Dinov2ViT
     from test_gpu_guards import _gigapose_with_vit
 

@@ -83,7 +83,7 @@ def hub_from_hf(hf, table37):
 @pytest.mark.parametrize("variant", ["dinov2_vits14", "dinov2_vitb14", "dinov2_vitl14"])
 @pytest.mark.parametrize("numerics", ["chain", "split"])
 def test_hub_format_checkpoint_through_the_parent_load_state_dict(variant, numerics):
-    from gigapose_amd import factory
+    from gigapose_testing import factory
     from gigapose_amd.ae_net import AENet
     from gigapose_amd.vit import VARIANTS, Dinov2ViT
 
@@ -129,7 +129,8 @@ def test_hub_format_checkpoint_through_the_parent_load_state_dict(variant, numer
 
 def test_vit_base_end_to_end_predict_both_numerics():
     """dinov2_vitb14 through the whole path (onboarding, calibration, predict): chain == split in every discrete output on an easy bank."""
-    from gigapose_amd import _lib, factory
+    from gigapose_amd import _lib
+    from gigapose_testing import factory
 
     outs = {}
     for numerics in ("chain", "split"):

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from gigapose_amd import synthetic as syn
+from gigapose_testing import synthetic as syn
 from oracle import cpu as oracle
 from oracle import ist_torch
 
@@ -40,6 +40,7 @@ def hip_conv(X, W, alpha, beta, res, stride, pad, relu, nchw=False):
     (24, 64, 1, 2, 0, 32, 1, True, False, False),    # downsample 1x1 stride 2
     (32, 64, 1, 1, 0, 16, 1, False, False, False),   # layer4_outconv (no BN)
 ])
+@pytest.mark.probes
 def test_conv_bit_exact_vs_oracle(cin, cout, k, stride, pad, hw, B, bn, res, relu):
     rs = np.random.RandomState(cin * 7 + cout)
     X = rs.standard_normal((cin, B, hw, hw)).astype(np.float32)

@@ -12,8 +12,8 @@ import pytest
 import torch
 
 import dropin_flow as df
-from gigapose_amd import factory
-from gigapose_amd import synthetic as syn
+from gigapose_testing import factory
+from gigapose_testing import synthetic as syn
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"

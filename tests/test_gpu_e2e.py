@@ -12,7 +12,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-from gigapose_amd import synthetic as syn
+from gigapose_testing import synthetic as syn
 from oracle import ist_torch
 from test_oracle_pose_ist import build_ist
 
@@ -226,7 +226,7 @@ def test_template_sharded_path_over_rccl_equals_unsharded(monkeypatch, numerics)
 
     import torch.distributed as dist
 
-    from gigapose_amd import factory
+    from gigapose_testing import factory
 
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -265,7 +265,7 @@ def test_template_sharded_path_over_rccl_equals_unsharded(monkeypatch, numerics)
 def test_ist_backbone_on_a_second_stream_gives_the_same_predictions(monkeypatch, numerics):
     """`overlap_ist` (GIGAPOSE_OVERLAP_IST = 1 / auto): the IST backbone runs on a side stream next to ViT + matching -- below 64 crops the
     two chains together fill the chip (+7 % at 8 crops).  Same kernels with deterministic reductions: every tensor of predict() is equal."""
-    from gigapose_amd import factory
+    from gigapose_testing import factory
 
     monkeypatch.setenv("GIGAPOSE_NUMERICS", numerics)
     dev = torch.device("cuda", 0)

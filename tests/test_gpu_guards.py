@@ -10,8 +10,10 @@ import numpy as np
 import pytest
 import torch
 
-from gigapose_amd import _lib, factory
-from gigapose_amd import synthetic as syn
+from gigapose_amd import _lib
+
+from gigapose_testing import factory
+from gigapose_testing import synthetic as syn
 from gigapose_amd.vit import Dinov2ViT
 
 pytestmark = pytest.mark.gpu
@@ -31,7 +33,6 @@ def images(B=64, seed=3):
 def clean_status():
     _lib.status_word(DEV).zero_()
     yield
-    _lib.lib().gp_gemm_planes256_set_dp(1)
     torch.cuda.synchronize()
     _lib.status_word(DEV).zero_()
 
@@ -83,6 +84,7 @@ def test_token_x500_stays_legal_and_accurate():
     assert err < 2e-6
 
 
+@pytest.mark.probes
 def test_lost_handoff_raises():
     """260 tiles on 256 slots (a fully tiled J = 16640): half the slots hand accumulator fragments over.  With the
     publishes dropped (test hook) every waiter must time out, flag it, and the host must raise; afterwards a clean
@@ -150,7 +152,7 @@ def test_range_trip_falls_back_to_the_wide_kernels_automatically():
         with a model built on the wide 128 x 128 kernels (both f32-class).
     (b) The remedy behind it still exists: with the calibration disabled the guard trips, GigaPose moves the ViT to the
         two-accumulator 128 x 128 kernels (range 65504), re-onboards and runs again -- the result equals a model that was told
-        GIGAPOSE_SPLIT_GEMM=128 from the start bit for bit, the status word is clean, a warning says what happened.
+        Dinov2ViT.set_split_gemm("128") from the start bit for bit, the status word is clean, a warning says what happened.
     A NaN still raises."""
     from test_gpu_e2e import make_batch
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from gigapose_amd import synthetic as syn
+from gigapose_testing import synthetic as syn
 from oracle import cpu as oracle
 from test_oracle_matcher import CASES, VARIANT_CASES, load_case
 
@@ -252,6 +252,7 @@ def test_val_matches_reference_golden_and_oracle(golden_dir, numerics, monkeypat
         np.testing.assert_array_equal(out.score.cpu().numpy().view(np.uint32), ref["score"].view(np.uint32))
 
 
+@pytest.mark.probes
 @pytest.mark.parametrize("C", [64, 1024])
 def test_split_matcher_live_patch_compaction_is_bit_identical(C):
     """The split matcher builds its tile from the live (mask != 0) patches only (gp_match.hip: 1..2 x 1..4 matrix tiles per wave

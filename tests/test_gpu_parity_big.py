@@ -17,7 +17,7 @@ import pandas as pd
 import pytest
 import torch
 
-from gigapose_amd import synthetic as syn
+from gigapose_testing import synthetic as syn
 from oracle import cpu as oracle
 
 pytestmark = pytest.mark.gpu

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from gigapose_amd import synthetic as syn
+from gigapose_testing import synthetic as syn
 from oracle import cpu as oracle
 from test_oracle_pose_ist import build_ist, mlp_weights, pose_case
 

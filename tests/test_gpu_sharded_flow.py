@@ -47,7 +47,8 @@ def _load(log_dir, idx):
 
 
 def _run(tmp, sub, numerics, sizes, rank, dev, sharded, rows, n_templates=11):
-    from gigapose_amd import _lib, factory
+    from gigapose_amd import _lib
+    from gigapose_testing import factory
 
     log_dir = os.path.join(tmp, f"{sub}_r{rank}")
     tset = factory.TemplateSet(2, n_templates, seed=70)

@@ -11,11 +11,12 @@ import pytest
 import torch
 
 from gigapose_amd import _lib
-from gigapose_amd import synthetic as syn
+from gigapose_testing import synthetic as syn
 from oracle import ist_torch
 from test_gpu_vit import hip_gemm, run_vit
 
-pytestmark = pytest.mark.gpu
+# stage-level tests of the GEMM machinery: plain-f32 epilogues, A/B switches and the scratch error word live in the probe build
+pytestmark = [pytest.mark.gpu, pytest.mark.probes]
 DEV = "cuda"
 
 
@@ -421,8 +422,8 @@ def test_attention_split_matches_f64():
     _lib.call("gp_split_planes", _lib.ptr(qkv), ctypes.c_size_t(qkv.numel()), _lib.f(8.0), _lib.ptr(hi), _lib.ptr(lo), _lib.stream_ptr())
     ohi = torch.zeros(Mpad, C, dtype=torch.float16, device=DEV)
     olo = torch.zeros_like(ohi)
-    _lib.call("gp_attention_split", _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(ohi), _lib.ptr(olo), _lib.i(B), _lib.i(H), _lib.i(C), _lib.i(Mpad),
-              _lib.stream_ptr())
+    _lib.call("gp_attention_split_scaled", _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(ohi), _lib.ptr(olo), _lib.i(B), _lib.i(H), _lib.i(C), _lib.i(Mpad),
+              _lib.f(8.0), _lib.stream_ptr())
     torch.cuda.synchronize()
     got = ((ohi.double() + olo.double()) / 8.0)[:M].view(B, 257, H, 64)
     x = ((hi.double() + lo.double()) / 8.0)[:M].view(B, 257, 3, H, 64)
@@ -454,11 +455,12 @@ def planes256_gemm(A, Bm, epi, bias=None, scale=None, res=None, a_scale=64.0, b_
     D = res.clone() if res is not None else torch.zeros(I, J, device=DEV)
     ohi = torch.zeros(J, I, dtype=torch.float16, device=DEV)
     olo = torch.zeros_like(ohi)
-    _lib.call("gp_gemm_planes256_ragged", _lib.ptr(ahi), _lib.ptr(alo), _lib.ptr(bhi), _lib.ptr(blo), _lib.ptr(D), _lib.i(J), _lib.ptr(ohi),
+    _lib.call("gp_gemm_planes256_scaled", _lib.ptr(ahi), _lib.ptr(alo), _lib.ptr(bhi), _lib.ptr(blo), _lib.ptr(D), _lib.i(J), _lib.ptr(ohi),
               _lib.ptr(olo), _lib.i(I), _lib.i(I), _lib.i(J), _lib.i(J if j_valid is None else j_valid), _lib.i(K), _lib.i(epi), _lib.ptr(bias),
-              _lib.ptr(scale), _lib.ptr(D), _lib.i(J), _lib.f(1.0 / (a_scale * b_scale)), _lib.ptr(ws), ctypes.c_size_t(nb), _lib.stream_ptr())
+              _lib.ptr(scale), _lib.ptr(D), _lib.i(J), _lib.f(1.0 / (a_scale * b_scale)), _lib.f(8.0), _lib.ptr(None), _lib.ptr(ws), ctypes.c_size_t(nb), _lib.stream_ptr())
     torch.cuda.synchronize()
-    assert lib.gp_gemm_split256_error(_lib.ptr(ws), _lib.stream_ptr()) == 0
+    if hasattr(lib, "gp_gemm_split256_error"):   # the scratch's error word: probe library only (the product raises through the status word)
+        assert lib.gp_gemm_split256_error(_lib.ptr(ws), _lib.stream_ptr()) == 0
     return (ohi, olo) if epi in (6, 7) else D
 
 
@@ -609,47 +611,3 @@ def test_planes256_parallel_split_k(I, J, jv, K):
         got = (oh[:jv].double() + ol[:jv].double()).t() / 8.0
         assert ((got - want).abs() <= 1.5e-6 * (mag + bias[:, None].abs().double()) + 1e-6 * want.abs()).all(), f"epilogue {epi}"
         assert not oh[top:].any() and not ol[top:].any()
-
-
-@pytest.mark.parametrize("parts", [1, 2, 4])
-def test_planes256_long_k_in_parts_folded_into_the_residual(parts):
-    """gp_gemm_planes256_park (round 5): the fc2 shape of ViT-L at 64 crops (I = 1024, J = 16640 of which 16448 carry tokens, K = 4096),
-    in place on the residual: x += scale_i (A B^T / 512 + bias_i) with every whole tile's K run as `parts` parts, each from a zero
-    accumulator and folded into x by the tile's own epilogue.  parts = 1 is gp_gemm_planes256_ragged bit for bit; more parts move
-    the result TOWARDS float64 (the one f32 accumulator sees K / parts products' roundings) -- asserted as 'not worse, within the
-    noise of the comparison', the measured gain is printed (and recorded by tools/probe_stage_errors.py on real activations)."""
-    torch.manual_seed(21)
-    I, J, jv, K = 1024, 16640, 16448, 4096
-    A = torch.randn(I, K, device=DEV) * 0.03
-    Bm = torch.nn.functional.gelu(torch.randn(J, K, device=DEV))      # GELU-shaped activations: mostly small positives, a long right tail
-    bias, scale = torch.randn(I, device=DEV), torch.randn(I, device=DEV)
-    X0 = torch.randn(I, J, device=DEV)
-    lib = _lib.lib()
-    lib.gp_gemm_split256_workspace_bytes.restype = ctypes.c_size_t
-    nb = lib.gp_gemm_split256_workspace_bytes()
-    ws = torch.zeros(nb // 4, device=DEV)
-
-    def planes(W, sc):
-        hi = torch.empty(W.shape, dtype=torch.float16, device=DEV)
-        lo = torch.empty_like(hi)
-        _lib.call("gp_split_planes", _lib.ptr(W), ctypes.c_size_t(W.numel()), _lib.f(sc), _lib.ptr(hi), _lib.ptr(lo), _lib.stream_ptr())
-        return hi, lo
-
-    (ahi, alo), (bhi, blo) = planes(A, 64.0), planes(Bm, 8.0)
-    X = X0.clone()
-    _lib.call("gp_gemm_planes256_park", _lib.ptr(ahi), _lib.ptr(alo), _lib.ptr(bhi), _lib.ptr(blo), _lib.ptr(X), _lib.i(J), _lib.i(I), _lib.i(J),
-              _lib.i(jv), _lib.i(K), _lib.ptr(bias), _lib.ptr(scale), _lib.f(1.0 / 512.0), _lib.i(parts), _lib.ptr(ws), ctypes.c_size_t(nb),
-              _lib.stream_ptr())
-    torch.cuda.synchronize()
-    assert lib.gp_gemm_split256_error(_lib.ptr(ws), _lib.stream_ptr()) == 0
-    _lib.check_status()
-    base = planes256_gemm(A, Bm, 3, bias=bias, scale=scale, res=X0, j_valid=jv)
-    if parts == 1:
-        assert torch.equal(X[:, :jv], base[:, :jv])
-    av, bv = (ahi.double() + alo.double()) / 64.0, (bhi.double() + blo.double()) / 8.0     # the values the planes hold
-    branch64 = scale.double()[:, None] * (av @ bv.t() + bias.double()[:, None])
-    rms = lambda e: float((e ** 2).mean().sqrt())
-    e_p = rms(((X.double() - X0.double()) - branch64)[:, :jv]) / rms(branch64[:, :jv])
-    e_1 = rms(((base.double() - X0.double()) - branch64)[:, :jv]) / rms(branch64[:, :jv])
-    print(f"fc2-shaped in-place GEMM, K = 4096 in {parts} part(s): branch error vs float64 {e_p:.2e} of its rms (one part: {e_1:.2e})")
-    assert e_p < 1.05 * e_1 + 2e-8 and torch.equal(X[:, jv + 32:], X0[:, jv + 32:])      # columns beyond the padded data untouched

@@ -72,6 +72,7 @@ def hip_gemm_sk(A, B, epi, bias, scale, res):
     return D.cpu().numpy()
 
 
+@pytest.mark.probes
 @pytest.mark.parametrize("shape", ["proj", "v", "qk", "ragged", "fc1"])
 def test_gemm_streamk_is_bit_identical(shape):
     """ViT-L shapes at B=64 (8 x 129, 129 x 8, 16 x 129 tiles on 1024 resident slots) + a tile count with
@@ -177,6 +178,7 @@ def test_aenet_interface_chunks():
     assert tuple(net(x[:0].to(DEV)).shape) == (0, 128, 16, 16)
 
 
+@pytest.mark.probes
 def test_attention_variants_are_bit_identical():
     """The three attention kernels (1 or 2 query tiles per wave, K/V through LDS) run the same MFMA chains."""
     from gigapose_amd import _lib
@@ -201,7 +203,7 @@ def test_vit_large_width_every_batch_size_split_vs_chain():
     import numpy as np
 
     from gigapose_amd import _lib
-    from gigapose_amd import synthetic as syn
+    from gigapose_testing import synthetic as syn
     from gigapose_amd.vit import Dinov2ViT
 
     vit = syn.fill_state_dict(Dinov2ViT(1024, 4, 16), 21).eval().to(DEV)

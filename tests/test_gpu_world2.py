@@ -31,7 +31,8 @@ def _worker(rank, world, port):
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from gigapose_amd import _lib, factory
+        from gigapose_amd import _lib
+        from gigapose_testing import factory
         from gigapose_amd.sharding import ShardedMatcher, shard_bounds
 
         for n_templates in (162, 11):

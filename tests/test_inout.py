@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from gigapose_amd import inout
-from gigapose_amd import synthetic as syn
+from gigapose_testing import synthetic as syn
 
 
 @pytest.mark.parametrize("dataset", ["lmo", "ycbv"])

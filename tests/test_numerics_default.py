@@ -4,7 +4,8 @@ import pytest
 
 def test_product_default_is_split(monkeypatch):
     monkeypatch.delenv("GIGAPOSE_NUMERICS", raising=False)
-    from gigapose_amd import _lib, factory
+    from gigapose_amd import _lib
+    from gigapose_testing import factory
     from gigapose_amd.ist_net import ResNet
     from gigapose_amd.matching import LocalSimilarity
     from gigapose_amd.vit import Dinov2ViT
@@ -18,7 +19,8 @@ def test_product_default_is_split(monkeypatch):
 
 
 def test_chain_is_opt_in_by_env_and_by_yaml_key(monkeypatch):
-    from gigapose_amd import _lib, factory
+    from gigapose_amd import _lib
+    from gigapose_testing import factory
 
     monkeypatch.setenv("GIGAPOSE_NUMERICS", "chain")
     assert _lib.default_numerics() == "chain"
@@ -36,7 +38,7 @@ def test_chain_is_opt_in_by_env_and_by_yaml_key(monkeypatch):
 def test_second_stream_switch_defaults_to_auto_and_is_read_from_the_environment(monkeypatch):
     """GigaPose.overlap_ist: "auto" (IST backbone on a second stream up to 32 crops; round 5 -- the GPU suite runs with it) unless
     GIGAPOSE_OVERLAP_IST says 0 / 1 (small batches)."""
-    from gigapose_amd import factory
+    from gigapose_testing import factory
 
     monkeypatch.delenv("GIGAPOSE_OVERLAP_IST", raising=False)
     assert factory.build_model("dinov2_vits14", k=2, device="cpu").overlap_ist == "auto"
@@ -50,7 +52,7 @@ def test_cross_image_accumulation_default_and_keys(monkeypatch):
     like `numerics`, so the constructor keeps the reference's signature) override it; 0 = the reference's per-image flow."""
     import tempfile
 
-    from gigapose_amd import factory
+    from gigapose_testing import factory
     from gigapose_amd.gigaPose import GigaPose
 
     monkeypatch.delenv("GIGAPOSE_ACCUMULATE_CROPS", raising=False)

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from gigapose_amd import synthetic as syn
+from gigapose_testing import synthetic as syn
 from oracle import crop_numpy
 
 

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from gigapose_amd import synthetic as syn
+from gigapose_testing import synthetic as syn
 from oracle import cpu as oracle
 
 CASES = ["match_small", "match_vits", "match_kN", "match_fullmask", "match_noshift"]

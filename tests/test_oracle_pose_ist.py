@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from gigapose_amd import synthetic as syn
+from gigapose_testing import synthetic as syn
 from oracle import ist_torch
 from oracle import cpu as oracle
 

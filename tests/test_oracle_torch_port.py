@@ -30,7 +30,7 @@ def test_torch_eval_retrieval_port_vs_reference_golden(golden_dir):
     from test_oracle_pose_ist import build_ist
     from transformers import Dinov2Config, Dinov2Model
 
-    from gigapose_amd import synthetic as syn
+    from gigapose_testing import synthetic as syn
 
     torch.set_num_threads(8)
     g = np.load(os.path.join(golden_dir, "e2e.npz"))

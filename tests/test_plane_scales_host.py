@@ -15,12 +15,12 @@ def test_scale_is_the_largest_power_of_two_with_headroom():
     for a in (3.0, 77.0, 4097.0, 3.3e4, 2.0e5):
         s = f(a, 4)
         assert a * s * 4 <= 65504.0 and (s == 8.0 or a * (2 * s) * 4 > 65504.0) and np.log2(s) == int(np.log2(s))
-    assert f(1.2e4, 1) == 4.0                                          # GIGAPOSE_PLANE_HEADROOM = 1: no headroom
+    assert f(1.2e4, 1) == 4.0                                          # plane_headroom = 1: no headroom
 
 
 def test_calibration_state_and_report():
     vit = Dinov2ViT(384, 2, 6)
-    assert vit.plane_scales is None and vit.plane_amax is None and vit.plane_scale_report() == {} and vit.fc2_park == 0
+    assert vit.plane_scales is None and vit.plane_amax is None and vit.plane_scale_report() == {}
     # nothing to calibrate outside the split plane path: no launch is attempted (these would raise on a CPU tensor otherwise)
     x = torch.zeros(2, 3, 224, 224)
     assert vit.set_numerics("chain").calibrate_plane_scales(x) is False

@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from gigapose_amd import sharding
-from gigapose_amd import synthetic as syn
+from gigapose_testing import synthetic as syn
 from oracle import cpu as oracle
 
 
@@ -276,7 +276,8 @@ def _sync_worker(rank, world, port, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from gigapose_amd import _lib, factory
+        from gigapose_amd import _lib
+        from gigapose_testing import factory
 
         # (1) the batch-size agreement: equal sizes pass, unequal sizes raise on EVERY rank (nobody is left inside a collective)
         sharding.require_same_batch(5, torch.device("cpu"))

@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gigapose_amd.vit import Dinov2ViT
 from gigapose_amd import _lib
+
+_lib.use_probe_library()   # hooks / traced builds / error words live in libgigapose_hip_probe.so (include/gigapose_hip_probe.h)
 dev = "cuda"
 lib = _lib.lib()
 def timeit(fn, iters=3, warm=1):

@@ -11,7 +11,7 @@ def run(qkv):
     hi = torch.empty(Mpad, 3 * C, dtype=torch.float16, device=dev); lo = torch.empty_like(hi)
     _lib.call("gp_split_planes", _lib.ptr(qkv), ctypes.c_size_t(qkv.numel()), _lib.f(8.0), _lib.ptr(hi), _lib.ptr(lo), _lib.stream_ptr())
     ohi = torch.zeros(Mpad, C, dtype=torch.float16, device=dev); olo = torch.zeros_like(ohi)
-    _lib.call("gp_attention_split", _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(ohi), _lib.ptr(olo), _lib.i(B), _lib.i(H), _lib.i(C), _lib.i(Mpad), _lib.stream_ptr())
+    _lib.call("gp_attention_split_scaled", _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(ohi), _lib.ptr(olo), _lib.i(B), _lib.i(H), _lib.i(C), _lib.i(Mpad), _lib.f(8.0), _lib.stream_ptr())
     torch.cuda.synchronize()
     got = ((ohi.double() + olo.double()) / 8.0)[:M].view(B, 257, H, 64)
     x = ((hi.double() + lo.double()) / 8.0)[:M].view(B, 257, 3, H, 64)

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from gigapose_amd import _lib
+
+_lib.use_probe_library()   # hooks / traced builds / error words live in libgigapose_hip_probe.so (include/gigapose_hip_probe.h)
 dev = "cuda"
 lib = _lib.lib()
 def timeit(fn, iters=10, warm=3):
@@ -23,19 +25,12 @@ qkv = torch.randn(Mpad, 3 * C, device=dev)
 hi = torch.empty(Mpad, 3 * C, dtype=torch.float16, device=dev); lo = torch.empty_like(hi)
 _lib.call("gp_split_planes", _lib.ptr(qkv), ctypes.c_size_t(qkv.numel()), _lib.f(8.0), _lib.ptr(hi), _lib.ptr(lo), _lib.stream_ptr())
 ohi = torch.zeros(Mpad, C, dtype=torch.float16, device=dev); olo = torch.zeros_like(ohi)
-run = lambda: _lib.call("gp_attention_split", _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(ohi), _lib.ptr(olo), _lib.i(B), _lib.i(H), _lib.i(C), _lib.i(Mpad), _lib.stream_ptr())
+run = lambda: _lib.call("gp_attention_split_scaled", _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(ohi), _lib.ptr(olo), _lib.i(B), _lib.i(H), _lib.i(C), _lib.i(Mpad), _lib.f(8.0), _lib.stream_ptr())
 ms = timeit(run)
 fl = 4.0 * B * H * 257 * 257 * 64
 print(f"attention_split_kernel B={B} H={H}: {ms*1e3:.1f} us isolated = {fl/ms/1e9:.1f} TF-equivalent (f32 kernel: 286 us in the bench)")
 if "--plain" in sys.argv:   # PMC passes: only the product kernel
     sys.exit(0)
-# round 6: A/B of the staging order inside one binary -- 0 = every chunk staged before the first matrix pass (the product),
-# 1 = key chunk c + 1 staged under the matrix pass over chunk c
-for rep in range(3):
-    for mode, what in ((0, "all chunks staged up front (product)"), (1, "chunk c + 1 staged under the matrix pass over chunk c")):
-        lib.gp_vit_set_attn_probe(mode)
-        print(f"  probe {mode}: {what}: {timeit(run, iters=30)*1e3:.1f} us per launch")
-lib.gp_vit_set_attn_probe(0)
 from test_gpu_split import planes256_gemm
 I, J, K = 4096, 4096, 64
 for mag in (1e-3, 3e-6, 3e-7):

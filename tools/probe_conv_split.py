@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from gigapose_amd import factory
+from gigapose_testing import factory
 dev = "cuda"
 def timeit(fn, iters=5, warm=2):
     for _ in range(warm): fn()

@@ -11,6 +11,8 @@ import torch
 
 from gigapose_amd import _lib
 
+_lib.use_probe_library()   # hooks / traced builds / error words live in libgigapose_hip_probe.so (include/gigapose_hip_probe.h)
+
 dev = "cuda"
 if os.environ.get("GP_LIB"):   # a library built with other macros (tools/patches/conv_epi_probe.diff, -DGP_CONV_PROBE=..)
     _lib.LIB_PATH = os.path.abspath(os.environ["GP_LIB"])

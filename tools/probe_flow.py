@@ -13,7 +13,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from gigapose_amd import factory  # noqa: E402
+from gigapose_testing import factory  # noqa: E402
 from gigapose_amd.gigaPose import GigaPose  # noqa: E402
 from gigapose_amd.tensor_collection import PandasTensorCollection  # noqa: E402
 

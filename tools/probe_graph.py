@@ -6,7 +6,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from gigapose_amd import _lib, factory
+from gigapose_amd import _lib
+
+from gigapose_testing import factory
 
 dev = "cuda"
 model = factory.build_model("dinov2_vitl14", k=5, device=dev, seed=2)

@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gigapose_amd.matching import LocalSimilarity, MatchBank
-from gigapose_amd import synthetic as syn
+from gigapose_testing import synthetic as syn
 
 dev = "cuda"
 print(torch.cuda.get_device_name(0), torch.cuda.get_device_properties(0).multi_processor_count, "CUs")

@@ -13,6 +13,8 @@ import numpy as np
 import torch
 
 from gigapose_amd import _lib
+
+_lib.use_probe_library()   # hooks / traced builds / error words live in libgigapose_hip_probe.so (include/gigapose_hip_probe.h)
 from gigapose_amd.matching import LocalSimilarity, MatchBank, patch_grid_mask
 
 dev = "cuda"

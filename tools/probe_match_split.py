@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gigapose_amd.matching import LocalSimilarity, MatchBank
-from gigapose_amd import synthetic as syn
+from gigapose_testing import synthetic as syn
 dev = "cuda"
 def timeit(fn, iters=3, warm=1):
     for _ in range(warm): fn()

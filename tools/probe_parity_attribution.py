@@ -73,9 +73,9 @@ class HybridViT:
         if out_planes:
             ohi = torch.zeros(Mpad, I, dtype=torch.float16, device=DEV)
             olo = torch.zeros_like(ohi)
-        _lib.call("gp_gemm_planes256_ragged", _lib.ptr(wpl[0]), _lib.ptr(wpl[1]), _lib.ptr(bhi), _lib.ptr(blo), _lib.ptr(D), _lib.i(Mpad),
+        _lib.call("gp_gemm_planes256_scaled", _lib.ptr(wpl[0]), _lib.ptr(wpl[1]), _lib.ptr(bhi), _lib.ptr(blo), _lib.ptr(D), _lib.i(Mpad),
                   _lib.ptr(ohi), _lib.ptr(olo), _lib.i(I), _lib.i(I), _lib.i(Mpad), _lib.i(Mtok), _lib.i(K), _lib.i(epi), _lib.ptr(bias),
-                  _lib.ptr(scale), _lib.ptr(D), _lib.i(Mpad if res is not None else 0), _lib.f(1.0 / 512.0), _lib.ptr(self.ws),
+                  _lib.ptr(scale), _lib.ptr(D), _lib.i(Mpad if res is not None else 0), _lib.f(1.0 / 512.0), _lib.f(8.0), _lib.ptr(None), _lib.ptr(self.ws),
                   ctypes.c_size_t(self.nb), _lib.stream_ptr())
         return (ohi, olo) if out_planes else D
 
@@ -126,8 +126,8 @@ class HybridViT:
                 o = planes_of(pad(attn64(val(*a)[:Mtok].view(B, T, 3, H, 64))))
             else:
                 o = (torch.zeros(Mpad, C, dtype=torch.float16, device=DEV), torch.zeros(Mpad, C, dtype=torch.float16, device=DEV))
-                _lib.call("gp_attention_split", _lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(o[0]), _lib.ptr(o[1]), _lib.i(B), _lib.i(H), _lib.i(C), _lib.i(Mpad),
-                          _lib.stream_ptr())
+                _lib.call("gp_attention_split_scaled", _lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(o[0]), _lib.ptr(o[1]), _lib.i(B), _lib.i(H), _lib.i(C), _lib.i(Mpad),
+                          _lib.f(8.0), _lib.stream_ptr())
             # x += ls1 * proj(.)
             if ideal & {"proj", "gemms", "all"}:
                 X1 = X.clone()

@@ -3,6 +3,8 @@ import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gigapose_amd import _lib
+
+_lib.use_probe_library()   # hooks / traced builds / error words live in libgigapose_hip_probe.so (include/gigapose_hip_probe.h)
 dev = "cuda"
 lib = _lib.lib()
 lib.gp_gemm_split256_workspace_bytes.restype = ctypes.c_size_t
@@ -38,9 +40,9 @@ for (nw, K, w_is_a, name, epi) in [(1024, 1024, 1, "proj", 3), (4096, 1024, 1, "
     ohi = torch.zeros(M, nw, dtype=torch.float16, device=dev); olo = torch.zeros_like(ohi)
     a_hi, a_lo, b_hi, b_lo = (whi, wlo, xhi, xlo) if w_is_a else (xhi, xlo, whi, wlo)
     def run_new():
-        _lib.call("gp_gemm_planes256", _lib.ptr(a_hi), _lib.ptr(a_lo), _lib.ptr(b_hi), _lib.ptr(b_lo), _lib.ptr(Dn), _lib.i(J),
-                  _lib.ptr(ohi), _lib.ptr(olo), _lib.i(nw), _lib.i(I), _lib.i(J), _lib.i(K), _lib.i(epi), _lib.ptr(bias), _lib.ptr(sc),
-                  _lib.ptr(Dn), _lib.i(J), _lib.f(1.0 / 512.0), _lib.ptr(ws), ctypes.c_size_t(NB), _lib.stream_ptr())
+        _lib.call("gp_gemm_planes256_scaled", _lib.ptr(a_hi), _lib.ptr(a_lo), _lib.ptr(b_hi), _lib.ptr(b_lo), _lib.ptr(Dn), _lib.i(J),
+                  _lib.ptr(ohi), _lib.ptr(olo), _lib.i(nw), _lib.i(I), _lib.i(J), _lib.i(J), _lib.i(K), _lib.i(epi), _lib.ptr(bias), _lib.ptr(sc),
+                  _lib.ptr(Dn), _lib.i(J), _lib.f(1.0 / 512.0), _lib.f(8.0), _lib.ptr(None), _lib.ptr(ws), ctypes.c_size_t(NB), _lib.stream_ptr())
     def run_old():
         _lib.call("gp_gemm_split256", _lib.ptr(Xk), _lib.i(M), _lib.ptr(whi), _lib.ptr(wlo), _lib.ptr(Do), _lib.i(J), _lib.i(I), _lib.i(J),
                   _lib.i(K), _lib.i(w_is_a), _lib.i(2 if epi == 6 else epi), _lib.ptr(bias), _lib.ptr(sc), _lib.ptr(Do), _lib.i(J), _lib.ptr(ws),
@@ -80,9 +82,9 @@ whi, wlo = planes(W, 64.0); xhi, xlo = planes(Xt, 8.0); D = torch.empty(I, J, de
 out = (ctypes.c_ulonglong * 8)()
 def timed(): lib.gp_gemm_planes256_timing(_lib.ptr(whi), _lib.ptr(wlo), _lib.ptr(xhi), _lib.ptr(xlo), _lib.ptr(D), J, I, J, K, _lib.ptr(ws), out, _lib.stream_ptr())
 def plain():
-    _lib.call("gp_gemm_planes256", _lib.ptr(whi), _lib.ptr(wlo), _lib.ptr(xhi), _lib.ptr(xlo), _lib.ptr(D), _lib.i(J), _lib.ptr(None), _lib.ptr(None),
-              _lib.i(0), _lib.i(I), _lib.i(J), _lib.i(K), _lib.i(0), _lib.ptr(None), _lib.ptr(None), _lib.ptr(None), _lib.i(0), _lib.f(1.0 / 512.0),
-              _lib.ptr(ws), ctypes.c_size_t(NB), _lib.stream_ptr())
+    _lib.call("gp_gemm_planes256_scaled", _lib.ptr(whi), _lib.ptr(wlo), _lib.ptr(xhi), _lib.ptr(xlo), _lib.ptr(D), _lib.i(J), _lib.ptr(None), _lib.ptr(None),
+              _lib.i(0), _lib.i(I), _lib.i(J), _lib.i(J), _lib.i(K), _lib.i(0), _lib.ptr(None), _lib.ptr(None), _lib.ptr(None), _lib.i(0), _lib.f(1.0 / 512.0),
+              _lib.f(8.0), _lib.ptr(None), _lib.ptr(ws), ctypes.c_size_t(NB), _lib.stream_ptr())
 for label, heat in (("cold (single launch)", 0), ("sustained (after 30 back-to-back launches)", 30)):
     torch.cuda.synchronize()
     for _ in range(heat): plain()

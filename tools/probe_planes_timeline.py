@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from gigapose_amd import _lib
+
+_lib.use_probe_library()   # hooks / traced builds / error words live in libgigapose_hip_probe.so (include/gigapose_hip_probe.h)
 dev = "cuda"
 if os.environ.get("GP_LIB"):   # a library built with other macros (e.g. -DGP_EPI_PROBE=.., tools/patches/epi_probe.diff)
     _lib.LIB_PATH = os.path.abspath(os.environ["GP_LIB"])
@@ -40,7 +42,7 @@ for (nw, K, name, epi) in [(3072, 1024, "qkv", 7), (1024, 1024, "proj", 3), (409
     trace = torch.zeros(256 * 32, dtype=torch.int64, device=dev)
     args = (_lib.ptr(whi), _lib.ptr(wlo), _lib.ptr(xhi), _lib.ptr(xlo), _lib.ptr(D), _lib.i(J), _lib.ptr(ohi), _lib.ptr(olo), _lib.i(nw),
             _lib.i(I), _lib.i(J), _lib.i(MV), _lib.i(K), _lib.i(epi), _lib.ptr(bias), _lib.ptr(sc), _lib.ptr(D), _lib.i(J), _lib.f(1.0 / 512.0), _lib.ptr(ws))
-    def plain(): _lib.call("gp_gemm_planes256_ragged", *args, ctypes.c_size_t(NB), _lib.stream_ptr())
+    def plain(): _lib.call("gp_gemm_planes256_scaled", *args[:-1], _lib.f(8.0), _lib.ptr(None), args[-1], ctypes.c_size_t(NB), _lib.stream_ptr())
     def traced(): _lib.call("gp_gemm_planes256_trace", *args, _lib.ptr(trace), _lib.stream_ptr())
     t_plain = timeit(plain)
     for _ in range(20): plain()          # sustained clocks

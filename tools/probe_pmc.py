@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gigapose_amd import _lib
 from gigapose_amd.matching import LocalSimilarity, MatchBank
-from gigapose_amd import synthetic as syn
+from gigapose_testing import synthetic as syn
 dev = "cuda"
 J = 16512
 for (I, K, epi) in [(1024, 1024, 3), (2048, 1024, 1), (4096, 1024, 2), (1024, 4096, 3)]:

@@ -10,7 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from gigapose_amd import factory  # noqa: E402
+from gigapose_testing import factory  # noqa: E402
 
 
 def main(steps=10, live=None):

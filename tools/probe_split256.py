@@ -3,6 +3,8 @@ import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gigapose_amd import _lib
+
+_lib.use_probe_library()   # hooks / traced builds / error words live in libgigapose_hip_probe.so (include/gigapose_hip_probe.h)
 dev = "cuda"
 lib = _lib.lib()
 lib.gp_gemm_split256_workspace_bytes.restype = ctypes.c_size_t

@@ -19,7 +19,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from gigapose_amd import _lib, factory  # noqa: E402
+from gigapose_amd import _lib  # noqa: E402
+from gigapose_testing import factory
 from gigapose_amd.vit import split_planes_x64  # noqa: E402
 
 DEV = "cuda"
@@ -67,10 +68,10 @@ def main():
         whi, wlo = split_planes_x64(W)
         D = res.clone() if res is not None else torch.zeros(1, device=DEV)
         ohi, olo = planes_empty(Mpad, I) if out_planes else (None, None)
-        _lib.call("gp_gemm_planes256_ragged", _lib.ptr(whi), _lib.ptr(wlo), _lib.ptr(bhi), _lib.ptr(blo), _lib.ptr(D if not out_planes else None),
+        _lib.call("gp_gemm_planes256_scaled", _lib.ptr(whi), _lib.ptr(wlo), _lib.ptr(bhi), _lib.ptr(blo), _lib.ptr(D if not out_planes else None),
                   _lib.i(Mpad), _lib.ptr(ohi), _lib.ptr(olo), _lib.i(I), _lib.i(I), _lib.i(Mpad), _lib.i(Mtok), _lib.i(K), _lib.i(epi),
                   _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(D if res is not None else None), _lib.i(Mpad if res is not None else 0), _lib.f(os_),
-                  _lib.ptr(ws), ctypes.c_size_t(nb), st())
+                  _lib.f(8.0), _lib.ptr(None), _lib.ptr(ws), ctypes.c_size_t(nb), st())
         torch.cuda.synchronize()
         return (ohi, olo) if out_planes else D
 
@@ -103,7 +104,7 @@ def main():
     # ---- attention
     qkv = val(ahi, alo)[:Mtok].view(B, 257, 3, vit.heads, 64)
     ohi, olo = planes_empty(Mpad, C)
-    _lib.call("gp_attention_split", _lib.ptr(ahi), _lib.ptr(alo), _lib.ptr(ohi), _lib.ptr(olo), _lib.i(B), _lib.i(vit.heads), _lib.i(C), _lib.i(Mpad), st())
+    _lib.call("gp_attention_split_scaled", _lib.ptr(ahi), _lib.ptr(alo), _lib.ptr(ohi), _lib.ptr(olo), _lib.i(B), _lib.i(vit.heads), _lib.i(C), _lib.i(Mpad), _lib.f(8.0), st())
     torch.cuda.synchronize()
 
     def attn(x):
@@ -141,15 +142,6 @@ def main():
     alt = X1.t() + f32(ls2) * torch.nn.functional.linear(f.float(), f32(W2), f32(b2))
     report("fc2 + residual (x2)", X2.t().double(), ref, alt)
     report("  fc2 branch alone", (X2 - X1).t().double(), ref - x1_64, alt - X1.t())
-    # ---- the same fc2 with its K = 4096 run in parts, each folded into the f32 residual (round 5: gp_gemm_planes256_park)
-    w2hi, w2lo = split_planes_x64(f32(W2))
-    for parts in (2, 4, 8):
-        Xp = X1.clone()
-        _lib.call("gp_gemm_planes256_park", _lib.ptr(w2hi), _lib.ptr(w2lo), _lib.ptr(fhi), _lib.ptr(flo), _lib.ptr(Xp), _lib.i(Mpad), _lib.i(C),
-                  _lib.i(Mpad), _lib.i(Mtok), _lib.i(vit.mlp_dim), _lib.ptr(f32(b2)), _lib.ptr(f32(ls2)), _lib.f(os_), _lib.i(parts), _lib.ptr(ws),
-                  ctypes.c_size_t(nb), st())
-        torch.cuda.synchronize()
-        report(f"  fc2 branch, K in {parts} parts", (Xp - X1).t().double(), ref - x1_64, alt - X1.t())
     _lib.check_status()
 
     print(f"ViT-L layer {L}, {B} crops ({Mtok} tokens): per-stage error vs float64 on the same inputs, rms relative to the stage output's rms")

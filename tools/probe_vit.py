@@ -5,6 +5,8 @@ import torch
 from gigapose_amd.vit import Dinov2ViT
 from gigapose_amd import _lib
 
+_lib.use_probe_library()   # hooks / traced builds / error words live in libgigapose_hip_probe.so (include/gigapose_hip_probe.h)
+
 dev = "cuda"
 def timeit(fn, iters=5, warm=2):
     for _ in range(warm): fn()

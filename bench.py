@@ -129,11 +129,14 @@ def matrix_ceiling_on_this_socket():
         return None
     out = {}
     for ln in r.stdout.splitlines():
-        if "TFLOP/s" not in ln:
+        if ln.startswith("#") or "TFLOP/s" not in ln or "clk" not in ln:
             continue
-        tf = float(ln.split("TFLOP/s")[0].split()[-1])
-        mhz = float(ln.split("clk")[1].split()[0])
-        watts = float(ln.split("smi:")[1].split()[0]) if "smi:" in ln else 0.0
+        try:
+            tf = float(ln.split("TFLOP/s")[0].split()[-1])
+            mhz = float(ln.split("clk")[1].split()[0])
+            watts = float(ln.split("smi:")[1].split()[0]) if "smi:" in ln else 0.0
+        except (IndexError, ValueError):   # a reported extra: never lose the bench line over it
+            continue
         rec = {"tflops": round(tf, 1), "in_kernel_clock_mhz": round(mhz), "socket_watts": round(watts)}
         if ln.startswith("R  same") and " zeros " in ln:
             out["mfma_only_zero_operands"] = rec

@@ -189,26 +189,44 @@ __device__ __forceinline__ void match_epilogue(SM& sm, f32x16 (&acc)[2][4], int 
     }
 
     // ---- column maxima (over t, first max wins)   torch.max(sim, dim=2)  (matching.py:241)
+    // PERM: LDS rows are not in patch order, so the candidate is tracked by its PATCH index and an exact tie between positive values
+    // goes to the lower patch.  Round 6: the patch indices of this lane's 32 rows are read ONCE into registers and every step is a
+    // branch-free select (round 5 looked t_of[] up in LDS inside the 128-step loop behind short-circuit branches: the maxima phase of
+    // a full tile took 16-20 us against 6.7 us before compaction existed, profiles/r06_match.txt).  Same total order, same bits.
+    int tp[32];
+    if constexpr (PERM) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {   // rows t_lane + 32 mi + 8 r4 + 0..3: four consecutive shorts = one 8-byte LDS read
+                typedef short s16x4 __attribute__((ext_vector_type(4)));
+                const s16x4 q4 = *reinterpret_cast<const s16x4*>(&sm.t_of[t_lane + 32 * mi + 8 * r4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tp[mi * 16 + 4 * r4 + e] = (int)q4[e];
+            }
+    }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         if (PERM && (ni >= wt.ni_n || !wt.active)) continue;  // wave-uniform
         float bv = acc[0][ni][0];
-        int bi = t_lane;
+        int bi = PERM ? tp[0] : t_lane;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             if (PERM && mi >= wt.mi_n) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {  // (mi, r) ascending == t ascending for this lane (unpermuted tile)
                 const float x = acc[mi][ni][r];
-                const int row = t_lane + 32 * mi + (r & 3) + 8 * (r >> 2);
-                if constexpr (PERM) {  // LDS rows are not in patch order: an exact tie between positive values goes to the lower patch
-                    if (x > bv || (x == bv && (x > 0.f || !compact) && sm.t_of[row] < sm.t_of[bi])) { bv = x; bi = row; }
+                if constexpr (PERM) {
+                    const int tq = tp[mi * 16 + r];
+                    const bool take = (x > bv) | ((x == bv) & ((x > 0.f) | (compact == 0)) & (tq < bi));
+                    bv = take ? x : bv;
+                    bi = take ? tq : bi;
                 } else {
+                    const int row = t_lane + 32 * mi + (r & 3) + 8 * (r >> 2);
                     if (x > bv) { bv = x; bi = row; }
                 }
             }
         }
-        if constexpr (PERM) bi = sm.t_of[bi];
         const float ov = __shfl_xor(bv, 32);
         const int oi = __shfl_xor(bi, 32);
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }

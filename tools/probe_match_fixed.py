@@ -45,8 +45,23 @@ for C in (32, 64, 256, 1024):
     t = e0.elapsed_time(e1) / 5
     print(f"C={C:5d}: {t*1e3:8.1f} us per launch = {t*1e3*256/(B*N):6.1f} us per tile per CU ({C//32} k-steps)")
 
-for C in (32, 1024):
-    m, q, qm, bank, lab = setup(C)
+def setup_disc(C):
+    """The benchmark's kind of masks (disc-shaped: ~5 x 5 live 32 x 32 blocks per tile) with planted, graded matches."""
+    from gigapose_testing import synthetic as syn
+
+    case = syn.matcher_case(seed=5, B=B, O=1, N=N, C=C)
+    m = LocalSimilarity(5, 0.5, 3)
+    m.numerics = "split"
+    bank = MatchBank(torch.from_numpy(case["src_feats"]).to(dev), torch.from_numpy(case["src_masks"]).to(dev), "split")
+    q = m.normalize(torch.from_numpy(case["tar_feat"]).to(dev).view(B, C, 256))
+    return m, q, patch_grid_mask(torch.from_numpy(case["tar_mask"]).to(dev)), bank, torch.from_numpy(case["labels"]).to(dev).int() - 0
+
+
+for C, make in ((32, setup), (1024, setup), (1024, setup_disc)):
+    m, q, qm, bank, lab = make(C)
+    if make is setup_disc:
+        lab = torch.zeros(B, dtype=torch.int32, device=dev)
+        print("\n--- disc masks (the benchmark's kind): live-patch compaction at work")
     idx = torch.empty(B, N, 256, dtype=torch.uint8, device=dev)
     sc = torch.empty(B, N, 256, device=dev)
     ma = torch.empty(B, N, 256, device=dev)

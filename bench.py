@@ -730,6 +730,7 @@ def main():
                 model.template_datas, model.match_banks, model.pose_recovery = {}, {}, {}
                 if dist.is_initialized():
                     dist.destroy_process_group()
+                model.set_template_data("syn")   # the unsharded bank again (the roofline block below reads its masks)
             model.log_dir, model.accumulate_crops = keep_dir, keep_acc
             if "value" in dropin_flow.get("sharded_forced_world1", {}):
                 dropin_flow["sharded_over_b64_rate"] = round(dropin_flow["sharded_forced_world1"]["value"] / (world * args.batch * args.steps / dt), 3)

@@ -132,3 +132,61 @@ def test_sharded_test_step_over_rccl_with_forced_collectives(tmp_path, monkeypat
     finally:
         dist.destroy_process_group()
     _compare(want, got, sizes, numerics, "rccl world 1")
+
+
+def _replica_worker(rank, world, port, tmp):
+    """Unsharded replicas + `image_ownership: round_robin`: both ranks are fed EVERY image (the reference's loader has no split_by_node),
+    each computes idx % world == rank, rank 0 merges after the barrier of on_test_epoch_end."""
+    import torch.distributed as dist
+
+    from gigapose_testing import factory
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tset = factory.TemplateSet(2, 11, seed=70)
+        model = factory.build_model("dinov2_vits14", k=5, device=dev, seed=5, log_dir=os.path.join(tmp, "owned"))
+        model.set_numerics("chain")
+        model.global_rank = rank
+        model.image_ownership, model.accumulate_crops = "round_robin", 16
+        model.test_dataset_name, model.run_id = "syn", "r0"
+        model.template_datasets = {"syn": tset}
+        model.set_template_data("syn")
+        sizes = [5, 9, 3, 7, 12, 4]
+        for i, n in enumerate(sizes):
+            assert model.test_step(_image(tset, 300 + i, n, 20 + i, dev), i) == 0
+        model.on_test_epoch_end()
+        if rank == 0:   # every image's file is there when rank 0 merges (the barrier), each written once, and the csv holds them all
+            pred = os.path.join(tmp, "owned", "predictions")
+            assert sorted(f for f in os.listdir(pred) if f.endswith(".npz")) == sorted(f"{i}.npz" for i in range(len(sizes)))
+            csv = [f for f in sorted(os.listdir(pred)) if f.endswith(".csv")][0]
+            assert len(pd.read_csv(os.path.join(pred, csv))) == sum(sizes)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_round_robin_image_ownership_with_two_replicas_on_one_gpu(tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_replica_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    # the same images through ONE process: identical files (chain numerics: a crop's result does not depend on its batch)
+    from gigapose_testing import factory
+
+    dev = torch.device("cuda", 0)
+    tset = factory.TemplateSet(2, 11, seed=70)
+    model = factory.build_model("dinov2_vits14", k=5, device=dev, seed=5, log_dir=str(tmp_path / "single"))
+    model.set_numerics("chain")
+    model.accumulate_crops, model.test_dataset_name, model.run_id = 0, "syn", "r0"
+    model.template_datasets = {"syn": tset}
+    model.set_template_data("syn")
+    sizes = [5, 9, 3, 7, 12, 4]
+    for i, n in enumerate(sizes):
+        model.test_step(_image(tset, 300 + i, n, 20 + i, dev), i)
+    for i in range(len(sizes)):
+        a, b = _load(str(tmp_path / "owned"), i), _load(str(tmp_path / "single"), i)
+        for key in a:
+            if key != "time":
+                assert a[key].tobytes() == b[key].tobytes(), f"image {i}: {key}"

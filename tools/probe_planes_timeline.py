@@ -26,6 +26,17 @@ def timeit(fn, iters=10, warm=3):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
+def timeit_cold(fn, iters=10):
+    """Each launch after 2 x 400 MB of unrelated traffic (the 256 MB Infinity Cache and the L2s hold nothing of the GEMM's operands or
+    of the residual its epilogue reads: the state a launch finds inside the ViT, where ~650 MB pass between two uses of X)."""
+    a_, b_ = torch.empty(100 << 20, device=dev), torch.zeros(100 << 20, device=dev)
+    tot = 0.0
+    for _ in range(iters):
+        a_.copy_(b_)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    return tot / iters * 1e3
 torch.manual_seed(0)
 if os.environ.get("PAR_MIN_STEPS"):   # parallel split-K (fewer tiles than slots): at least this many k-steps per slot of a split tile
     lib.gp_gemm_planes256_set_par(int(os.environ["PAR_MIN_STEPS"]))
@@ -45,6 +56,9 @@ for (nw, K, name, epi) in [(3072, 1024, "qkv", 7), (1024, 1024, "proj", 3), (409
     def plain(): _lib.call("gp_gemm_planes256_scaled", *args[:-1], _lib.f(8.0), _lib.ptr(None), args[-1], ctypes.c_size_t(NB), _lib.stream_ptr())
     def traced(): _lib.call("gp_gemm_planes256_trace", *args, _lib.ptr(trace), _lib.stream_ptr())
     t_plain = timeit(plain)
+    if os.environ.get("COLD"):
+        t_one = timeit_cold(plain, 1) * 0 + sum(timeit(plain, 1, 0) for _ in range(10)) / 10   # one launch per event pair, caches warm
+        print(f"{name:5s} event-timed one launch at a time: caches warm {t_one:6.1f} us, after 800 MB of other traffic {timeit_cold(plain):6.1f} us", flush=True)
     for _ in range(20): plain()          # sustained clocks
     traced(); torch.cuda.synchronize()
     t = trace.cpu().numpy().reshape(256, 32).astype(np.int64)

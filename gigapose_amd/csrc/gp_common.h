@@ -84,6 +84,55 @@ struct GpProfScope {
     hipStream_t st_;
 };
 
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) of the split kernels' epilogues (fc1), scaled by 2 hs (hs = 0.5: GELU itself; hs = half the plane
+// scale folds an activation plane's power-of-two scaling into it, bit for bit).  Form (round 6): erfc(|x| / sqrt 2) = 2^-Q(z), z = min(|x|, 9),
+// Q a degree-8 polynomial without constant term fitted (weighted minimax, tools/fit_gelu.py) to -log2 erfc so that the error of GELU is uniform
+// in |x| + 1; then 2 hs GELU = (a + |a|) - |a| E with a = hs x, E = 2^-Q: ONE fma covers both signs -- x >= 0: 2a - aE (a single rounding of the
+// exact value), x < 0: a E, no cancellation.  12 vector instructions + v_exp_f32 per element where the round-2 form (erfc = t P9(t) exp(-z^2),
+// t = 1 / (1 + 0.3275911 z): 20 + v_rcp_f32 + v_exp_f32) spent the fc1 tile epilogue's 16.6 us on the vector pipes; max |error| / (|x| + 1) over
+// [-12, 12] in f32: 4.9e-8 (the round-2 form: 7.0e-8, f32 0.5 x (1 + erf) with an exact erf: 8.2e-8), rms on N(0, 2) inputs 3.6e-8 (4.5e-8).
+// z is clamped, so |x| > 9 returns x or -|x| 2^-64; NaN and inf come out as NaN (the plane epilogues' range guard counts both).
+__device__ __forceinline__ float gp_gelu_scaled(float x, float hs)
+{
+    const float z = __builtin_fminf(__builtin_fabsf(x), 9.0f);
+    float p = 2.3157908378749728e-06f;
+    p = __builtin_fmaf(p, z, -3.3171934239110258e-05f);
+    p = __builtin_fmaf(p, z, 0.00015670828855028176f);
+    p = __builtin_fmaf(p, z, 0.00020827152112870692f);
+    p = __builtin_fmaf(p, z, -0.0071571907367062922f);
+    p = __builtin_fmaf(p, z, 0.05256192828655367f);
+    p = __builtin_fmaf(p, z, 0.45918599081344252f);
+    p = __builtin_fmaf(p, z, 1.151107890162735f);
+    const float e = __builtin_amdgcn_exp2f(-(p * z));   // erfc(|x| / sqrt 2), Q <= 64: a normal number
+    const float a = hs * x;
+    return __builtin_fmaf(-__builtin_fabsf(a), e, a + __builtin_fabsf(a));
+}
+
+// The same for two elements, bit for bit, written on 2-vectors so that the polynomial issues as v_pk_fma_f32 (two lanes' worth per issue slot:
+// 7.5 + v_exp_f32 instructions per element instead of 12.5; the hot caller is the fc1 tile epilogue of gp_split256.hip).
+typedef float gp_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gp_f32x2 gp_gelu_scaled2(gp_f32x2 x, float hs)
+{
+    gp_f32x2 z;
+    z[0] = __builtin_fminf(__builtin_fabsf(x[0]), 9.0f);
+    z[1] = __builtin_fminf(__builtin_fabsf(x[1]), 9.0f);
+    const auto k = [](float c) { return gp_f32x2{c, c}; };
+    gp_f32x2 p = k(2.3157908378749728e-06f);
+    p = __builtin_elementwise_fma(p, z, k(-3.3171934239110258e-05f));
+    p = __builtin_elementwise_fma(p, z, k(0.00015670828855028176f));
+    p = __builtin_elementwise_fma(p, z, k(0.00020827152112870692f));
+    p = __builtin_elementwise_fma(p, z, k(-0.0071571907367062922f));
+    p = __builtin_elementwise_fma(p, z, k(0.05256192828655367f));
+    p = __builtin_elementwise_fma(p, z, k(0.45918599081344252f));
+    p = __builtin_elementwise_fma(p, z, k(1.151107890162735f));
+    const gp_f32x2 q = p * z;
+    const gp_f32x2 a = x * hs;
+    gp_f32x2 r;
+    r[0] = __builtin_fmaf(-__builtin_fabsf(a[0]), __builtin_amdgcn_exp2f(-q[0]), a[0] + __builtin_fabsf(a[0]));
+    r[1] = __builtin_fmaf(-__builtin_fabsf(a[1]), __builtin_amdgcn_exp2f(-q[1]), a[1] + __builtin_fabsf(a[1]));
+    return r;
+}
+
 // MFMA 32x32x2 f32 C/D fragment map (guide section 3): lane l, register r in [0,16):
 //   col = l & 31,  row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
 __device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

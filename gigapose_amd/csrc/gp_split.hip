@@ -69,28 +69,8 @@ struct SplitArgs {
     const int* j_limit;  // optional device word: tiles whose first column is >= *j_limit have nothing to compute and return (gp_ist.hip: compacted rows)
 };
 
-// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) without libm's erff (which costs 0.15 ms of the 0.66 ms fc1 launch at ViT-L, B=64):
-// erfc(z) = t P9(t) exp(-z^2), t = 1 / (1 + 0.3275911 z), z = |x| / sqrt 2, with P9 a degree-9 least-squares fit of
-// erfcx on [0, 6.2] (|error| < 1e-8 on erfc, fitted by tools' offline script); 1 + erf = erfc(z) for x < 0 and
-// 2 - erfc(z) for x >= 0 -- no cancellation in the negative tail.  In f32 the result is within 1.2e-7 (|x| + 1) of the
-// exact value over [-8, 8] (torch's f32 GELU: 2.8e-7).
-__device__ __forceinline__ float gelu_fast(float x)
-{
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = 0.02651038324816011f;
-    p = fmaf(p, t, -0.284242067130941f);
-    p = fmaf(p, t, 0.8274675429718052f);
-    p = fmaf(p, t, -0.8329329722108324f);
-    p = fmaf(p, t, 0.7896692586773671f);
-    p = fmaf(p, t, -0.14005398441300523f);
-    p = fmaf(p, t, 0.25548806601570556f);
-    p = fmaf(p, t, 0.17245176856740801f);
-    p = fmaf(p, t, 0.18564199446374482f);
-    const float c = p * t * __expf(-z * z);  // erfc(z)
-    return 0.5f * x * (x >= 0.f ? 2.0f - c : c);
-}
-__device__ __forceinline__ float gelu_erf_s(float x) { return gelu_fast(x); }
+// GELU: gp_common.h (gp_gelu_scaled), shared with gp_split256.hip
+__device__ __forceinline__ float gelu_erf_s(float x) { return gp_gelu_scaled(x, 0.5f); }
 
 // probe state (tools/probe_split.py; TIMING instantiation only)
 __device__ unsigned long long g_split_clk[4][5];         // [wave][phase] cycle totals of one mid-grid block

@@ -50,28 +50,8 @@ struct Args256 {
 };
 
 __device__ __forceinline__ int toff(int row, int kc) { return row * TROW + ((kc ^ ((row >> 2) & 3)) << 3); }
-// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) without libm's erff (which costs 0.15 ms of the 0.66 ms fc1 launch at ViT-L, B=64):
-// erfc(z) = t P9(t) exp(-z^2), t = 1 / (1 + 0.3275911 z), z = |x| / sqrt 2, with P9 a degree-9 least-squares fit of
-// erfcx on [0, 6.2] (|error| < 1e-8 on erfc, fitted by tools' offline script); 1 + erf = erfc(z) for x < 0 and
-// 2 - erfc(z) for x >= 0 -- no cancellation in the negative tail.  In f32 the result is within 1.2e-7 (|x| + 1) of the
-// exact value over [-8, 8] (torch's f32 GELU: 2.8e-7).
-__device__ __forceinline__ float gelu_fast(float x)
-{
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = 0.02651038324816011f;
-    p = fmaf(p, t, -0.284242067130941f);
-    p = fmaf(p, t, 0.8274675429718052f);
-    p = fmaf(p, t, -0.8329329722108324f);
-    p = fmaf(p, t, 0.7896692586773671f);
-    p = fmaf(p, t, -0.14005398441300523f);
-    p = fmaf(p, t, 0.25548806601570556f);
-    p = fmaf(p, t, 0.17245176856740801f);
-    p = fmaf(p, t, 0.18564199446374482f);
-    const float c = p * t * __expf(-z * z);  // erfc(z)
-    return 0.5f * x * (x >= 0.f ? 2.0f - c : c);
-}
-__device__ __forceinline__ float gelu_x(float x) { return gelu_fast(x); }
+// GELU: gp_common.h (gp_gelu_scaled), shared with gp_split.hip
+__device__ __forceinline__ float gelu_x(float x) { return gp_gelu_scaled(x, 0.5f); }
 
 // W [n][K] f32 (PyTorch [out][in]) -> planes hi = f16(64 w), lo = f16(64 w - hi), same shape
 __global__ __launch_bounds__(256) void split256_weights_kernel(const float* __restrict__ W, size_t count, _Float16* __restrict__ hi,
@@ -537,23 +517,8 @@ __device__ __forceinline__ float sum8_lanes(float v)
     v = v + dpp_mov<0x141>(v);  // row_half_mirror: lane i <- lane 7 - i of its group of 8 (every lane of a quad holds the quad's sum)
     return v;
 }
-// 2 hs * gelu_fast(x), bit for bit (the plane scale folded into the exact 0.5 x); hs = half the plane scale (4 for the default x 8)
-__device__ __forceinline__ float gelu_fast_x8(float x, float hs = 0.5f * kActScale)
-{
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = 0.02651038324816011f;
-    p = fmaf(p, t, -0.284242067130941f);
-    p = fmaf(p, t, 0.8274675429718052f);
-    p = fmaf(p, t, -0.8329329722108324f);
-    p = fmaf(p, t, 0.7896692586773671f);
-    p = fmaf(p, t, -0.14005398441300523f);
-    p = fmaf(p, t, 0.25548806601570556f);
-    p = fmaf(p, t, 0.17245176856740801f);
-    p = fmaf(p, t, 0.18564199446374482f);
-    const float c = p * t * __expf(-z * z);
-    return hs * x * (x >= 0.f ? 2.0f - c : c);
-}
+// 2 hs * gelu_x(x), bit for bit (the plane scale folded into the exact 0.5 x); hs = half the plane scale (4 for the default x 8)
+__device__ __forceinline__ float gelu_fast_x8(float x, float hs = 0.5f * kActScale) { return gp_gelu_scaled(x, hs); }
 
 // The plane epilogues 6 / 7: planes O[j][i] (x 8, hi + lo) of bias_i + out_scale acc [6: through GELU].  Round h = columns 64 h .. 64 h + 63
 // of the wave tile, all 64 rows: per plane 64 token rows of 128 bytes in the wave's 16 KiB of LDS, the 8-byte pieces a lane produces
@@ -589,9 +554,11 @@ __device__ __forceinline__ void epilogue_planes_thin(const ArgsP& a, f32x16 (&ac
                     const int sw = (jl & 7) << 1;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = __builtin_fmaf(acc[mi][ni][4 * r4 + e], A, bq[e]);
-                        v[e] = kGelu ? gelu_fast_x8(x, hs) : x;
+                    for (int e = 0; e < 4; e += 2) {
+                        gp_f32x2 x = {__builtin_fmaf(acc[mi][ni][4 * r4 + e], A, bq[e]), __builtin_fmaf(acc[mi][ni][4 * r4 + e + 1], A, bq[e + 1])};
+                        if (kGelu) x = gp_gelu_scaled2(x, hs);   // pairs: the polynomial as v_pk_fma_f32
+                        v[e] = x[0];
+                        v[e + 1] = x[1];
                     }
                     u32x2 oh, ol;
                     oh[0] = pack_hi_pair(v[0], v[1]);

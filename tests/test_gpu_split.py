@@ -503,6 +503,36 @@ def test_planes256_gemm_epilogues():
     np.testing.assert_allclose(back.t().cpu(), (base + bias[:I, None].double()).cpu(), **tol)
 
 
+def test_gelu_epilogue_on_a_grid_vs_float64():
+    """The GELU of the plane kernels' epilogues (gp_common.h: gp_gelu_scaled, erfc = 2^-Q(|x|), one fma for both signs) evaluated on a grid:
+    acc = 1 * x exactly (A = e_0, B = the grid in column 0), so D[i][j] = GELU(x~_j) with x~ the 22-bit plane value of x.  Both the scalar form
+    (f32 epilogue 2) and the packed form inside the plane epilogue 6; the bound is |error| <= 7e-8 (|x| + 1) -- the f32 rounding of the result
+    alone is 4.8e-8 there -- plus, for the planes, their own 2^-21 relative representation."""
+    torch.manual_seed(11)
+    I, J, K = 4096, 4096, 32          # 256 whole tiles: the data-parallel launch of the ViT
+    xs = torch.cat([torch.linspace(-12.0, 12.0, J - 16, device=DEV, dtype=torch.float64).float(),
+                    torch.tensor([0.0, -0.0, 1e-30, -1e-30, 9.0, -9.0, 9.5, -9.5, 50.0, -50.0, 1000.0, -1000.0, 1e-4, -1e-4, 0.5, -0.5], device=DEV)])
+    A = torch.zeros(I, K, device=DEV)
+    A[:, 0] = 1.0
+    Bm = torch.zeros(J, K, device=DEV)
+    Bm[:, 0] = xs
+    hi = (xs * 8.0).half()
+    x22 = (hi.double() + (xs * 8.0 - hi.float()).half().double()) / 8.0          # what the planes carry
+    want = x22 * 0.5 * (1.0 + torch.erf(x22 / 2.0 ** 0.5))
+    far = x22 < -5.0                                                               # 1 + erf cancels in float64 out there: erfc
+    want[far] = x22[far] * 0.5 * torch.special.erfc(-x22[far] / 2.0 ** 0.5)
+    bias = torch.zeros(I, device=DEV)
+    D = planes256_gemm(A, Bm, 2, bias).double()                                    # f32 out, scalar form
+    e2 = ((D - want[None, :]).abs() / (x22.abs()[None, :] + 1.0)).max().item()
+    ohi, olo = planes256_gemm(A, Bm, 6, bias)                                      # planes out (x 8), packed form
+    back = (ohi.double() + olo.double()) / 8.0                                     # [J][I]
+    e6 = (((back - want[:, None]).abs() - 2.0 ** -21 * want.abs()[:, None]).clamp_min(0.0) / (x22.abs()[:, None] + 1.0)).max().item()
+    print(f"GELU epilogues vs float64 on [-12, 12] + extremes: max |err| / (|x| + 1): f32 out {e2:.2e}, planes out (beyond their 2^-21) {e6:.2e}")
+    assert e2 < 7e-8 and e6 < 7e-8
+    assert torch.equal(D[0], D[I - 1]) and torch.isfinite(D).all()
+    assert (D[0][x22 >= 9.0] == x22[x22 >= 9.0]).all() and (D[0][x22 <= -9.0].abs() < 1e-15).all()   # clamped tails: x and -|x| 2^-63
+
+
 @pytest.mark.parametrize("I,J,jv,K", [(1024, 16640, 16448, 64), (2048, 8448, 8224, 96), (1024, 16640, 16385, 32), (4096, 4352, 4350, 64),
                                       (1024, 16640, 16448, 1024)])
 def test_planes256_ragged_rows(I, J, jv, K):

@@ -363,7 +363,7 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)  // value held by
 // in two rounds, so that every global access is 16 bytes per lane over full 128-byte lines (64 instead of 512
 // instructions per lane for the residual epilogue).  Wave-private: no workgroup barrier between the rounds (LDS
 // operations of one wave execute in order).  Same arithmetic per element as before: results are bit-identical.
-template <int EPI, int NJ = 4>
+template <int EPI, int NJ = 4, bool PIPE = true>
 __device__ __forceinline__ void epilogue_f32_lds(const ArgsP& a, f32x16 (&acc)[2][NJ], float* __restrict__ wl, int i_base, int j_base, int ln)
 {
     const int l31 = ln & 31, half = ln >> 5;
@@ -418,57 +418,73 @@ __device__ __forceinline__ void epilogue_f32_lds(const ArgsP& a, f32x16 (&acc)[2
         if (EPI == XEPI_BIAS_I_SCALE_RES) scale_l = a.scale[i_base + ln];
         f32x4 bias_j = {0.f, 0.f, 0.f, 0.f};
         if (EPI == XEPI_BIAS_J) bias_j = *reinterpret_cast<const f32x4*>(a.bias + j_base + 4 * l31);
-        const unsigned j = (unsigned)(j_base + 4 * l31);
+        // Rows as buffer accesses: one lane offset (column piece + the lane half's row) and a scalar row offset per item -- 64-bit flat
+        // addresses cost an address pair per item in flight.
+        constexpr bool kRes = EPI == XEPI_BIAS_I_SCALE_RES;
+        const __amdgpu_buffer_rsrc_t r_d = __builtin_amdgcn_make_buffer_rsrc((void*)a.D, 0, 0x7ffffff0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc((void*)(kRes ? a.res : a.D), 0, 0x7ffffff0, 0x00020000);
+        const unsigned v_d = ((unsigned)half * (unsigned)a.ldd + (unsigned)(j_base + 4 * l31)) * 4u;
+        const unsigned v_res = ((unsigned)half * (unsigned)a.ldr + (unsigned)(j_base + 4 * l31)) * 4u;
+        // The tile's 32 items (row pairs) in eight batches of four.  Residual rows (round 6): batch b + 1 is requested BEFORE batch b is
+        // computed and stored, into the other half of rs -- the wait for a batch then allows the previous batch's stores to be outstanding.
+        // (Round 2's form, eight loads / wait / eight stores / eight loads, made every batch a full round trip INCLUDING the acknowledgment of
+        // the stores before it -- s_waitcnt vmcnt(0) four times per tile, 14-16 us per proj / fc2 tile epilogue.)  In place (D == res) this is
+        // safe as before: an item reads and writes only its own row piece, and its load precedes its store in program order.
+        f32x4 rs[2][4];
+        auto res_load = [&](int b) __attribute__((always_inline)) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            // round mi: rows 32 mi .. 32 mi + 31 of the wave tile as wl[32][128] (writes: a lane group covers 32 consecutive
-            // words of a row; reads: 16 bytes per lane, a wave covers two whole rows -- both conflict-free without padding)
+            for (int u = 0; u < 4; ++u) {
+                const unsigned row0 = (unsigned)(i_base + 32 * (b >> 2) + 2 * (4 * (b & 3) + u));
+                rs[b & 1][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, v_res, row0 * (unsigned)a.ldr * 4u, 0));
+            }
+        };
+        // PIPE = false (the parallel split-K builds, which spill already): round 2's form, eight loads, then their two batches
+        if (kRes && PIPE) res_load(0);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+        for (int b = 0; b < 8; ++b) {
+            const int mi = b >> 2;
+            if ((b & 3) == 0) {
+                // round mi: rows 32 mi .. 32 mi + 31 of the wave tile as wl[32][128] (writes: a lane group covers 32 consecutive
+                // words of a row; reads: 16 bytes per lane, a wave covers two whole rows -- both conflict-free without padding)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) wl[frag_row(r, ln) * 128 + 32 * ni + l31] = acc[mi][ni][r];
-            // residual rows of this round in two batches of eight 16-byte loads, all in flight before the first is used: D may be
-            // the residual buffer itself (x += ...), so hipcc keeps every load behind the previous item's store -- one exposed
-            // memory round trip per item, 8-10 us of an 18-22 us tile epilogue (profiles/r02_planes_timeline.txt, proj / fc2).
-            // Safe in place: item `it` reads and writes only its own row piece.
+                for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int it0 = 0; it0 < 16; it0 += 8) {
-                f32x4 rs[8];
-                if (EPI == XEPI_BIAS_I_SCALE_RES) {
+                    for (int r = 0; r < 16; ++r) wl[frag_row(r, ln) * 128 + 32 * ni + l31] = acc[mi][ni][r];
+            }
+            if (kRes && PIPE && b + 1 < 8) {
+                res_load(b + 1);
+                asm volatile("" : "+v"(rs[(b + 1) & 1][0]), "+v"(rs[(b + 1) & 1][1]), "+v"(rs[(b + 1) & 1][2]), "+v"(rs[(b + 1) & 1][3]));
+            }
+            if (kRes && !PIPE && (b & 1) == 0) {
+                res_load(b);
+                res_load(b + 1);
+                asm volatile("" : "+v"(rs[0][0]), "+v"(rs[0][1]), "+v"(rs[0][2]), "+v"(rs[0][3]), "+v"(rs[1][0]), "+v"(rs[1][1]), "+v"(rs[1][2]), "+v"(rs[1][3]));
+            }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const unsigned i = (unsigned)(i_base + 32 * mi + 2 * (it0 + u) + half);
-                        rs[u] = *reinterpret_cast<const f32x4*>(a.res + i * (unsigned)a.ldr + j);
-                    }
-                    asm volatile("" : "+v"(rs[0]), "+v"(rs[1]), "+v"(rs[2]), "+v"(rs[3]), "+v"(rs[4]), "+v"(rs[5]), "+v"(rs[6]), "+v"(rs[7]));
+            for (int u = 0; u < 4; ++u) {
+                const int it = 4 * (b & 3) + u, row = 2 * it + half;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(wl + row * 128 + 4 * l31);
+                float bb = 0.f, sc = 0.f;
+                if (kBiasI) {
+                    const float b0 = lane_bcast(bias_l, 32 * mi + 2 * it), b1 = lane_bcast(bias_l, 32 * mi + 2 * it + 1);
+                    bb = half ? b1 : b0;
                 }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int it = it0 + u, row = 2 * it + half;
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(wl + row * 128 + 4 * l31);
-                    const unsigned i = (unsigned)(i_base + 32 * mi + row);
-                    float b = 0.f, sc = 0.f;
-                    if (kBiasI) {
-                        const float b0 = lane_bcast(bias_l, 32 * mi + 2 * it), b1 = lane_bcast(bias_l, 32 * mi + 2 * it + 1);
-                        b = half ? b1 : b0;
-                    }
-                    if (EPI == XEPI_BIAS_I_SCALE_RES) {
-                        const float s0 = lane_bcast(scale_l, 32 * mi + 2 * it), s1 = lane_bcast(scale_l, 32 * mi + 2 * it + 1);
-                        sc = half ? s1 : s0;
-                    }
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = t[e] * a.out_scale;
-                        if (kBiasI) v = v + b;
-                        if (EPI == XEPI_BIAS_J) v = v + bias_j[e];
-                        if (EPI == XEPI_BIAS_I_GELU) v = gelu_x(v);
-                        if (EPI == XEPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
-                        if (EPI == XEPI_BIAS_I_SCALE_RES) v = rs[u][e] + sc * v;
-                        o[e] = v;
-                    }
-                    *reinterpret_cast<f32x4*>(a.D + i * (unsigned)a.ldd + j) = o;
+                if (kRes) {
+                    const float s0 = lane_bcast(scale_l, 32 * mi + 2 * it), s1 = lane_bcast(scale_l, 32 * mi + 2 * it + 1);
+                    sc = half ? s1 : s0;
                 }
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = t[e] * a.out_scale;
+                    if (kBiasI) v = v + bb;
+                    if (EPI == XEPI_BIAS_J) v = v + bias_j[e];
+                    if (EPI == XEPI_BIAS_I_GELU) v = gelu_x(v);
+                    if (EPI == XEPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
+                    if (kRes) v = rs[b & 1][u][e] + sc * v;
+                    o[e] = v;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_d, v_d, (unsigned)(i_base + 32 * mi + 2 * it) * (unsigned)a.ldd * 4u, 0);
             }
         }
     }
@@ -527,8 +543,12 @@ __device__ __forceinline__ float gelu_fast_x8(float x, float hs = 0.5f * kActSca
 // profiles/r04_thin_epilogue_ab.txt): bias rows from 16-byte loads of exactly the rows a lane holds (no readlane + select), ONE fma for
 // scale + bias + the planes' x 8 (acc * out_scale is an exact power-of-two scaling, so fma(acc, 8 out_scale, 8 b) rounds where
 // (acc * out_scale + b) * 8 did), the pair conversions above, v_maximum3_f32 as the range guard, buffer stores.
-template <int EPI, int NJ = 4>
-__device__ __forceinline__ void epilogue_planes_thin(const ArgsP& a, f32x16 (&acc)[2][NJ], char* __restrict__ wl, int i_base, int j_base, int ln)
+// bias_w (round 6): the wave's 64 bias rows in LDS, parked there by the tile's prologue.  Read from global memory inside the rounds each of the
+// 16 row quads of a tile was a dependent round trip behind `s_waitcnt vmcnt(0)` -- which in the second round also waits for the first round's 16
+// stores to be acknowledged: the ISA showed load, wait, 8 ds_writes, load, wait, ... (the registers for hoisting 32 values do not exist at 235).
+template <int EPI, int NJ = 4, int RB = 4>
+__device__ __forceinline__ void epilogue_planes_thin(const ArgsP& a, f32x16 (&acc)[2][NJ], char* __restrict__ wl, int i_base, int j_base, int ln,
+                                                     const float* __restrict__ bias_w)
 {
     const int l31 = ln & 31, half = ln >> 5;
     constexpr bool kGelu = EPI == PEPI_GELU_PLANES;
@@ -544,7 +564,8 @@ __device__ __forceinline__ void epilogue_planes_thin(const ArgsP& a, f32x16 (&ac
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                f32x4 bq = *reinterpret_cast<const f32x4*>(a.bias + i_base + 32 * mi + 8 * r4 + 4 * half);
+                f32x4 bq = RB == 1 ? *reinterpret_cast<const f32x4*>(a.bias + i_base + 32 * mi + 8 * r4 + 4 * half)   // parallel split-K builds: as before
+                                   : *reinterpret_cast<const f32x4*>(bias_w + 32 * mi + 8 * r4 + 4 * half);
                 if (!kGelu) bq = bq * k8;
                 const int c8 = 8 * mi + 2 * r4 + half;  // 8-byte piece of the 128-byte row: rows 4 c8 .. 4 c8 + 3
 #pragma unroll
@@ -570,13 +591,22 @@ __device__ __forceinline__ void epilogue_planes_thin(const ArgsP& a, f32x16 (&ac
                     *reinterpret_cast<u32x2*>(wrow + 8192 + ((c8 ^ sw) << 3)) = ol;
                 }
             }
+        // RB = 4 row pieces in flight per lane (left to itself hipcc turns this into read, wait, store, read, ... on ONE register quad; RB = 1:
+        // that form, for the parallel split-K instantiations, which spill already)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int jl = 8 * it + (ln >> 3), c16 = ln & 7;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(wl + pl * 8192 + jl * 128 + ((c16 ^ (jl & 7)) << 4));
-                __builtin_amdgcn_raw_buffer_store_b128(v, pl ? r_lo : r_hi, v_pl, (unsigned)(64 * h + 8 * it) * (unsigned)a.ldo * 2u, 0);
+            for (int it0 = 0; it0 < 8; it0 += RB) {
+                u32x4 v[RB];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    const int jl = 8 * (it0 + u) + (ln >> 3), c16 = ln & 7;
+                    v[u] = *reinterpret_cast<const u32x4*>(wl + pl * 8192 + jl * 128 + ((c16 ^ (jl & 7)) << 4));
+                }
+                if constexpr (RB == 4) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+                for (int u = 0; u < RB; ++u)
+                    __builtin_amdgcn_raw_buffer_store_b128(v[u], pl ? r_lo : r_hi, v_pl, (unsigned)(64 * h + 8 * (it0 + u)) * (unsigned)a.ldo * 2u, 0);
             }
         }
     }
@@ -949,8 +979,13 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
             *reinterpret_cast<u32x4*>(L + P_BLO) = rg[6];
             if (NJ == 4) *reinterpret_cast<u32x4*>(L + P_BLO + 128 * TROW) = rg[7];
         };
+        float bias_v = 0.f;   // plane epilogues: the tile's 256 bias rows travel with the first slab and wait in LDS behind the operand buffers
+        if constexpr (kEpiPlanesOut<EPI> && !kParSplit)
+            if (tid < TB) bias_v = a.bias[i0 + tid];
         gload(0);
         stage(0);
+        if constexpr (kEpiPlanesOut<EPI> && !kParSplit)
+            if (tid < TB) reinterpret_cast<float*>(lds + 2 * TBUF)[tid] = bias_v;   // (the strip's rows: unused until strip_phase)
         __builtin_amdgcn_sched_barrier(0);
         if (ns > 1) gload(1);
         __syncthreads();
@@ -1092,9 +1127,9 @@ __global__ __launch_bounds__(TNT, 2) void gemm_planes256_kernel(const ArgsP a)
             __syncthreads();                // every wave has read its last operand fragments: the buffers are free
             char* wl = reinterpret_cast<char*>(lds) + (tid_ >> 6) * 16384;
             if constexpr (EPI == PEPI_GELU_PLANES || EPI == PEPI_BIAS_I_PLANES)
-                epilogue_planes_thin<EPI, NJ>(a, acc, wl, i0 + 64 * wr, j0 + 32 * NJ * wc, tid_ & 63);
+                epilogue_planes_thin<EPI, NJ, kParSplit ? 1 : 4>(a, acc, wl, i0 + 64 * wr, j0 + 32 * NJ * wc, tid_ & 63, reinterpret_cast<const float*>(lds + 2 * TBUF) + 64 * wr);
             else
-                epilogue_f32_lds<EPI, NJ>(a, acc, reinterpret_cast<float*>(wl), i0 + 64 * wr, j0 + 32 * NJ * wc, tid_ & 63);
+                epilogue_f32_lds<EPI, NJ, !kParSplit>(a, acc, reinterpret_cast<float*>(wl), i0 + 64 * wr, j0 + 32 * NJ * wc, tid_ & 63);
             __syncthreads();  // LDS buffer 0 is re-staged by the next segment's prologue
         }
         if (TIMING && a.trace && tid == 0 && seg < 7) a.trace[(size_t)p * 32 + 5 + 4 * seg] = wall_clock64();

@@ -340,12 +340,31 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
             float* wl = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + (tid_ >> 6) * 16384);
             constexpr int WC = 32 * NIW, QPR = 8 * NIW;  // f32 columns / 4-column quads per row of the wave tile
             float mx = 0.f;  // range guard: largest |8 x| written (v_maximum3_f32 propagates NaN)
+            // eval-BatchNorm alpha | beta of the channels a lane finishes: item `it` of a lane is quad (ln + 64 it) % QPR of its row -- ONE quad
+            // for 16 / 32 quads per row (NI = 2 / 4) -- so they are loaded once per tile.  (Round 6: read inside the item loop they were two
+            // 16-byte global loads + s_waitcnt vmcnt(0) PER ITEM -- the stores to the output planes may alias them as far as hipcc knows -- i.e.
+            // 16 dependent round trips per tile, each also waiting for the previous item's stores.)
+            // (24 quads per row, NI = 3: three quads per lane = 24 registers, which the 192-channel builds do not have -- 7 spilled when tried;
+            // they keep the loads in the loop.)
+            constexpr bool kHoist = 64 % QPR == 0;
+            f32x4 al_ = {1.f, 1.f, 1.f, 1.f}, be_ = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (kHoist) {
+                const int co_l = j0 + WC * wc + 4 * (ln % QPR);
+                if (a.alpha && co_l < a.Cout) {
+                    al_ = *reinterpret_cast<const f32x4*>(a.alpha + co_l);
+                    be_ = *reinterpret_cast<const f32x4*>(a.beta + co_l);
+                }
+            }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
                 for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) wl[frag_row(r, ln) * WC + 32 * ni + l31] = acc[mi][ni][r];
+                // one unconditional use in straight-line code: hipcc then waits for alpha | beta HERE (under the LDS writes above), once -- behind the
+                // items' `co < Cout` branches its wait-count pass assumes them pending at every join and emits vmcnt(0) per item, i.e. a wait for
+                // the previous item's stores
+                if (kHoist && mi == 0) asm volatile("" : "+v"(al_), "+v"(be_));
                 // residual planes: the loads of a round of RG items up front (RG x 2 x 8 bytes per lane in flight).  Loaded inside
                 // the item loop, one dependent 8-byte load per item, they cost 16 us of a 25 us tile tail (tools/probe_conv_timeline.py).
                 constexpr int RG = NIW == 2 ? 8 : (NIW == 3 ? 6 : 4);  // items per round (divides 4 NIW); fewer where the accumulators leave fewer registers
@@ -372,7 +391,7 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = tv[e] * kOutScale;
                             if (a.alpha) {
-                                const f32x4 al4 = *reinterpret_cast<const f32x4*>(a.alpha + co), be4 = *reinterpret_cast<const f32x4*>(a.beta + co);
+                                const f32x4 al4 = kHoist ? al_ : *reinterpret_cast<const f32x4*>(a.alpha + co), be4 = kHoist ? be_ : *reinterpret_cast<const f32x4*>(a.beta + co);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = v[e] * al4[e] + be4[e];
                             }
@@ -763,12 +782,31 @@ __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
             float* wl = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + (tid_ >> 6) * EPI_STRIDE);
             constexpr int WC = 32 * NIW, QPR = 8 * NIW;
             float mx = 0.f;  // range guard: largest |8 x| written (v_maximum3_f32 propagates NaN)
+            // eval-BatchNorm alpha | beta of the channels a lane finishes: item `it` of a lane is quad (ln + 64 it) % QPR of its row -- ONE quad
+            // for 16 / 32 quads per row (NI = 2 / 4) -- so they are loaded once per tile.  (Round 6: read inside the item loop they were two
+            // 16-byte global loads + s_waitcnt vmcnt(0) PER ITEM -- the stores to the output planes may alias them as far as hipcc knows -- i.e.
+            // 16 dependent round trips per tile, each also waiting for the previous item's stores.)
+            // (24 quads per row, NI = 3: three quads per lane = 24 registers, which the 192-channel builds do not have -- 7 spilled when tried;
+            // they keep the loads in the loop.)
+            constexpr bool kHoist = 64 % QPR == 0;
+            f32x4 al_ = {1.f, 1.f, 1.f, 1.f}, be_ = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (kHoist) {
+                const int co_l = j0 + WC * wc + 4 * (ln % QPR);
+                if (a.alpha && co_l < a.Cout) {
+                    al_ = *reinterpret_cast<const f32x4*>(a.alpha + co_l);
+                    be_ = *reinterpret_cast<const f32x4*>(a.beta + co_l);
+                }
+            }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
                 for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) wl[frag_row(r, ln) * WC + 32 * ni + l31] = acc[mi][ni][r];
+                // one unconditional use in straight-line code: hipcc then waits for alpha | beta HERE (under the LDS writes above), once -- behind the
+                // items' `co < Cout` branches its wait-count pass assumes them pending at every join and emits vmcnt(0) per item, i.e. a wait for
+                // the previous item's stores
+                if (kHoist && mi == 0) asm volatile("" : "+v"(al_), "+v"(be_));
                 constexpr int RG = NIW == 2 ? 8 : (NIW == 3 ? 6 : 4);
 #pragma unroll
                 for (int it0 = 0; it0 < 4 * NIW; it0 += RG) {
@@ -793,7 +831,7 @@ __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = tv[e] * kOutScale;
                             if (a.alpha) {
-                                const f32x4 al4 = *reinterpret_cast<const f32x4*>(a.alpha + co), be4 = *reinterpret_cast<const f32x4*>(a.beta + co);
+                                const f32x4 al4 = kHoist ? al_ : *reinterpret_cast<const f32x4*>(a.alpha + co), be4 = kHoist ? be_ : *reinterpret_cast<const f32x4*>(a.beta + co);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = v[e] * al4[e] + be4[e];
                             }

@@ -339,13 +339,15 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
             const int ln = tid_ & 63, l31 = ln & 31;
             float* wl = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + (tid_ >> 6) * 16384);
             constexpr int WC = 32 * NIW, QPR = 8 * NIW;  // f32 columns / 4-column quads per row of the wave tile
+            float* const AB_STASH = wl + 32 * WC;        // NI = 3: 768 bytes behind the 12 KiB of the wave's 16 KiB region that a round uses
+            static_assert(NIW != 3 || 32 * WC * 4 + 8 * QPR * 4 <= 16384, "alpha | beta stash must fit the wave's region");
             float mx = 0.f;  // range guard: largest |8 x| written (v_maximum3_f32 propagates NaN)
             // eval-BatchNorm alpha | beta of the channels a lane finishes: item `it` of a lane is quad (ln + 64 it) % QPR of its row -- ONE quad
             // for 16 / 32 quads per row (NI = 2 / 4) -- so they are loaded once per tile.  (Round 6: read inside the item loop they were two
             // 16-byte global loads + s_waitcnt vmcnt(0) PER ITEM -- the stores to the output planes may alias them as far as hipcc knows -- i.e.
             // 16 dependent round trips per tile, each also waiting for the previous item's stores.)
             // (24 quads per row, NI = 3: three quads per lane = 24 registers, which the 192-channel builds do not have -- 7 spilled when tried;
-            // they keep the loads in the loop.)
+            // there the wave parks its 24 + 24 quads in LDS behind its epilogue region -- AB_STASH -- and an item reads its two from there.)
             constexpr bool kHoist = 64 % QPR == 0;
             f32x4 al_ = {1.f, 1.f, 1.f, 1.f}, be_ = {0.f, 0.f, 0.f, 0.f};
             if constexpr (kHoist) {
@@ -354,6 +356,11 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
                     al_ = *reinterpret_cast<const f32x4*>(a.alpha + co_l);
                     be_ = *reinterpret_cast<const f32x4*>(a.beta + co_l);
                 }
+            } else if (a.alpha && ln < 2 * QPR) {   // lanes 0 .. 23: alpha quads, 24 .. 47: beta quads
+                const int qd_l = ln < QPR ? ln : ln - QPR, co_l = j0 + WC * wc + 4 * qd_l;
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (co_l < a.Cout) t = *reinterpret_cast<const f32x4*>((ln < QPR ? a.alpha : a.beta) + co_l);
+                *reinterpret_cast<f32x4*>(AB_STASH + 4 * ln) = t;
             }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(CNT, 2) void conv_planes_kernel(const ConvPArgs a)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = tv[e] * kOutScale;
                             if (a.alpha) {
-                                const f32x4 al4 = kHoist ? al_ : *reinterpret_cast<const f32x4*>(a.alpha + co), be4 = kHoist ? be_ : *reinterpret_cast<const f32x4*>(a.beta + co);
+                                const f32x4 al4 = kHoist ? al_ : *reinterpret_cast<const f32x4*>(AB_STASH + 4 * qd), be4 = kHoist ? be_ : *reinterpret_cast<const f32x4*>(AB_STASH + 4 * (QPR + qd));
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = v[e] * al4[e] + be4[e];
                             }
@@ -779,15 +786,18 @@ __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
             asm volatile("" : "+v"(tid_));
             __syncthreads();  // every wave has read its last operand fragments
             const int ln = tid_ & 63, l31 = ln & 31;
-            float* wl = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + (tid_ >> 6) * EPI_STRIDE);
+            constexpr int EPI_PITCH = EPI_STRIDE + (NIW == 3 ? 1024 : 0);   // NI = 3: + the wave's alpha | beta stash (a constant offset from wl: no register)
+            static_assert(LDS_HALFS * 2 >= 8 * EPI_PITCH, "the epilogue regions (+ stashes) must fit the operand buffers");
+            float* wl = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + (tid_ >> 6) * EPI_PITCH);
             constexpr int WC = 32 * NIW, QPR = 8 * NIW;
+            float* const AB_STASH = wl + EPI_STRIDE / 4;
             float mx = 0.f;  // range guard: largest |8 x| written (v_maximum3_f32 propagates NaN)
             // eval-BatchNorm alpha | beta of the channels a lane finishes: item `it` of a lane is quad (ln + 64 it) % QPR of its row -- ONE quad
             // for 16 / 32 quads per row (NI = 2 / 4) -- so they are loaded once per tile.  (Round 6: read inside the item loop they were two
             // 16-byte global loads + s_waitcnt vmcnt(0) PER ITEM -- the stores to the output planes may alias them as far as hipcc knows -- i.e.
             // 16 dependent round trips per tile, each also waiting for the previous item's stores.)
             // (24 quads per row, NI = 3: three quads per lane = 24 registers, which the 192-channel builds do not have -- 7 spilled when tried;
-            // they keep the loads in the loop.)
+            // there the wave parks its 24 + 24 quads in LDS behind its epilogue region -- AB_STASH -- and an item reads its two from there.)
             constexpr bool kHoist = 64 % QPR == 0;
             f32x4 al_ = {1.f, 1.f, 1.f, 1.f}, be_ = {0.f, 0.f, 0.f, 0.f};
             if constexpr (kHoist) {
@@ -796,6 +806,11 @@ __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
                     al_ = *reinterpret_cast<const f32x4*>(a.alpha + co_l);
                     be_ = *reinterpret_cast<const f32x4*>(a.beta + co_l);
                 }
+            } else if (a.alpha && ln < 2 * QPR) {   // lanes 0 .. 23: alpha quads, 24 .. 47: beta quads
+                const int qd_l = ln < QPR ? ln : ln - QPR, co_l = j0 + WC * wc + 4 * qd_l;
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (co_l < a.Cout) t = *reinterpret_cast<const f32x4*>((ln < QPR ? a.alpha : a.beta) + co_l);
+                *reinterpret_cast<f32x4*>(AB_STASH + 4 * ln) = t;
             }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
@@ -831,7 +846,7 @@ __global__ __launch_bounds__(CNT, 2) void conv_halo_kernel(const ConvPArgs a)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = tv[e] * kOutScale;
                             if (a.alpha) {
-                                const f32x4 al4 = kHoist ? al_ : *reinterpret_cast<const f32x4*>(a.alpha + co), be4 = kHoist ? be_ : *reinterpret_cast<const f32x4*>(a.beta + co);
+                                const f32x4 al4 = kHoist ? al_ : *reinterpret_cast<const f32x4*>(AB_STASH + 4 * qd), be4 = kHoist ? be_ : *reinterpret_cast<const f32x4*>(AB_STASH + 4 * (QPR + qd));
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = v[e] * al4[e] + be4[e];
                             }

@@ -16,4 +16,4 @@ print("$v", d["value"], d["ms_per_step"], "conv", k["conv"]["ms_per_step"], "gem
 PY
 done
 done
-PYTHONPATH=. python tools/probe_conv_timeline.py 2>&1 | tail -12 | cut -c1-200
+PYTHONPATH=. python tools/probe_conv_timeline.py 2>&1 | tail -8 | cut -c1-60,150-420; GIGAPOSE_LIB=gigapose_amd/libbase.so GP_LIB=gigapose_amd/libbase.so PYTHONPATH=. python tools/probe_conv_timeline.py 2>&1 | tail -8 | cut -c1-60,150-420

@@ -4,7 +4,7 @@ O=gpurun_out/r06_epi
 mkdir -p $O
 echo "new:";  python tools/feature_hash.py 2>&1 | tail -3
 echo "base:"; GIGAPOSE_LIB=gigapose_amd/libbase.so python tools/feature_hash.py 2>&1 | tail -3
-timeout 1200 python -m pytest tests/test_gpu_split.py tests/test_gpu_conv.py tests/test_gpu_pose_ist.py tests/test_gpu_guards.py -x -q 2>&1 | tail -3
+timeout 1200 python -m pytest tests/test_gpu_split.py tests/test_gpu_vit.py tests/test_gpu_plane_scales.py tests/test_gpu_guards.py -x -q 2>&1 | tail -3
 for r in 1 2 3; do
 for v in new base; do
 L=gigapose_amd/libgigapose_hip.so; [ $v = base ] && L=gigapose_amd/libbase.so
@@ -16,4 +16,4 @@ print("$v", d["value"], d["ms_per_step"], "conv", k["conv"]["ms_per_step"], "gem
 PY
 done
 done
-PYTHONPATH=. python tools/probe_conv_timeline.py 2>&1 | tail -8 | cut -c1-60,150-420; GIGAPOSE_LIB=gigapose_amd/libbase.so GP_LIB=gigapose_amd/libbase.so PYTHONPATH=. python tools/probe_conv_timeline.py 2>&1 | tail -8 | cut -c1-60,150-420
+PYTHONPATH=. python tools/probe_planes_timeline.py 2>&1 | grep -E "^(qkv|proj|fc1|fc2)" | cut -c1-130,330-520

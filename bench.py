@@ -346,14 +346,16 @@ def main():
         model.enable_template_sharding()  # world 1: only meaningful with GIGAPOSE_FORCE_COLLECTIVES=1 (path check)
     model.template_datasets = {"syn": tset}
     kinds = 8
-    SAMPLE_STRIDE = 5  # coprime with the 4 plane-GEMM launches of a ViT layer: the sample cycles through q|k|v, proj, fc1, fc2
+    # coprime with the 4 plane-GEMM launches of a ViT layer: the sample cycles through q|k|v, proj, fc1, fc2.  13 (round 6; 5 before): an event pair
+    # costs the launch stream ~11 us of idle time around the sampled launch (rocprofv3: 0.21 ms of a 40 ms step at one in 5); ~7 samples per step
+    SAMPLE_STRIDE = 13
 
     def step():
         return model.predict(q["tar_img"], q["tar_mask"], q["tar_K"], q["tar_M"], q["labels"], "syn")
 
     def timed(steps, profile):
         """profile: None = no events; "all" = HIP events around every launch (per-family table; costs ~3 us per launch);
-        ("sampled", kind_name) = events around one in 5 launches of the dominant family only -- what THE timed region uses."""
+        ("sampled", kind_name) = events around one in SAMPLE_STRIDE launches of the dominant family only -- what THE timed region uses."""
         if world > 1:
             dist.barrier()
         sync()

@@ -632,8 +632,9 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
     _Float16* sKp = pl ? sKl : sKh;
     unsigned* sVp = reinterpret_cast<unsigned*>(pl ? sVl : sVh);
     const bool odd = (lane & 8) != 0;  // key parity: piece c = t8 + 256 i -> key = c >> 3
-    au32x4 kv[3], vv[3];
-    auto load_chunk = [&](int c3) __attribute__((always_inline)) {
+    // two register sets (round 6): chunk c + 1 is requested before chunk c is written to LDS -- three dependent round trips became one and a bit
+    au32x4 kvA[3], vvA[3], kvB[3], vvB[3];
+    auto load_chunk = [&](int c3, au32x4 (&kv)[3], au32x4 (&vv)[3]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int c = t8 + 256 * (3 * c3 + u), key = c >> 3, ch8 = c & 7;
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
             }
         }
     };
-    auto store_chunk = [&](int c3) __attribute__((always_inline)) {
+    auto store_chunk = [&](int c3, au32x4 (&kv)[3], au32x4 (&vv)[3]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int c = t8 + 256 * (3 * c3 + u), key = c >> 3, ch8 = c & 7;
@@ -664,7 +665,8 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
             }
         }
     };
-    load_chunk(0);
+    load_chunk(0, kvA, vvA);
+    load_chunk(1, kvB, vvB);
     for (int c = tid; c < 2 * (AKEYS - T_TOK - 1) * 8; c += ATH) {  // keys 258..287: zero rows (masked below)
         const int plane = c >= (AKEYS - T_TOK - 1) * 8 ? 1 : 0, r = c - plane * (AKEYS - T_TOK - 1) * 8;
         *reinterpret_cast<au32x4*>((plane ? sKl : sKh) + (T_TOK + 1 + (r >> 3)) * AKS + 8 * (r & 7)) = au32x4{0u, 0u, 0u, 0u};
@@ -683,11 +685,10 @@ __global__ __launch_bounds__(ATH) void attention_split_kernel(const _Float16* __
         const size_t q256 = (tok0 + (T_TOK - 1)) * ld + h * 64 + tid;
         xq[tid] = (float)QKVhi[q256] + (float)QKVlo[q256];
     }
-    store_chunk(0);
-    load_chunk(1);
-    store_chunk(1);
-    load_chunk(2);
-    store_chunk(2);
+    store_chunk(0, kvA, vvA);
+    load_chunk(2, kvA, vvA);
+    store_chunk(1, kvB, vvB);
+    store_chunk(2, kvA, vvA);
     __syncthreads();
 
     f32x16 o0, o1;

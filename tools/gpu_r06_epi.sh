@@ -12,8 +12,7 @@ GIGAPOSE_LIB=$L python bench.py --steps 20 --no-cpu-baseline --no-configs --no-o
 python - <<PY
 import json
 d=json.load(open("$O/bench_${v}_$r.json")); k=d["roofline"]["kernels"]
-print("$v", d["value"], d["ms_per_step"], "conv", k["conv"]["ms_per_step"], "gemm_split", k["gemm_split"]["ms_per_step"], d["roofline"]["executed_tflops"], d["roofline"]["sustained_mfma_only_tflops"], {b: d["batch_curve"][b]["value"] for b in ("b8","b16","b32")} if "batch_curve" in d else "")
+print("$v", d["value"], d["ms_per_step"], "attention", k["attention"]["ms_per_step"], "gemm_split", k["gemm_split"]["ms_per_step"], d["roofline"]["executed_tflops"], d["roofline"]["sustained_mfma_only_tflops"], {b: d["batch_curve"][b]["value"] for b in ("b8","b16","b32")} if "batch_curve" in d else "")
 PY
 done
 done
-PYTHONPATH=. python tools/probe_planes_timeline.py 2>&1 | grep -E "^(qkv|proj|fc1|fc2)" | cut -c1-130,330-520

@@ -274,6 +274,19 @@ __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
         if (wave == 0) { g_split_wall[0] = __builtin_readcyclecounter() - blk_c0; g_split_wall[1] = wall_clock64() - blk_w0; }
     }
 
+    // The 32 bias rows of a lane, loaded ONCE (round 6): inside the element loop each was a 4-byte load + s_waitcnt vmcnt(0) between two stores
+    // (D may alias bias as far as hipcc knows) -- 64 dependent round trips per tile, each also waiting for the previous element's store; the
+    // tile epilogue cost more than the k loop of the IST heads' K = 256 / 512 GEMMs.
+    constexpr bool kBiasI = EPI == SEPI_BIAS_I || EPI == SEPI_BIAS_I_GELU || EPI == SEPI_BIAS_I_SCALE_RES || EPI == SEPI_BIAS_I_RELU;
+    f32x4 bias_q[2][4];
+    if (kBiasI) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) bias_q[mi][r4] = *reinterpret_cast<const f32x4*>(a.bias + i0 + wm * 64 + mi * 32 + frag_row(4 * r4, lane));
+        asm volatile("" : "+v"(bias_q[0][0]), "+v"(bias_q[0][1]), "+v"(bias_q[0][2]), "+v"(bias_q[0][3]), "+v"(bias_q[1][0]), "+v"(bias_q[1][1]),
+                          "+v"(bias_q[1][2]), "+v"(bias_q[1][3]));
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -283,8 +296,7 @@ __global__ __launch_bounds__(SNT, 2) void gemm_split_kernel(const SplitArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int i = i0 + wm * 64 + mi * 32 + frag_row(r, lane);
                 float v = hh[mi][ni][r] + xx[mi][ni][r] * kLoInv;
-                if (EPI == SEPI_BIAS_I || EPI == SEPI_BIAS_I_GELU || EPI == SEPI_BIAS_I_SCALE_RES || EPI == SEPI_BIAS_I_RELU)
-                    v = v + a.bias[i];
+                if (kBiasI) v = v + bias_q[mi][r >> 2][r & 3];
                 if (EPI == SEPI_BIAS_J) v = v + a.bias[j];
                 if (EPI == SEPI_BIAS_I_GELU) v = gelu_erf_s(v);
                 if (EPI == SEPI_BIAS_I_RELU) v = fmaxf(v, 0.f);
